@@ -1,0 +1,248 @@
+/* madarch_hip.h -- C ABI of libmadarch_hip.so, the MI355X (gfx950) back end
+ * that replaces the OpenGL/GLSL dispatch of Madarch.Renderers.
+ *
+ * Every entry point below stands for one public operation of the reference
+ * package `Madarch.Renderers` (madarch/madarch-renderers.ads:21-97) or for an
+ * output of `Madarch.Scenes.Compile` (madarch/madarch-scenes.ads:47-76); the
+ * reference file:line each one replaces is cited next to it.  An Ada body of
+ * Madarch.Renderers binds these with `pragma Import (C, ...)` (see
+ * INTEGRATION.md and ada/).
+ *
+ * Conventions (mirroring the reference):
+ *  - plain pointers and sizes only; the library copies everything on call and
+ *    keeps no caller pointer;
+ *  - every function returns an int32 status, 0 = ok; the text of the last
+ *    error of the calling thread is returned by mdh_last_error();
+ *  - a handle is NOT thread safe (the reference is single threaded and calls
+ *    Make_Current on every entry, madarch-renderers.adb:170,304);
+ *  - primitives and lights are 1-based (Ada `Positive`), materials 0-based
+ *    (`Materials.Id`, madarch-renderers.adb:349-367);
+ *  - GL.Types.Single = float, GL.Types.Int = int32_t, Singles.Vector3 = 3
+ *    contiguous floats, Singles.Matrix3 = 9 floats passed COLUMN-major;
+ *  - entity blobs use the std140 element layout the reference computes in
+ *    GPU_Types (support/gpu_types-structs.adb:23-38): vec3 aligned to 16,
+ *    float/int aligned to 4, fields in declared component order.
+ */
+#ifndef MADARCH_HIP_H
+#define MADARCH_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mdh_renderer mdh_renderer; /* opaque; = access Renderer_Internal (renderers.ads:109-145) */
+
+/* status codes; the Ada body raises Program_Error / Constraint_Error from them */
+enum {
+   MDH_OK = 0,
+   MDH_E_INVALID = 1,          /* bad argument (null pointer, negative size, ...)            */
+   MDH_E_PROBE_MISMATCH = 2,   /* Program_Error "Probe_Count should match grid dimensions."
+                                  (madarch-renderers.adb:63-65)                               */
+   MDH_E_UNSUPPORTED_KIND = 3, /* primitive/light kind that is not a built-in one             */
+   MDH_E_INDEX = 4,            /* Constraint_Error: index out of the declared range           */
+   MDH_E_DEVICE = 5,           /* a HIP call failed (text in mdh_last_error)                  */
+   MDH_E_NO_DEVICE = 6,        /* no gfx950 device visible: the library never falls back to
+                                  the CPU                                                     */
+   MDH_E_STATE = 7             /* call not valid in this state (e.g. partitioning disabled)   */
+};
+
+/* = Madarch.Values.Value_Kind order (madarch-values.ads:8) */
+typedef enum { MDH_VEC3 = 0, MDH_FLOAT = 1, MDH_INT = 2 } mdh_kind;
+
+/* = Madarch.Components.Component (name, kind)  (madarch-components.ads) */
+typedef struct {
+   const char *name;
+   int32_t kind; /* mdh_kind */
+} mdh_component;
+
+/* One primitive or light kind with its declared maximum:
+ * Scenes.Primitive_Count / Light_Count (madarch-scenes.ads:15-23).  Built-in
+ * names: "Sphere", "Plane", "Box", "Triangle" (madarch-primitives-*.ads),
+ * "PointLight", "SpotLight" (madarch-lights-*.ads). */
+typedef struct {
+   const char *name;
+   int32_t max_count;
+   int32_t n_components;
+   const mdh_component *components;
+} mdh_kind_decl;
+
+/* = Scenes.Partitioning_Settings (madarch-scenes.ads:30-41) */
+typedef struct {
+   int32_t enable;
+   int32_t index_count;
+   int32_t border_behavior; /* 0 Clamp, 1 Fallback (scenes.ads:28) */
+   int32_t grid_dimensions[3];
+   float grid_spacing[3];
+   float grid_offset[3];
+} mdh_partitioning;
+
+/* = Renderers.Probe_Settings (madarch-renderers.ads:23-29) */
+typedef struct {
+   int32_t radiance_resolution;
+   int32_t irradiance_resolution;
+   int32_t probe_count[2];
+   int32_t grid_dimensions[3];
+   float grid_spacing[3];
+} mdh_probe_settings;
+
+/* = Renderers.Volumetrics_Settings (madarch-renderers.ads:33-41) */
+typedef struct {
+   int32_t enabled;
+   int32_t visibility_resolution[3];
+   float visibility_step_size;
+   int32_t scattering_resolution[2];
+   float scattering_step_size;
+} mdh_volumetrics;
+
+/* = the arguments of Scenes.Compile (madarch-scenes.ads:47-53) */
+typedef struct {
+   int32_t n_prim_kinds;
+   const mdh_kind_decl *prim_kinds;
+   int32_t n_light_kinds;
+   const mdh_kind_decl *light_kinds;
+   mdh_partitioning partitioning;
+   float max_dist;
+   int32_t loop_strategy; /* 0 Split, 1 Unify (scenes.ads:45); same results, kept for the record */
+} mdh_scene_desc;
+
+/* ---- options: switches the reference fixes at shader-compile time (the M_*
+ * macros of madarch-renderers.adb:109-143) or that the headless build adds ---- */
+enum {
+   /* atlas storage: 0 = RGB8 as the reference (render_passes.adb:94), 1 = fp32 */
+   MDH_OPT_ATLAS_FORMAT = 0,
+   /* screen pass content: 0 = full pixel_color_probes as draw_screen.glsl;
+    * 1 = BASELINE config 1 (primary ray only, colour 0.5 n + 0.5, no tonemap);
+    * 2 = BASELINE config 2 (direct PBR + AO, irradiance = 0, no indirect specular) */
+   MDH_OPT_SCREEN_MODE = 1,
+   /* M_AMBIENT_OCCLUSION_STEPS of the screen pass (default 3, renderers.adb:140) */
+   MDH_OPT_AO_STEPS = 2,
+   /* 1 = also write the primary-ray geometry buffer (hit index, t, steps) */
+   MDH_OPT_GBUFFER = 3,
+   /* image/probe sharding for one-process-per-GPU runs: this renderer draws the
+    * screen tiles and probe slices of `rank` out of `world` (default 0 / 1) */
+   MDH_OPT_RANK = 4,
+   MDH_OPT_WORLD = 5,
+   /* 1 = record HIP events around every pass (read with mdh_pass_time) */
+   MDH_OPT_TIMING = 6,
+   /* Eval_Distance_To arithmetic: 1 = reproduce Madarch.Values."/" on floats
+    * (L + R, madarch-values.adb:112) as the Ada evaluator does; 0 = GLSL "/" */
+   MDH_OPT_ADA_EVAL_DIV = 7
+};
+
+/* passes of Renderers.Render (madarch-renderers.adb:302-321) */
+enum {
+   MDH_PASS_RADIANCE = 0,   /* compute_probe_radiance.glsl        */
+   MDH_PASS_IRRADIANCE = 1, /* update_probe_irradiance.glsl       */
+   MDH_PASS_VISIBILITY = 2, /* compute_frustrum_visibility.glsl   */
+   MDH_PASS_SCATTERING = 3, /* accumulate_scattering.glsl         */
+   MDH_PASS_SCREEN = 4,     /* draw_screen.glsl                   */
+   MDH_PASS_COUNT = 5
+};
+
+/* atlases / textures of the renderer (texture units 0-3, renderers.adb:239-279) */
+enum { MDH_TEX_RADIANCE = 0, MDH_TEX_IRRADIANCE = 1, MDH_TEX_VISIBILITY = 2, MDH_TEX_SCATTERING = 3 };
+
+/* Renderers.Create (madarch-renderers.adb:91-300) together with Scenes.Compile
+ * (madarch-scenes.adb:1378-1421).  `width`/`height` replace the window size
+ * (Windows.Open; the build is headless).  `device` is the HIP device ordinal
+ * (one process per GPU: pass LOCAL_RANK). */
+int32_t mdh_create(int32_t width, int32_t height, const mdh_scene_desc *scene,
+                   const mdh_probe_settings *probes, const mdh_volumetrics *volumetrics,
+                   int32_t device, mdh_renderer **out);
+
+/* the reference never frees a Renderer; explicit release is new and harmless */
+int32_t mdh_destroy(mdh_renderer *r);
+
+int32_t mdh_set_option(mdh_renderer *r, int32_t option, int32_t value);
+int32_t mdh_get_option(mdh_renderer *r, int32_t option, int32_t *value);
+
+/* Renderers.Set_Material (madarch-renderers.adb:349-367); id is 0-based */
+int32_t mdh_set_material(mdh_renderer *r, int32_t id0, const float albedo[3], float metallic,
+                         float roughness);
+/* Renderers.Add_Material (madarch-renderers.adb:369-377) */
+int32_t mdh_add_material(mdh_renderer *r, const float albedo[3], float metallic, float roughness,
+                         int32_t *out_id0);
+
+/* Renderers.Set_Primitive (madarch-renderers.adb:379-398); index1 is 1-based */
+int32_t mdh_set_primitive(mdh_renderer *r, int32_t kind_ix, int32_t index1, const void *std140_blob,
+                          int32_t nbytes);
+/* Renderers.Add_Primitive (madarch-renderers.adb:435-456) */
+int32_t mdh_add_primitive(mdh_renderer *r, int32_t kind_ix, const void *std140_blob, int32_t nbytes,
+                          int32_t *out_count);
+/* Renderers.Set_Light (madarch-renderers.adb:458-483): also sets the kind's
+ * count and total_light_count to index1, as the reference does */
+int32_t mdh_set_light(mdh_renderer *r, int32_t index1, int32_t light_kind_ix, const void *std140_blob,
+                      int32_t nbytes);
+
+/* Renderers.Set_Camera_Position / Set_Camera_Orientation (renderers.adb:485-497) */
+int32_t mdh_set_camera_position(mdh_renderer *r, const float p[3]);
+int32_t mdh_set_camera_orientation(mdh_renderer *r, const float m_colmajor[9]);
+
+/* Renderers.Update_Partitioning (madarch-renderers.adb:757-775);
+ * method: 0 CPU_Best, 1 CPU_Fast, 2 GPU_Fast (renderers.ads:93) */
+int32_t mdh_update_partitioning(mdh_renderer *r, int32_t method);
+
+/* Renderers.Render (madarch-renderers.adb:302-321): enqueues all passes of one
+ * frame on the renderer's stream.  mdh_finish waits for them. */
+int32_t mdh_render(mdh_renderer *r);
+/* one pass only (for one-process-per-GPU runs that exchange atlas slices
+ * between the passes, see DESIGN.md "Multi-GPU") */
+int32_t mdh_render_pass(mdh_renderer *r, int32_t pass);
+int32_t mdh_finish(mdh_renderer *r);
+
+/* replaces Swap_Buffers (renderers.adb:320): linear RGB floats, H*W*3, row 0 = top.
+ * In a sharded run only this rank's tiles are written, the rest is 0. */
+int32_t mdh_read_framebuffer(mdh_renderer *r, float *rgb_out);
+/* primary-ray geometry buffer (needs MDH_OPT_GBUFFER): per pixel the flat
+ * primitive index of closest_primitive_info (-1 = miss), the march length t
+ * and the number of SDF evaluations of the primary march */
+int32_t mdh_read_gbuffer(mdh_renderer *r, int32_t *index_out, float *t_out, int32_t *steps_out);
+
+/* texture contents as the reference's 2-D images (row 0 = normalised y of 0),
+ * `channels` floats per texel (3, or 4 for scattering); out may be NULL to
+ * query the size only */
+int32_t mdh_read_texture(mdh_renderer *r, int32_t tex, float *out, int32_t *width, int32_t *height,
+                         int32_t *channels);
+/* deterministic warm start / checkpoint of the DDGI state (same layout) */
+int32_t mdh_write_texture(mdh_renderer *r, int32_t tex, const float *in, int32_t width, int32_t height,
+                          int32_t channels);
+
+/* device-resident atlas slices for the RCCL all-gather of a sharded run:
+ * pointer to the probe-major atlas, its total byte size and the byte range
+ * [offset, offset+bytes) this rank owns */
+int32_t mdh_atlas_device_ptr(mdh_renderer *r, int32_t tex, void **dptr, int64_t *total_bytes,
+                             int64_t *own_offset, int64_t *own_bytes);
+/* the HIP stream (hipStream_t) every pass is enqueued on */
+int32_t mdh_stream(mdh_renderer *r, void **stream);
+
+/* Renderers.Eval_Distance_To (madarch-renderers.adb:499-526), batched: for
+ * each of n points the closest distance over the listed kinds (initial
+ * closest 1.0e10) and the normal of the arg-min primitive.  n = 1 is the
+ * reference call. */
+int32_t mdh_eval_distance_to(mdh_renderer *r, int32_t n, const float *points_xyz,
+                             const int32_t *kind_ixs, int32_t n_kinds, float *normals_xyz_out,
+                             float *dist_out);
+
+/* accumulated HIP-event time and launch count of one pass (MDH_OPT_TIMING) */
+int32_t mdh_pass_time(mdh_renderer *r, int32_t pass, double *total_ms, int64_t *launches);
+int32_t mdh_reset_pass_times(mdh_renderer *r);
+
+/* std140 layout queries = Scenes.Get_Primitives_Location / Get_Lights_Location
+ * (madarch-scenes.adb:1435-1462) and Get_GPU_Type(...).Size */
+int32_t mdh_scene_layout(mdh_renderer *r, int32_t is_light, int32_t kind_ix, int32_t *count_offset,
+                         int32_t *array_offset, int32_t *stride, int32_t *element_size);
+int32_t mdh_scene_buffer_size(mdh_renderer *r, int32_t *size, int32_t *total_light_count_offset);
+/* raw std140 image of the scene uniform block (binding 1) for inspection */
+int32_t mdh_read_scene_buffer(mdh_renderer *r, void *out, int32_t nbytes);
+/* partition table as int32 [cell][n_prim_kinds counts + index_count indices] */
+int32_t mdh_read_partitioning(mdh_renderer *r, int32_t *out, int32_t n_ints);
+
+const char *mdh_last_error(void);
+const char *mdh_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MADARCH_HIP_H */

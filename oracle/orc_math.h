@@ -1,0 +1,97 @@
+/* orc_math.h -- TEST INFRASTRUCTURE (CPU oracle), not product code.
+ *
+ * fp32 scalar/vec3 arithmetic with the semantics the oracle fixes for the GLSL
+ * built-ins the reference's shaders use and for Math_Utils
+ * (/root/reference/madarch/support/math_utils.ads:12-93).  PARITY UNPINNED: the
+ * reference holds no numeric fixture for any of these;
+ * where GLSL leaves precision or operation order to the driver the choice made
+ * here is written next to the function and is the one the HIP kernels follow.
+ *
+ * Build with -ffp-contract=off and without -ffast-math: every operation below
+ * is one correctly rounded IEEE binary32 operation, in the order written.
+ */
+#ifndef ORC_MATH_H
+#define ORC_MATH_H
+
+#include <math.h>
+#include <stdint.h>
+
+typedef struct { float x, y, z; } v3;
+typedef struct { float x, y; } v2;
+typedef struct { int x, y, z; } iv3;
+
+#define ORC_INLINE static inline __attribute__((always_inline))
+
+/* maths.glsl:1-3 */
+#define ORC_PI 3.14159265358f
+#define ORC_EPSILON 0.001f
+/* raymarching.glsl:1 */
+#define ORC_MIN_STEP 0.05f
+
+ORC_INLINE v3 V3(float x, float y, float z) { v3 r = {x, y, z}; return r; }
+ORC_INLINE v3 v3s(float s) { return V3(s, s, s); }
+ORC_INLINE v2 V2(float x, float y) { v2 r = {x, y}; return r; }
+
+/* GLSL min/max (GLSL 4.30 8.3: y < x ? y : x, undefined for NaN).  The oracle
+ * fixes the NaN case as IEEE 754-2008 minNum/maxNum -- a NaN operand is
+ * ignored -- which is what the gfx950 v_min_f32/v_max_f32 the kernels use do. */
+ORC_INLINE float fmin_(float a, float b) { return (a != a) ? b : (b != b) ? a : (b < a) ? b : a; }
+ORC_INLINE float fmax_(float a, float b) { return (a != a) ? b : (b != b) ? a : (a < b) ? b : a; }
+ORC_INLINE float clamp_(float x, float lo, float hi) { return fmin_(fmax_(x, lo), hi); }
+ORC_INLINE int imin_(int a, int b) { return b < a ? b : a; }
+ORC_INLINE int imax_(int a, int b) { return a < b ? b : a; }
+ORC_INLINE int iclamp_(int x, int lo, int hi) { return imin_(imax_(x, lo), hi); }
+/* sign(): -1, 0, +1 (GLSL and Math_Utils.Sign, math_utils.ads:12-16) */
+ORC_INLINE float sign_(float x) { return x < 0.0f ? -1.0f : (x > 0.0f ? 1.0f : 0.0f); }
+ORC_INLINE float fract_(float x) { return x - floorf(x); }
+/* mix(x,y,a) = x*(1-a) + y*a (GLSL 4.30 8.3) */
+ORC_INLINE float mix_(float x, float y, float a) { return x * (1.0f - a) + y * a; }
+
+ORC_INLINE v3 add(v3 a, v3 b) { return V3(a.x + b.x, a.y + b.y, a.z + b.z); }
+ORC_INLINE v3 sub(v3 a, v3 b) { return V3(a.x - b.x, a.y - b.y, a.z - b.z); }
+ORC_INLINE v3 mul(v3 a, v3 b) { return V3(a.x * b.x, a.y * b.y, a.z * b.z); }
+ORC_INLINE v3 vdiv(v3 a, v3 b) { return V3(a.x / b.x, a.y / b.y, a.z / b.z); }
+ORC_INLINE v3 scale(v3 a, float s) { return V3(a.x * s, a.y * s, a.z * s); }
+ORC_INLINE v3 divs(v3 a, float s) { return V3(a.x / s, a.y / s, a.z / s); }
+ORC_INLINE v3 adds(v3 a, float s) { return V3(a.x + s, a.y + s, a.z + s); }
+ORC_INLINE v3 neg(v3 a) { return V3(-a.x, -a.y, -a.z); }
+ORC_INLINE v3 vabs(v3 a) { return V3(fabsf(a.x), fabsf(a.y), fabsf(a.z)); }
+ORC_INLINE v3 vmaxs(v3 a, float s) { return V3(fmax_(a.x, s), fmax_(a.y, s), fmax_(a.z, s)); }
+ORC_INLINE v3 vmins(v3 a, float s) { return V3(fmin_(a.x, s), fmin_(a.y, s), fmin_(a.z, s)); }
+ORC_INLINE v3 vfloor(v3 a) { return V3(floorf(a.x), floorf(a.y), floorf(a.z)); }
+ORC_INLINE v3 vsqrt(v3 a) { return V3(sqrtf(a.x), sqrtf(a.y), sqrtf(a.z)); }
+
+/* dot: left-to-right sum of the three products, as Singles.Dot_Product is
+ * taken to be (OpenGLAda is not vendored; math_utils.ads:55-56) */
+ORC_INLINE float dot(v3 a, v3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+ORC_INLINE float dot2(v3 a) { return dot(a, a); } /* maths.glsl:5-7 */
+/* length = sqrt(dot2) (math_utils.ads:77-79) */
+ORC_INLINE float length(v3 a) { return sqrtf(dot2(a)); }
+/* normalize = v / length(v), a true division per component (math_utils.ads:81-83) */
+ORC_INLINE v3 normalize(v3 a) { return divs(a, length(a)); }
+ORC_INLINE v3 cross(v3 a, v3 b)
+{
+   return V3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+/* reflect(I,N) = I - 2 dot(N,I) N (GLSL 4.30 8.5) */
+ORC_INLINE v3 reflect(v3 i, v3 n) { return sub(i, scale(n, 2.0f * dot(n, i))); }
+
+/* Transcendentals.  GLSL gives them implementation-defined precision; the
+ * oracle fixes them as the correctly rounded fp32 value, obtained by
+ * evaluating in fp64 and rounding once (the kernels do the same through the
+ * fp64 ocml functions).  Small literal integer powers are fixed as repeated
+ * multiplication (below). */
+ORC_INLINE float exp_(float x) { return (float)exp((double)x); }
+ORC_INLINE float acos_(float x) { return (float)acos((double)x); }
+ORC_INLINE float pow_(float x, float y) { return (float)pow((double)x, (double)y); }
+/* pow(x, 5.0) of fresnel_schlick (cook_torrance_brdf.glsl:2) */
+ORC_INLINE float pow5_(float x) { float x2 = x * x; return (x2 * x2) * x; }
+/* pow(x, 8.0) of the spot light (madarch-lights-spot_lights.adb:18) */
+ORC_INLINE float pow8_(float x) { float x2 = x * x; float x4 = x2 * x2; return x4 * x4; }
+/* pow(x, 1.5) of henvey_greenstein_phase (volumetrics.glsl:25-28) */
+ORC_INLINE float pow1_5_(float x) { return x * sqrtf(x); }
+
+ORC_INLINE float f_of_bits(uint32_t u) { union { uint32_t u; float f; } c; c.u = u; return c.f; }
+ORC_INLINE uint32_t bits_of_f(float f) { union { uint32_t u; float f; } c; c.f = f; return c.u; }
+
+#endif
