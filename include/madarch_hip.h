@@ -209,6 +209,12 @@ int32_t mdh_read_texture(mdh_renderer *r, int32_t tex, float *out, int32_t *widt
 int32_t mdh_write_texture(mdh_renderer *r, int32_t tex, const float *in, int32_t width, int32_t height,
                           int32_t channels);
 
+/* probe-major atlas slices through host memory, [probe][res][res][3] floats:
+ * the exchange step of a sharded run when the ranks have no device collective */
+int32_t mdh_read_atlas_slice(mdh_renderer *r, int32_t tex, int32_t probe_begin, int32_t n_probes, float *out);
+int32_t mdh_write_atlas_slice(mdh_renderer *r, int32_t tex, int32_t probe_begin, int32_t n_probes,
+                              const float *in);
+
 /* device-resident atlas slices for the RCCL all-gather of a sharded run:
  * pointer to the probe-major atlas, its total byte size and the byte range
  * [offset, offset+bytes) this rank owns */
@@ -238,6 +244,9 @@ int32_t mdh_scene_buffer_size(mdh_renderer *r, int32_t *size, int32_t *total_lig
 int32_t mdh_read_scene_buffer(mdh_renderer *r, void *out, int32_t nbytes);
 /* partition table as int32 [cell][n_prim_kinds counts + index_count indices] */
 int32_t mdh_read_partitioning(mdh_renderer *r, int32_t *out, int32_t n_ints);
+/* cells of the last Update_Partitioning whose candidate list overflowed Index_Count
+ * (the reference prints "Warning : partition size too small", renderers.adb:593-598) */
+int32_t mdh_partition_warnings(mdh_renderer *r);
 
 const char *mdh_last_error(void);
 const char *mdh_version(void);

@@ -105,6 +105,7 @@ ABI = {
     "scene_buffer_size": (_I, [_P, _PI, _PI]),
     "read_scene_buffer": (_I, [_P, _P, _I]),
     "read_partitioning": (_I, [_P, _P, _I]),
+    "partition_warnings": (_I, [_P]),
     "last_error": (C.c_char_p, []),
     "version": (C.c_char_p, []),
 }

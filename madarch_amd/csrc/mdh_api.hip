@@ -1,0 +1,905 @@
+// mdh_api.hip -- libmadarch_hip.so: the C ABI of include/madarch_hip.h.
+//
+// Host side of the MI355X back end: what Madarch.Renderers does with OpenGL
+// objects (reference madarch/madarch-renderers.adb:91-497, support/gpu_buffers.adb,
+// support/render_passes.adb) is done here with HIP memory, one stream per renderer
+// and the kernels of mdh_kernels.h.  There is no CPU rendering path: without a
+// gfx950 device mdh_create fails with MDH_E_NO_DEVICE.
+#include "../../include/madarch_hip.h"
+#include "mdh_kernels.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+static thread_local char g_err[512];
+static int seterr(int code, const char *msg)
+{
+   snprintf(g_err, sizeof g_err, "%s", msg);
+   return code;
+}
+#define HIP_TRY(expr)                                                                               \
+   do {                                                                                             \
+      hipError_t e_ = (expr);                                                                       \
+      if (e_ != hipSuccess) {                                                                       \
+         snprintf(g_err, sizeof g_err, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+         return MDH_E_DEVICE;                                                                       \
+      }                                                                                             \
+   } while (0)
+
+extern "C" const char *mdh_last_error(void) { return g_err; }
+extern "C" const char *mdh_version(void) { return "madarch-hip 0.1 (gfx950)"; }
+
+// ------------------------------------------------------------------ std140 layout
+// = GPU_Types (support/gpu_types-base.ads:21-37, gpu_types-structs.adb:11-38,
+// gpu_types-fixed_arrays.adb:17-39)
+static int pad_to(int x, int a) { while (x % a) ++x; return x; }
+static int base_align(int kind) { return kind == MDH_VEC3 ? 16 : 4; }
+static int base_size(int kind) { return kind == MDH_VEC3 ? 12 : 4; }
+
+struct Kind {
+   int type = -1, max_count = 0, ncomp = 0;
+   std::string comp_name[8];
+   int comp_kind[8], comp_off[8];
+   int elem_size = 0, stride = 0, count_off = 0, array_off = 0;
+   int f_a = -1, f_b = -1, f_c = -1, f_d = -1; // resolved field offsets
+   int offset_of(const char *name, int kind) const
+   {
+      for (int i = 0; i < ncomp; ++i)
+         if (comp_name[i] == name && comp_kind[i] == kind) return comp_off[i];
+      return -1;
+   }
+};
+
+static bool resolve_kind(Kind &k, const mdh_kind_decl &d, bool is_light)
+{
+   static const char *P[4] = {"Sphere", "Plane", "Box", "Triangle"};
+   static const char *L[2] = {"PointLight", "SpotLight"};
+   if (!d.name || !d.components) return false;
+   k.type = -1;
+   for (int t = 0; t < (is_light ? 2 : 4); ++t)
+      if (strcmp(d.name, is_light ? L[t] : P[t]) == 0) k.type = t;
+   if (k.type < 0 || d.n_components < 1 || d.n_components > 8 || d.max_count < 0) return false;
+   k.max_count = d.max_count;
+   k.ncomp = d.n_components;
+   int off = 0;
+   for (int i = 0; i < k.ncomp; ++i) {
+      k.comp_name[i] = d.components[i].name ? d.components[i].name : "";
+      k.comp_kind[i] = d.components[i].kind;
+      off = pad_to(off, base_align(k.comp_kind[i]));
+      k.comp_off[i] = off;
+      off += base_size(k.comp_kind[i]);
+   }
+   k.elem_size = off;
+   k.stride = pad_to(off, 16);
+   if (!is_light) {
+      k.f_d = k.offset_of("material_id", MDH_INT);
+      switch (k.type) {
+      case PK_SPHERE: k.f_a = k.offset_of("center", MDH_VEC3); k.f_b = k.offset_of("radius", MDH_FLOAT); k.f_c = 0; break;
+      case PK_PLANE: k.f_a = k.offset_of("normal", MDH_VEC3); k.f_b = k.offset_of("offset", MDH_FLOAT); k.f_c = 0; break;
+      case PK_BOX: k.f_a = k.offset_of("center", MDH_VEC3); k.f_b = k.offset_of("side", MDH_VEC3); k.f_c = 0; break;
+      default: k.f_a = k.offset_of("v1", MDH_VEC3); k.f_b = k.offset_of("v2", MDH_VEC3); k.f_c = k.offset_of("v3", MDH_VEC3); break;
+      }
+   } else {
+      k.f_a = k.offset_of("position", MDH_VEC3);
+      if (k.type == LK_POINT) { k.f_b = k.offset_of("color", MDH_VEC3); k.f_c = 0; k.f_d = 0; }
+      else { k.f_b = k.offset_of("direction", MDH_VEC3); k.f_c = k.offset_of("aperture", MDH_FLOAT); k.f_d = k.offset_of("color", MDH_VEC3); }
+   }
+   return k.f_a >= 0 && k.f_b >= 0 && k.f_c >= 0 && k.f_d >= 0;
+}
+
+// Single'Image keeps 6 significant digits: literals that reach the shaders through
+// the generated GLSL text are rounded that way (scenes.adb:21-24,1200-1201;
+// renderers.adb:119-134)
+static float image_roundtrip(float x)
+{
+   char buf[64];
+   snprintf(buf, sizeof buf, "%.5E", (double)x);
+   return strtof(buf, nullptr);
+}
+
+// -------------------------------------------------------------------- the renderer
+#define MAX_MATERIALS 20 // glsl/materials.glsl:9
+
+struct mdh_renderer {
+   int W = 0, H = 0, device = 0;
+   hipStream_t stream = nullptr;
+   int npk = 0, nlk = 0;
+   Kind pk[MDH_MAX_KINDS], lk[MDH_MAX_LIGHT_KINDS];
+   int prim_base[MDH_MAX_KINDS] = {0};
+   int host_count[MDH_MAX_KINDS] = {0}; // All_Primitives lengths (renderers.ads:128)
+   float max_dist = 20.0f;
+   mdh_partitioning part{};
+   float pg_spacing[3], pg_offset[3], part_gpu_diag = 0.0f;
+   int part_cells = 0, part_warnings = 0;
+   mdh_probe_settings probes{};
+   mdh_volumetrics vol{};
+   float vstep = 0.1f, sstep = 0.1f;
+   std::vector<uint8_t> scene_ubo; // std140 image of uniform block 1 (scenes.adb:551-600)
+   int total_light_off = 0;
+   uint8_t materials_ubo[16 + 32 * MAX_MATERIALS] = {0}; // renderers.adb:77-89
+   int last_material_index = 0;
+   float cam_pos[3] = {0, 0, 0}, cam_m[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}; // renderers.adb:225-226
+   // options
+   int opt_atlas = 0, opt_mode = 0, opt_ao = 3, opt_gbuffer = 0, opt_rank = 0, opt_world = 1, opt_timing = 0, opt_ada_div = 1;
+   // device state
+   std::vector<float4> table_host;
+   float4 *d_table = nullptr;
+   size_t table_cap = 0;
+   bool table_dirty = true;
+   int *d_part = nullptr, *d_warn = nullptr;
+   void *d_rad = nullptr, *d_irr = nullptr;
+   float *d_vis = nullptr;
+   float4 *d_scat = nullptr, *d_fb = nullptr;
+   int *d_gb_index = nullptr, *d_gb_steps = nullptr;
+   float *d_gb_t = nullptr;
+   KScene ks{};
+   // timing
+   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+   double pass_ms[MDH_PASS_COUNT] = {0};
+   long long pass_n[MDH_PASS_COUNT] = {0};
+};
+
+static int probe_total(const mdh_renderer *r) { return r->probes.probe_count[0] * r->probes.probe_count[1]; }
+static size_t texel_bytes(const mdh_renderer *r) { return r->opt_atlas == 0 ? 4 : 16; }
+static size_t atlas_bytes(const mdh_renderer *r, int tex)
+{
+   int res = tex == MDH_TEX_RADIANCE ? r->probes.radiance_resolution : r->probes.irradiance_resolution;
+   return (size_t)probe_total(r) * res * res * texel_bytes(r);
+}
+static void own_probes(const mdh_renderer *r, int *b, int *e)
+{
+   long long P = probe_total(r);
+   *b = (int)(P * r->opt_rank / r->opt_world);
+   *e = (int)(P * (r->opt_rank + 1) / r->opt_world);
+}
+
+static float rd_f(const mdh_renderer *r, int off) { float f; memcpy(&f, r->scene_ubo.data() + off, 4); return f; }
+static int rd_i(const mdh_renderer *r, int off) { int32_t i; memcpy(&i, r->scene_ubo.data() + off, 4); return i; }
+static float4 mk4(float x, float y, float z, float w) { float4 v; v.x = x; v.y = y; v.z = z; v.w = w; return v; }
+static float4 rd_v3w(const mdh_renderer *r, int off, float w) { return mk4(rd_f(r, off), rd_f(r, off + 4), rd_f(r, off + 8), w); }
+static float i_as_f(int i) { float f; memcpy(&f, &i, 4); return f; }
+
+// Repack the std140 images into the float4 table the kernels stage into LDS
+// (layout in mdh_device.h) and refresh the SGPR header.
+static int commit_scene(mdh_renderer *r)
+{
+   KScene &s = r->ks;
+   s.nk = r->npk;
+   s.nl = r->nlk;
+   s.max_dist = r->max_dist;
+   std::vector<float4> &t = r->table_host;
+   t.clear();
+   for (int k = 0; k < r->npk; ++k) {
+      const Kind &kd = r->pk[k];
+      int n = rd_i(r, kd.count_off);
+      if (n < 0) n = 0;
+      if (n > kd.max_count) n = kd.max_count;
+      s.ktype[k] = kd.type; s.kcount[k] = n; s.kbase[k] = r->prim_base[k]; s.kmax[k] = kd.max_count; s.kslot[k] = (int)t.size();
+      // every DECLARED element is packed: primitive_info gathers by flat index and the
+      // partition table may name any element below the count
+      for (int i = 0; i < kd.max_count; ++i) {
+         int b = kd.array_off + kd.stride * i;
+         float mat = i_as_f(rd_i(r, b + kd.f_d));
+         switch (kd.type) {
+         case PK_SPHERE: t.push_back(rd_v3w(r, b + kd.f_a, rd_f(r, b + kd.f_b))); t.push_back(mk4(0, 0, 0, mat)); break;
+         case PK_PLANE: t.push_back(rd_v3w(r, b + kd.f_a, rd_f(r, b + kd.f_b))); t.push_back(mk4(0, 0, 0, mat)); break;
+         case PK_BOX: t.push_back(rd_v3w(r, b + kd.f_a, 0.0f)); t.push_back(rd_v3w(r, b + kd.f_b, mat)); break;
+         default: t.push_back(rd_v3w(r, b + kd.f_a, mat)); t.push_back(rd_v3w(r, b + kd.f_b, 0.0f)); t.push_back(rd_v3w(r, b + kd.f_c, 0.0f)); break;
+         }
+      }
+   }
+   for (int k = 0; k < r->nlk; ++k) {
+      const Kind &kd = r->lk[k];
+      int n = rd_i(r, kd.count_off);
+      if (n < 0) n = 0;
+      if (n > kd.max_count) n = kd.max_count;
+      s.ltype[k] = kd.type; s.lcount[k] = n; s.lslot[k] = (int)t.size();
+      for (int i = 0; i < kd.max_count; ++i) {
+         int b = kd.array_off + kd.stride * i;
+         if (kd.type == LK_POINT) { t.push_back(rd_v3w(r, b + kd.f_a, 0.0f)); t.push_back(rd_v3w(r, b + kd.f_b, 0.0f)); }
+         else { t.push_back(rd_v3w(r, b + kd.f_a, rd_f(r, b + kd.f_c))); t.push_back(rd_v3w(r, b + kd.f_b, 0.0f)); t.push_back(rd_v3w(r, b + kd.f_d, 0.0f)); }
+      }
+   }
+   s.total_lights = rd_i(r, r->total_light_off);
+   s.mat_slot = (int)t.size();
+   for (int m = 0; m < MAX_MATERIALS; ++m) {
+      float f[5];
+      memcpy(f, r->materials_ubo + 16 + 32 * m, 20);
+      t.push_back(mk4(f[0], f[1], f[2], f[3]));
+      t.push_back(mk4(f[4], 0, 0, 0));
+   }
+   s.table_f4 = (int)t.size();
+   if ((size_t)s.table_f4 * 16 > 64 * 1024) return seterr(MDH_E_INVALID, "scene tables exceed the 64 KiB LDS budget of a workgroup");
+   if (t.size() > r->table_cap) {
+      if (r->d_table) HIP_TRY(hipFree(r->d_table));
+      r->table_cap = t.size() + 64;
+      HIP_TRY(hipMalloc(&r->d_table, r->table_cap * sizeof(float4)));
+   }
+   // the copy is enqueued on the renderer's stream, ahead of the kernels that stage it
+   HIP_TRY(hipMemcpyAsync(r->d_table, t.data(), t.size() * sizeof(float4), hipMemcpyHostToDevice, r->stream));
+   HIP_TRY(hipStreamSynchronize(r->stream)); // table_host may be rebuilt by the next call
+   s.table = r->d_table;
+   s.part_enable = r->part.enable;
+   s.part_border = r->part.border_behavior;
+   s.part_index_count = r->part.index_count;
+   s.part_cells = r->part_cells;
+   for (int a = 0; a < 3; ++a) { s.part_dims[a] = r->part.grid_dimensions[a]; s.part_sp[a] = r->pg_spacing[a]; s.part_off[a] = r->pg_offset[a]; }
+   s.part_table = r->d_part;
+   r->table_dirty = false;
+   return MDH_OK;
+}
+
+static KProbes make_probes(const mdh_renderer *r)
+{
+   KProbes p;
+   p.pcx = r->probes.probe_count[0]; p.pcy = r->probes.probe_count[1];
+   p.gx = r->probes.grid_dimensions[0]; p.gy = r->probes.grid_dimensions[1]; p.gz = r->probes.grid_dimensions[2];
+   p.sx = r->probes.grid_spacing[0]; p.sy = r->probes.grid_spacing[1]; p.sz = r->probes.grid_spacing[2];
+   p.rres = r->probes.radiance_resolution; p.ires = r->probes.irradiance_resolution;
+   p.fmt = r->opt_atlas;
+   p.rad = r->d_rad; p.irr = r->d_irr;
+   own_probes(r, &p.probe_begin, &p.probe_end);
+   return p;
+}
+static KCamera make_camera(const mdh_renderer *r)
+{
+   KCamera c;
+   c.px = r->cam_pos[0]; c.py = r->cam_pos[1]; c.pz = r->cam_pos[2];
+   memcpy(c.m, r->cam_m, sizeof c.m);
+   return c;
+}
+static KVolumetrics make_vol(const mdh_renderer *r, bool enabled)
+{
+   KVolumetrics v;
+   v.enabled = enabled ? 1 : 0;
+   v.vw = r->vol.visibility_resolution[0]; v.vh = r->vol.visibility_resolution[1]; v.vz = r->vol.visibility_resolution[2];
+   v.sw = r->vol.scattering_resolution[0]; v.sh = r->vol.scattering_resolution[1];
+   v.vstep = r->vstep; v.sstep = r->sstep;
+   v.vis = r->d_vis; v.scat = r->d_scat;
+   return v;
+}
+
+static int alloc_atlases(mdh_renderer *r)
+{
+   if (r->d_rad) HIP_TRY(hipFree(r->d_rad));
+   if (r->d_irr) HIP_TRY(hipFree(r->d_irr));
+   r->d_rad = r->d_irr = nullptr;
+   HIP_TRY(hipMalloc(&r->d_rad, atlas_bytes(r, MDH_TEX_RADIANCE)));
+   HIP_TRY(hipMalloc(&r->d_irr, atlas_bytes(r, MDH_TEX_IRRADIANCE)));
+   // Load_Empty_Texture (render_passes.adb:115-116): contents start as zeros here
+   HIP_TRY(hipMemsetAsync(r->d_rad, 0, atlas_bytes(r, MDH_TEX_RADIANCE), r->stream));
+   HIP_TRY(hipMemsetAsync(r->d_irr, 0, atlas_bytes(r, MDH_TEX_IRRADIANCE), r->stream));
+   return MDH_OK;
+}
+
+extern "C" int32_t mdh_destroy(mdh_renderer *r)
+{
+   if (!r) return MDH_OK;
+   hipSetDevice(r->device);
+   if (r->stream) hipStreamSynchronize(r->stream);
+   void *ptrs[] = {r->d_table, r->d_part, r->d_warn, r->d_rad, r->d_irr, r->d_vis, r->d_scat, r->d_fb, r->d_gb_index, r->d_gb_steps, r->d_gb_t};
+   for (void *p : ptrs)
+      if (p) hipFree(p);
+   if (r->ev0) hipEventDestroy(r->ev0);
+   if (r->ev1) hipEventDestroy(r->ev1);
+   if (r->stream) hipStreamDestroy(r->stream);
+   delete r;
+   return MDH_OK;
+}
+
+// Renderers.Create (renderers.adb:91-300) + Scenes.Compile (scenes.adb:1378-1421)
+extern "C" int32_t mdh_create(int32_t width, int32_t height, const mdh_scene_desc *scene, const mdh_probe_settings *probes,
+                              const mdh_volumetrics *vol, int32_t device, mdh_renderer **out)
+{
+   if (!scene || !probes || !vol || !out || width <= 0 || height <= 0) return seterr(MDH_E_INVALID, "bad argument");
+   if (scene->n_prim_kinds < 0 || scene->n_prim_kinds > MDH_MAX_KINDS || scene->n_light_kinds < 0 || scene->n_light_kinds > MDH_MAX_LIGHT_KINDS)
+      return seterr(MDH_E_INVALID, "too many kinds");
+   // Setup_Probe_Layout, renderers.adb:54-65
+   if (probes->grid_dimensions[0] * probes->grid_dimensions[1] * probes->grid_dimensions[2] != probes->probe_count[0] * probes->probe_count[1])
+      return seterr(MDH_E_PROBE_MISMATCH, "Probe_Count should match grid dimensions.");
+   if (probes->radiance_resolution < 1 || probes->irradiance_resolution < 1 || probes->probe_count[0] < 1 || probes->probe_count[1] < 1)
+      return seterr(MDH_E_INVALID, "bad probe settings");
+   mdh_renderer *r = new mdh_renderer();
+   r->W = width; r->H = height; r->device = device;
+   r->npk = scene->n_prim_kinds; r->nlk = scene->n_light_kinds;
+   // Compute_Scene_GPU_Type (scenes.adb:1268-1345)
+   int off = 0, base = 0;
+   for (int k = 0; k < r->npk; ++k) {
+      if (!resolve_kind(r->pk[k], scene->prim_kinds[k], false)) { delete r; return seterr(MDH_E_UNSUPPORTED_KIND, "primitive kind is not one of Sphere, Plane, Box, Triangle with their components"); }
+      off = pad_to(off, 4); r->pk[k].count_off = off; off += 4;
+      off = pad_to(off, 16); r->pk[k].array_off = off; off += r->pk[k].stride * r->pk[k].max_count;
+      r->prim_base[k] = base; base += r->pk[k].max_count;
+      if (r->pk[k].max_count > 4095) { delete r; return seterr(MDH_E_INVALID, "declared primitive count above 4095"); }
+   }
+   for (int k = 0; k < r->nlk; ++k) {
+      if (!resolve_kind(r->lk[k], scene->light_kinds[k], true)) { delete r; return seterr(MDH_E_UNSUPPORTED_KIND, "light kind is not PointLight or SpotLight with their components"); }
+      off = pad_to(off, 4); r->lk[k].count_off = off; off += 4;
+      off = pad_to(off, 16); r->lk[k].array_off = off; off += r->lk[k].stride * r->lk[k].max_count;
+   }
+   off = pad_to(off, 4); r->total_light_off = off; off += 4;
+   r->scene_ubo.assign((size_t)off, 0);
+   r->max_dist = image_roundtrip(scene->max_dist);
+   r->part = scene->partitioning;
+   r->probes = *probes;
+   r->vol = *vol;
+   r->vstep = image_roundtrip(vol->visibility_step_size);
+   r->sstep = image_roundtrip(vol->scattering_step_size);
+   if (r->part.enable) {
+      if (r->part.index_count < 1 || r->part.grid_dimensions[0] < 1 || r->part.grid_dimensions[1] < 1 || r->part.grid_dimensions[2] < 1) { delete r; return seterr(MDH_E_INVALID, "bad partitioning settings"); }
+      for (int a = 0; a < 3; ++a) { r->pg_spacing[a] = image_roundtrip(r->part.grid_spacing[a]); r->pg_offset[a] = image_roundtrip(r->part.grid_offset[a]); }
+      r->part_cells = r->part.grid_dimensions[0] * r->part.grid_dimensions[1] * r->part.grid_dimensions[2];
+      float sx = r->part.grid_spacing[0], sy = r->part.grid_spacing[1], sz = r->part.grid_spacing[2];
+      r->part_gpu_diag = image_roundtrip(sqrtf((sx * sx + sy * sy) + sz * sz));
+   }
+   // ---- device
+   int ndev = 0;
+   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { delete r; return seterr(MDH_E_NO_DEVICE, "no HIP device visible; libmadarch_hip has no CPU path"); }
+   if (device < 0 || device >= ndev) { delete r; return seterr(MDH_E_NO_DEVICE, "device ordinal out of range"); }
+   hipDeviceProp_t prop;
+   if (hipGetDeviceProperties(&prop, device) != hipSuccess || strncmp(prop.gcnArchName, "gfx950", 6) != 0) { delete r; return seterr(MDH_E_NO_DEVICE, "device is not gfx950 (MI355X); the kernels are built for gfx950 only"); }
+   int rc = MDH_OK;
+   auto fail = [&](int code) { mdh_destroy(r); return code; };
+#define TRY_OR_FAIL(expr)                                                                                          \
+   do {                                                                                                            \
+      hipError_t e_ = (expr);                                                                                      \
+      if (e_ != hipSuccess) {                                                                                      \
+         snprintf(g_err, sizeof g_err, "%s failed: %s", #expr, hipGetErrorString(e_));                             \
+         return fail(MDH_E_DEVICE);                                                                                \
+      }                                                                                                            \
+   } while (0)
+   TRY_OR_FAIL(hipSetDevice(device));
+   TRY_OR_FAIL(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking));
+   TRY_OR_FAIL(hipEventCreate(&r->ev0));
+   TRY_OR_FAIL(hipEventCreate(&r->ev1));
+   if ((rc = alloc_atlases(r)) != MDH_OK) return fail(rc);
+   size_t px = (size_t)width * height;
+   TRY_OR_FAIL(hipMalloc(&r->d_fb, px * sizeof(float4)));
+   TRY_OR_FAIL(hipMemsetAsync(r->d_fb, 0, px * sizeof(float4), r->stream));
+   TRY_OR_FAIL(hipMalloc(&r->d_gb_index, px * 4));
+   TRY_OR_FAIL(hipMalloc(&r->d_gb_steps, px * 4));
+   TRY_OR_FAIL(hipMalloc(&r->d_gb_t, px * 4));
+   TRY_OR_FAIL(hipMalloc(&r->d_warn, 4));
+   size_t vis_n = (size_t)vol->visibility_resolution[0] * vol->visibility_resolution[1] * vol->visibility_resolution[2] * 3;
+   size_t scat_n = (size_t)vol->scattering_resolution[0] * vol->scattering_resolution[1];
+   TRY_OR_FAIL(hipMalloc(&r->d_vis, (vis_n ? vis_n : 1) * 4));
+   TRY_OR_FAIL(hipMemsetAsync(r->d_vis, 0, (vis_n ? vis_n : 1) * 4, r->stream));
+   TRY_OR_FAIL(hipMalloc(&r->d_scat, (scat_n ? scat_n : 1) * sizeof(float4)));
+   TRY_OR_FAIL(hipMemsetAsync(r->d_scat, 0, (scat_n ? scat_n : 1) * sizeof(float4), r->stream));
+   if (r->part.enable) {
+      size_t n = (size_t)r->part_cells * (r->npk + r->part.index_count);
+      TRY_OR_FAIL(hipMalloc(&r->d_part, n * 4));
+      TRY_OR_FAIL(hipMemsetAsync(r->d_part, 0, n * 4, r->stream));
+   }
+   TRY_OR_FAIL(hipStreamSynchronize(r->stream));
+#undef TRY_OR_FAIL
+   *out = r;
+   return MDH_OK;
+}
+
+extern "C" int32_t mdh_set_option(mdh_renderer *r, int32_t option, int32_t value)
+{
+   if (!r) return seterr(MDH_E_INVALID, "null renderer");
+   switch (option) {
+   case MDH_OPT_ATLAS_FORMAT:
+      if (value != 0 && value != 1) return seterr(MDH_E_INVALID, "atlas format is 0 (RGB8) or 1 (fp32)");
+      if (value != r->opt_atlas) {
+         HIP_TRY(hipSetDevice(r->device));
+         HIP_TRY(hipStreamSynchronize(r->stream));
+         r->opt_atlas = value;
+         int rc = alloc_atlases(r);
+         if (rc != MDH_OK) return rc;
+      }
+      break;
+   case MDH_OPT_SCREEN_MODE: if (value < 0 || value > 2) return seterr(MDH_E_INVALID, "screen mode is 0, 1 or 2"); r->opt_mode = value; break;
+   case MDH_OPT_AO_STEPS: r->opt_ao = value; break;
+   case MDH_OPT_GBUFFER: r->opt_gbuffer = value ? 1 : 0; break;
+   case MDH_OPT_RANK: if (value < 0) return seterr(MDH_E_INVALID, "rank < 0"); r->opt_rank = value; break;
+   case MDH_OPT_WORLD: if (value < 1) return seterr(MDH_E_INVALID, "world < 1"); r->opt_world = value; break;
+   case MDH_OPT_TIMING: r->opt_timing = value ? 1 : 0; break;
+   case MDH_OPT_ADA_EVAL_DIV: r->opt_ada_div = value ? 1 : 0; break;
+   default: return seterr(MDH_E_INVALID, "unknown option");
+   }
+   return MDH_OK;
+}
+extern "C" int32_t mdh_get_option(mdh_renderer *r, int32_t option, int32_t *value)
+{
+   if (!r || !value) return seterr(MDH_E_INVALID, "bad argument");
+   switch (option) {
+   case MDH_OPT_ATLAS_FORMAT: *value = r->opt_atlas; break;
+   case MDH_OPT_SCREEN_MODE: *value = r->opt_mode; break;
+   case MDH_OPT_AO_STEPS: *value = r->opt_ao; break;
+   case MDH_OPT_GBUFFER: *value = r->opt_gbuffer; break;
+   case MDH_OPT_RANK: *value = r->opt_rank; break;
+   case MDH_OPT_WORLD: *value = r->opt_world; break;
+   case MDH_OPT_TIMING: *value = r->opt_timing; break;
+   case MDH_OPT_ADA_EVAL_DIV: *value = r->opt_ada_div; break;
+   default: return seterr(MDH_E_INVALID, "unknown option");
+   }
+   return MDH_OK;
+}
+
+// Set_Material (renderers.adb:349-367)
+extern "C" int32_t mdh_set_material(mdh_renderer *r, int32_t id0, const float albedo[3], float metallic, float roughness)
+{
+   if (!r || !albedo) return seterr(MDH_E_INVALID, "bad argument");
+   if (id0 < 0 || id0 >= MAX_MATERIALS) return seterr(MDH_E_INDEX, "material index out of range");
+   uint8_t *p = r->materials_ubo + 16 + 32 * id0;
+   memcpy(p, albedo, 12);
+   memcpy(p + 12, &metallic, 4);
+   memcpy(p + 16, &roughness, 4);
+   if (id0 >= r->last_material_index) r->last_material_index = id0 + 1;
+   r->table_dirty = true;
+   return MDH_OK;
+}
+// Add_Material (renderers.adb:369-377)
+extern "C" int32_t mdh_add_material(mdh_renderer *r, const float albedo[3], float metallic, float roughness, int32_t *out_id0)
+{
+   if (!r) return seterr(MDH_E_INVALID, "null renderer");
+   int id = r->last_material_index;
+   int rc = mdh_set_material(r, id, albedo, metallic, roughness);
+   if (rc == MDH_OK && out_id0) *out_id0 = id;
+   return rc;
+}
+// Write_Entity (renderers.adb:335-347) of a whole element
+static int write_entity(mdh_renderer *r, const Kind &k, int index1, const void *blob, int nbytes)
+{
+   if (!blob || nbytes != k.elem_size) return seterr(MDH_E_INVALID, "blob size does not match the std140 element size");
+   if (index1 < 1 || index1 > k.max_count) return seterr(MDH_E_INDEX, "index out of the declared range");
+   memcpy(r->scene_ubo.data() + k.array_off + k.stride * (index1 - 1), blob, (size_t)nbytes);
+   r->table_dirty = true;
+   return MDH_OK;
+}
+// Set_Primitive (renderers.adb:379-398)
+extern "C" int32_t mdh_set_primitive(mdh_renderer *r, int32_t kind_ix, int32_t index1, const void *blob, int32_t nbytes)
+{
+   if (!r || kind_ix < 0 || kind_ix >= r->npk) return seterr(MDH_E_INVALID, "bad kind index");
+   if (index1 < 1 || index1 > r->host_count[kind_ix]) return seterr(MDH_E_INDEX, "index past the primitives added");
+   return write_entity(r, r->pk[kind_ix], index1, blob, nbytes);
+}
+// Add_Primitive (renderers.adb:435-456)
+extern "C" int32_t mdh_add_primitive(mdh_renderer *r, int32_t kind_ix, const void *blob, int32_t nbytes, int32_t *out_count)
+{
+   if (!r || kind_ix < 0 || kind_ix >= r->npk) return seterr(MDH_E_INVALID, "bad kind index");
+   int count = r->host_count[kind_ix] + 1;
+   int rc = write_entity(r, r->pk[kind_ix], count, blob, nbytes);
+   if (rc != MDH_OK) return rc;
+   r->host_count[kind_ix] = count;
+   int32_t c = count;
+   memcpy(r->scene_ubo.data() + r->pk[kind_ix].count_off, &c, 4);
+   if (out_count) *out_count = count;
+   return MDH_OK;
+}
+// Set_Light (renderers.adb:458-483)
+extern "C" int32_t mdh_set_light(mdh_renderer *r, int32_t index1, int32_t light_kind_ix, const void *blob, int32_t nbytes)
+{
+   if (!r || light_kind_ix < 0 || light_kind_ix >= r->nlk) return seterr(MDH_E_INVALID, "bad light kind index");
+   int rc = write_entity(r, r->lk[light_kind_ix], index1, blob, nbytes);
+   if (rc != MDH_OK) return rc;
+   int32_t c = index1;
+   memcpy(r->scene_ubo.data() + r->lk[light_kind_ix].count_off, &c, 4);
+   memcpy(r->scene_ubo.data() + r->total_light_off, &c, 4);
+   return MDH_OK;
+}
+extern "C" int32_t mdh_set_camera_position(mdh_renderer *r, const float p[3])
+{
+   if (!r || !p) return seterr(MDH_E_INVALID, "bad argument");
+   memcpy(r->cam_pos, p, 12);
+   return MDH_OK;
+}
+extern "C" int32_t mdh_set_camera_orientation(mdh_renderer *r, const float m[9])
+{
+   if (!r || !m) return seterr(MDH_E_INVALID, "bad argument");
+   memcpy(r->cam_m, m, 36);
+   return MDH_OK;
+}
+
+static int ensure_committed(mdh_renderer *r)
+{
+   HIP_TRY(hipSetDevice(r->device));
+   if (r->table_dirty) return commit_scene(r);
+   return MDH_OK;
+}
+static size_t lds_bytes(const mdh_renderer *r) { return (size_t)r->ks.table_f4 * sizeof(float4); }
+
+// Update_Partitioning (renderers.adb:757-775): all three methods build the table on the device
+extern "C" int32_t mdh_update_partitioning(mdh_renderer *r, int32_t method)
+{
+   if (!r) return seterr(MDH_E_INVALID, "null renderer");
+   if (!r->part.enable) return MDH_OK; // renderers.adb:763-765
+   if (method < 0 || method > 2) return seterr(MDH_E_INVALID, "bad method");
+   int rc = ensure_committed(r);
+   if (rc != MDH_OK) return rc;
+   PartBuildArgs a;
+   a.method = method;
+   const int *d = r->part.grid_dimensions;
+   if (method == 2) { a.gx = 2 * (d[0] / 2); a.gy = 2 * (d[1] / 2); a.gz = 2 * (d[2] / 2); }
+   else { a.gx = d[0]; a.gy = d[1]; a.gz = d[2]; }
+   for (int i = 0; i < 3; ++i) {
+      // the CPU builders read the settings record, the compute shader the GLSL text
+      a.sp[i] = method == 2 ? r->pg_spacing[i] : r->part.grid_spacing[i];
+      a.off[i] = method == 2 ? r->pg_offset[i] : r->part.grid_offset[i];
+   }
+   a.gpu_diag = r->part_gpu_diag;
+   a.table = r->d_part;
+   a.warnings = r->d_warn;
+   HIP_TRY(hipMemsetAsync(r->d_warn, 0, 4, r->stream));
+   int cells = a.gx * a.gy * a.gz;
+   if (cells > 0) {
+      hipLaunchKernelGGL(k_partition_build, dim3((cells + 63) / 64), dim3(64), lds_bytes(r), r->stream, r->ks, a);
+      HIP_TRY(hipGetLastError());
+   }
+   HIP_TRY(hipMemcpyAsync(&r->part_warnings, r->d_warn, 4, hipMemcpyDeviceToHost, r->stream));
+   HIP_TRY(hipStreamSynchronize(r->stream));
+   return MDH_OK;
+}
+
+template <bool PART, int MODE> static void launch_screen_g(mdh_renderer *r, const KProbes &pr, const KVolumetrics &vol, const KCamera &cam, const ScreenArgs &a, int blocks)
+{
+   if (r->opt_gbuffer) hipLaunchKernelGGL((k_screen<PART, MODE, true>), dim3(blocks), dim3(MDH_BLOCK), lds_bytes(r), r->stream, r->ks, pr, vol, cam, a);
+   else hipLaunchKernelGGL((k_screen<PART, MODE, false>), dim3(blocks), dim3(MDH_BLOCK), lds_bytes(r), r->stream, r->ks, pr, vol, cam, a);
+}
+template <bool PART> static void launch_screen_m(mdh_renderer *r, const KProbes &pr, const KVolumetrics &vol, const KCamera &cam, const ScreenArgs &a, int blocks)
+{
+   if (r->opt_mode == 0) launch_screen_g<PART, 0>(r, pr, vol, cam, a, blocks);
+   else if (r->opt_mode == 1) launch_screen_g<PART, 1>(r, pr, vol, cam, a, blocks);
+   else launch_screen_g<PART, 2>(r, pr, vol, cam, a, blocks);
+}
+
+static int run_pass(mdh_renderer *r, int pass)
+{
+   const bool part = r->part.enable != 0;
+   KProbes pr = make_probes(r);
+   KCamera cam = make_camera(r);
+   if (r->opt_timing) HIP_TRY(hipEventRecord(r->ev0, r->stream));
+   switch (pass) {
+   case MDH_PASS_RADIANCE: {
+      long n = (long)(pr.probe_end - pr.probe_begin) * pr.rres * pr.rres;
+      if (n > 0) {
+         int blocks = (int)((n + MDH_BLOCK - 1) / MDH_BLOCK);
+         if (part) hipLaunchKernelGGL(k_radiance<true>, dim3(blocks), dim3(MDH_BLOCK), lds_bytes(r), r->stream, r->ks, pr);
+         else hipLaunchKernelGGL(k_radiance<false>, dim3(blocks), dim3(MDH_BLOCK), lds_bytes(r), r->stream, r->ks, pr);
+      }
+      break;
+   }
+   case MDH_PASS_IRRADIANCE: {
+      long n = (long)(pr.probe_end - pr.probe_begin) * pr.ires * pr.ires;
+      if (n > 0) hipLaunchKernelGGL(k_irradiance, dim3((int)((n + 63) / 64)), dim3(64), 0, r->stream, pr);
+      break;
+   }
+   case MDH_PASS_VISIBILITY: {
+      KVolumetrics vol = make_vol(r, true);
+      long n = (long)vol.vw * vol.vh * vol.vz;
+      if (n > 0) {
+         int blocks = (int)((n + MDH_BLOCK - 1) / MDH_BLOCK);
+         if (part) hipLaunchKernelGGL(k_visibility<true>, dim3(blocks), dim3(MDH_BLOCK), lds_bytes(r), r->stream, r->ks, vol, cam);
+         else hipLaunchKernelGGL(k_visibility<false>, dim3(blocks), dim3(MDH_BLOCK), lds_bytes(r), r->stream, r->ks, vol, cam);
+      }
+      break;
+   }
+   case MDH_PASS_SCATTERING: {
+      KVolumetrics vol = make_vol(r, true);
+      long n = (long)vol.sw * vol.sh;
+      if (n > 0) {
+         int blocks = (int)((n + MDH_BLOCK - 1) / MDH_BLOCK);
+         if (part) hipLaunchKernelGGL(k_scattering<true>, dim3(blocks), dim3(MDH_BLOCK), lds_bytes(r), r->stream, r->ks, vol, cam);
+         else hipLaunchKernelGGL(k_scattering<false>, dim3(blocks), dim3(MDH_BLOCK), lds_bytes(r), r->stream, r->ks, vol, cam);
+      }
+      break;
+   }
+   case MDH_PASS_SCREEN: {
+      KVolumetrics vol = make_vol(r, r->vol.enabled != 0 && r->opt_mode == 0);
+      ScreenArgs a;
+      a.W = r->W; a.H = r->H;
+      a.tiles_x = (r->W + 7) / 8;
+      a.n_tiles = a.tiles_x * ((r->H + 7) / 8);
+      a.rank = r->opt_rank; a.world = r->opt_world;
+      a.ao_steps = r->opt_ao;
+      a.fb = r->d_fb; a.gb_index = r->d_gb_index; a.gb_t = r->d_gb_t; a.gb_steps = r->d_gb_steps;
+      if (a.world > 1) HIP_TRY(hipMemsetAsync(r->d_fb, 0, (size_t)r->W * r->H * sizeof(float4), r->stream)); // other ranks' tiles read 0
+      int own_tiles = (a.n_tiles - a.rank + a.world - 1) / a.world;
+      if (own_tiles > 0) {
+         int blocks = (own_tiles + (MDH_BLOCK / 64) - 1) / (MDH_BLOCK / 64);
+         if (part) launch_screen_m<true>(r, pr, vol, cam, a, blocks);
+         else launch_screen_m<false>(r, pr, vol, cam, a, blocks);
+      }
+      break;
+   }
+   default: return seterr(MDH_E_INVALID, "bad pass");
+   }
+   HIP_TRY(hipGetLastError());
+   if (r->opt_timing) {
+      HIP_TRY(hipEventRecord(r->ev1, r->stream));
+      HIP_TRY(hipEventSynchronize(r->ev1));
+      float ms = 0.0f;
+      HIP_TRY(hipEventElapsedTime(&ms, r->ev0, r->ev1));
+      r->pass_ms[pass] += ms;
+      r->pass_n[pass] += 1;
+   }
+   return MDH_OK;
+}
+
+extern "C" int32_t mdh_render_pass(mdh_renderer *r, int32_t pass)
+{
+   if (!r) return seterr(MDH_E_INVALID, "null renderer");
+   int rc = ensure_committed(r);
+   if (rc != MDH_OK) return rc;
+   return run_pass(r, pass);
+}
+// Render (renderers.adb:302-321)
+extern "C" int32_t mdh_render(mdh_renderer *r)
+{
+   if (!r) return seterr(MDH_E_INVALID, "null renderer");
+   int rc = ensure_committed(r);
+   if (rc != MDH_OK) return rc;
+   if (r->opt_mode == 0) {
+      if ((rc = run_pass(r, MDH_PASS_RADIANCE)) != MDH_OK) return rc;
+      if ((rc = run_pass(r, MDH_PASS_IRRADIANCE)) != MDH_OK) return rc;
+      if (r->vol.enabled) {
+         if ((rc = run_pass(r, MDH_PASS_VISIBILITY)) != MDH_OK) return rc;
+         if ((rc = run_pass(r, MDH_PASS_SCATTERING)) != MDH_OK) return rc;
+      }
+   }
+   return run_pass(r, MDH_PASS_SCREEN);
+}
+extern "C" int32_t mdh_finish(mdh_renderer *r)
+{
+   if (!r) return seterr(MDH_E_INVALID, "null renderer");
+   HIP_TRY(hipSetDevice(r->device));
+   HIP_TRY(hipStreamSynchronize(r->stream));
+   return MDH_OK;
+}
+
+extern "C" int32_t mdh_read_framebuffer(mdh_renderer *r, float *rgb_out)
+{
+   if (!r || !rgb_out) return seterr(MDH_E_INVALID, "bad argument");
+   HIP_TRY(hipSetDevice(r->device));
+   size_t px = (size_t)r->W * r->H;
+   std::vector<float4> tmp(px);
+   HIP_TRY(hipMemcpyAsync(tmp.data(), r->d_fb, px * sizeof(float4), hipMemcpyDeviceToHost, r->stream));
+   HIP_TRY(hipStreamSynchronize(r->stream));
+   for (size_t i = 0; i < px; ++i) { rgb_out[3 * i] = tmp[i].x; rgb_out[3 * i + 1] = tmp[i].y; rgb_out[3 * i + 2] = tmp[i].z; }
+   return MDH_OK;
+}
+extern "C" int32_t mdh_read_gbuffer(mdh_renderer *r, int32_t *index_out, float *t_out, int32_t *steps_out)
+{
+   if (!r) return seterr(MDH_E_INVALID, "null renderer");
+   HIP_TRY(hipSetDevice(r->device));
+   size_t n = (size_t)r->W * r->H * 4;
+   if (index_out) HIP_TRY(hipMemcpyAsync(index_out, r->d_gb_index, n, hipMemcpyDeviceToHost, r->stream));
+   if (t_out) HIP_TRY(hipMemcpyAsync(t_out, r->d_gb_t, n, hipMemcpyDeviceToHost, r->stream));
+   if (steps_out) HIP_TRY(hipMemcpyAsync(steps_out, r->d_gb_steps, n, hipMemcpyDeviceToHost, r->stream));
+   HIP_TRY(hipStreamSynchronize(r->stream));
+   return MDH_OK;
+}
+
+// host copies of the probe-major atlases as float RGB per texel
+static int atlas_to_host(mdh_renderer *r, int tex, std::vector<float> &rgb)
+{
+   int res = tex == MDH_TEX_RADIANCE ? r->probes.radiance_resolution : r->probes.irradiance_resolution;
+   size_t n = (size_t)probe_total(r) * res * res;
+   void *src = tex == MDH_TEX_RADIANCE ? r->d_rad : r->d_irr;
+   rgb.resize(n * 3);
+   if (r->opt_atlas == 0) {
+      std::vector<uchar4> tmp(n);
+      HIP_TRY(hipMemcpyAsync(tmp.data(), src, n * 4, hipMemcpyDeviceToHost, r->stream));
+      HIP_TRY(hipStreamSynchronize(r->stream));
+      for (size_t i = 0; i < n; ++i) { rgb[3 * i] = (float)tmp[i].x / 255.0f; rgb[3 * i + 1] = (float)tmp[i].y / 255.0f; rgb[3 * i + 2] = (float)tmp[i].z / 255.0f; }
+   } else {
+      std::vector<float4> tmp(n);
+      HIP_TRY(hipMemcpyAsync(tmp.data(), src, n * 16, hipMemcpyDeviceToHost, r->stream));
+      HIP_TRY(hipStreamSynchronize(r->stream));
+      for (size_t i = 0; i < n; ++i) { rgb[3 * i] = tmp[i].x; rgb[3 * i + 1] = tmp[i].y; rgb[3 * i + 2] = tmp[i].z; }
+   }
+   return MDH_OK;
+}
+static float unorm8_host(float x)
+{
+   if (x != x) return 0.0f;
+   float c = x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x);
+   return rintf(c * 255.0f);
+}
+// upload texels [first, first + n) of a probe-major atlas from float RGB
+static int atlas_from_host(mdh_renderer *r, int tex, size_t first, size_t n, const float *rgb)
+{
+   void *dst = tex == MDH_TEX_RADIANCE ? r->d_rad : r->d_irr;
+   if (r->opt_atlas == 0) {
+      std::vector<uchar4> tmp(n);
+      for (size_t i = 0; i < n; ++i) {
+         tmp[i].x = (unsigned char)unorm8_host(rgb[3 * i]); tmp[i].y = (unsigned char)unorm8_host(rgb[3 * i + 1]);
+         tmp[i].z = (unsigned char)unorm8_host(rgb[3 * i + 2]); tmp[i].w = 255;
+      }
+      HIP_TRY(hipMemcpyAsync((uchar4 *)dst + first, tmp.data(), n * 4, hipMemcpyHostToDevice, r->stream));
+      HIP_TRY(hipStreamSynchronize(r->stream));
+   } else {
+      std::vector<float4> tmp(n);
+      for (size_t i = 0; i < n; ++i) {
+         float a = rgb[3 * i], b = rgb[3 * i + 1], c = rgb[3 * i + 2];
+         tmp[i] = mk4(a != a ? 0.0f : a, b != b ? 0.0f : b, c != c ? 0.0f : c, 1.0f);
+      }
+      HIP_TRY(hipMemcpyAsync((float4 *)dst + first, tmp.data(), n * 16, hipMemcpyHostToDevice, r->stream));
+      HIP_TRY(hipStreamSynchronize(r->stream));
+   }
+   return MDH_OK;
+}
+
+extern "C" int32_t mdh_read_texture(mdh_renderer *r, int32_t tex, float *out, int32_t *w, int32_t *h, int32_t *c)
+{
+   if (!r || tex < 0 || tex > 3) return seterr(MDH_E_INVALID, "bad argument");
+   HIP_TRY(hipSetDevice(r->device));
+   int W, H, C;
+   if (tex == MDH_TEX_RADIANCE || tex == MDH_TEX_IRRADIANCE) {
+      int res = tex == MDH_TEX_RADIANCE ? r->probes.radiance_resolution : r->probes.irradiance_resolution;
+      W = res * r->probes.probe_count[0]; H = res * r->probes.probe_count[1]; C = 3;
+      if (out) {
+         std::vector<float> rgb;
+         int rc = atlas_to_host(r, tex, rgb);
+         if (rc != MDH_OK) return rc;
+         int pcx = r->probes.probe_count[0];
+         for (int Y = 0; Y < H; ++Y)
+            for (int X = 0; X < W; ++X) {
+               int tx = X / res, ty = Y / res;
+               size_t idx = ((size_t)(ty * pcx + tx) * res + (Y - ty * res)) * res + (X - tx * res);
+               memcpy(out + ((size_t)Y * W + X) * 3, &rgb[idx * 3], 12);
+            }
+      }
+   } else if (tex == MDH_TEX_VISIBILITY) {
+      W = r->vol.visibility_resolution[0]; H = r->vol.visibility_resolution[1] * r->vol.visibility_resolution[2]; C = 3;
+      if (out) { HIP_TRY(hipMemcpyAsync(out, r->d_vis, (size_t)W * H * 12, hipMemcpyDeviceToHost, r->stream)); HIP_TRY(hipStreamSynchronize(r->stream)); }
+   } else {
+      W = r->vol.scattering_resolution[0]; H = r->vol.scattering_resolution[1]; C = 4;
+      if (out) { HIP_TRY(hipMemcpyAsync(out, r->d_scat, (size_t)W * H * 16, hipMemcpyDeviceToHost, r->stream)); HIP_TRY(hipStreamSynchronize(r->stream)); }
+   }
+   if (w) *w = W;
+   if (h) *h = H;
+   if (c) *c = C;
+   return MDH_OK;
+}
+extern "C" int32_t mdh_write_texture(mdh_renderer *r, int32_t tex, const float *in, int32_t w, int32_t h, int32_t c)
+{
+   if (!r || tex < 0 || tex > 3 || !in) return seterr(MDH_E_INVALID, "bad argument");
+   HIP_TRY(hipSetDevice(r->device));
+   int W, H, C;
+   int rc = mdh_read_texture(r, tex, nullptr, &W, &H, &C);
+   if (rc != MDH_OK) return rc;
+   if (w != W || h != H || c != C) return seterr(MDH_E_INVALID, "texture shape mismatch");
+   if (tex == MDH_TEX_RADIANCE || tex == MDH_TEX_IRRADIANCE) {
+      int res = tex == MDH_TEX_RADIANCE ? r->probes.radiance_resolution : r->probes.irradiance_resolution;
+      int pcx = r->probes.probe_count[0];
+      std::vector<float> rgb((size_t)W * H * 3);
+      for (int Y = 0; Y < H; ++Y)
+         for (int X = 0; X < W; ++X) {
+            int tx = X / res, ty = Y / res;
+            size_t idx = ((size_t)(ty * pcx + tx) * res + (Y - ty * res)) * res + (X - tx * res);
+            memcpy(&rgb[idx * 3], in + ((size_t)Y * W + X) * 3, 12);
+         }
+      return atlas_from_host(r, tex, 0, (size_t)W * H, rgb.data());
+   }
+   void *dst = tex == MDH_TEX_VISIBILITY ? (void *)r->d_vis : (void *)r->d_scat;
+   HIP_TRY(hipMemcpyAsync(dst, in, (size_t)W * H * C * 4, hipMemcpyHostToDevice, r->stream));
+   HIP_TRY(hipStreamSynchronize(r->stream));
+   return MDH_OK;
+}
+extern "C" int32_t mdh_read_atlas_slice(mdh_renderer *r, int32_t tex, int32_t probe_begin, int32_t n_probes, float *out)
+{
+   if (!r || (tex != MDH_TEX_RADIANCE && tex != MDH_TEX_IRRADIANCE) || !out) return seterr(MDH_E_INVALID, "bad argument");
+   if (probe_begin < 0 || n_probes < 0 || probe_begin + n_probes > probe_total(r)) return seterr(MDH_E_INDEX, "probe range");
+   HIP_TRY(hipSetDevice(r->device));
+   std::vector<float> rgb;
+   int rc = atlas_to_host(r, tex, rgb);
+   if (rc != MDH_OK) return rc;
+   int res = tex == MDH_TEX_RADIANCE ? r->probes.radiance_resolution : r->probes.irradiance_resolution;
+   size_t per = (size_t)res * res * 3;
+   memcpy(out, &rgb[(size_t)probe_begin * per], (size_t)n_probes * per * 4);
+   return MDH_OK;
+}
+extern "C" int32_t mdh_write_atlas_slice(mdh_renderer *r, int32_t tex, int32_t probe_begin, int32_t n_probes, const float *in)
+{
+   if (!r || (tex != MDH_TEX_RADIANCE && tex != MDH_TEX_IRRADIANCE) || !in) return seterr(MDH_E_INVALID, "bad argument");
+   if (probe_begin < 0 || n_probes < 0 || probe_begin + n_probes > probe_total(r)) return seterr(MDH_E_INDEX, "probe range");
+   HIP_TRY(hipSetDevice(r->device));
+   int res = tex == MDH_TEX_RADIANCE ? r->probes.radiance_resolution : r->probes.irradiance_resolution;
+   return atlas_from_host(r, tex, (size_t)probe_begin * res * res, (size_t)n_probes * res * res, in);
+}
+extern "C" int32_t mdh_atlas_device_ptr(mdh_renderer *r, int32_t tex, void **dptr, int64_t *total_bytes, int64_t *own_offset, int64_t *own_bytes)
+{
+   if (!r || (tex != MDH_TEX_RADIANCE && tex != MDH_TEX_IRRADIANCE)) return seterr(MDH_E_INVALID, "bad argument");
+   int res = tex == MDH_TEX_RADIANCE ? r->probes.radiance_resolution : r->probes.irradiance_resolution;
+   int b, e;
+   own_probes(r, &b, &e);
+   int64_t per = (int64_t)res * res * (int64_t)texel_bytes(r);
+   if (dptr) *dptr = tex == MDH_TEX_RADIANCE ? r->d_rad : r->d_irr;
+   if (total_bytes) *total_bytes = (int64_t)atlas_bytes(r, tex);
+   if (own_offset) *own_offset = per * b;
+   if (own_bytes) *own_bytes = per * (e - b);
+   return MDH_OK;
+}
+extern "C" int32_t mdh_stream(mdh_renderer *r, void **stream)
+{
+   if (!r || !stream) return seterr(MDH_E_INVALID, "bad argument");
+   *stream = (void *)r->stream;
+   return MDH_OK;
+}
+
+// Eval_Distance_To (renderers.adb:499-526), batched on the device
+extern "C" int32_t mdh_eval_distance_to(mdh_renderer *r, int32_t n, const float *pts, const int32_t *kind_ixs, int32_t n_kinds,
+                                        float *normals_out, float *dist_out)
+{
+   if (!r || !pts || !kind_ixs || !dist_out || n < 0 || n_kinds < 0 || n_kinds > MDH_MAX_KINDS) return seterr(MDH_E_INVALID, "bad argument");
+   for (int i = 0; i < n_kinds; ++i)
+      if (kind_ixs[i] < 0 || kind_ixs[i] >= r->npk) return seterr(MDH_E_INVALID, "bad kind index");
+   if (n == 0) return MDH_OK;
+   int rc = ensure_committed(r);
+   if (rc != MDH_OK) return rc;
+   float *d_pts = nullptr, *d_n = nullptr, *d_d = nullptr;
+   HIP_TRY(hipMalloc(&d_pts, (size_t)n * 12));
+   HIP_TRY(hipMalloc(&d_n, (size_t)n * 12));
+   HIP_TRY(hipMalloc(&d_d, (size_t)n * 4));
+   HIP_TRY(hipMemcpyAsync(d_pts, pts, (size_t)n * 12, hipMemcpyHostToDevice, r->stream));
+   EvalArgs a;
+   a.n = n; a.n_kinds = n_kinds;
+   for (int i = 0; i < MDH_MAX_KINDS; ++i) { a.kinds[i] = i < n_kinds ? kind_ixs[i] : 0; a.host_count[i] = r->host_count[i]; }
+   a.pts = d_pts; a.normals = d_n; a.dist = d_d;
+   if (r->opt_ada_div) hipLaunchKernelGGL(k_eval_distance<true>, dim3((n + 63) / 64), dim3(64), lds_bytes(r), r->stream, r->ks, a);
+   else hipLaunchKernelGGL(k_eval_distance<false>, dim3((n + 63) / 64), dim3(64), lds_bytes(r), r->stream, r->ks, a);
+   HIP_TRY(hipGetLastError());
+   HIP_TRY(hipMemcpyAsync(dist_out, d_d, (size_t)n * 4, hipMemcpyDeviceToHost, r->stream));
+   if (normals_out) HIP_TRY(hipMemcpyAsync(normals_out, d_n, (size_t)n * 12, hipMemcpyDeviceToHost, r->stream));
+   HIP_TRY(hipStreamSynchronize(r->stream));
+   hipFree(d_pts); hipFree(d_n); hipFree(d_d);
+   return MDH_OK;
+}
+
+extern "C" int32_t mdh_pass_time(mdh_renderer *r, int32_t pass, double *ms, int64_t *launches)
+{
+   if (!r || pass < 0 || pass >= MDH_PASS_COUNT) return seterr(MDH_E_INVALID, "bad argument");
+   if (ms) *ms = r->pass_ms[pass];
+   if (launches) *launches = r->pass_n[pass];
+   return MDH_OK;
+}
+extern "C" int32_t mdh_reset_pass_times(mdh_renderer *r)
+{
+   if (!r) return seterr(MDH_E_INVALID, "null renderer");
+   for (int i = 0; i < MDH_PASS_COUNT; ++i) { r->pass_ms[i] = 0; r->pass_n[i] = 0; }
+   return MDH_OK;
+}
+
+// Scenes.Get_Primitives_Location / Get_Lights_Location (scenes.adb:1435-1462)
+extern "C" int32_t mdh_scene_layout(mdh_renderer *r, int32_t is_light, int32_t kind_ix, int32_t *count_off, int32_t *array_off, int32_t *stride, int32_t *elem_size)
+{
+   if (!r || kind_ix < 0 || kind_ix >= (is_light ? r->nlk : r->npk)) return seterr(MDH_E_INVALID, "bad kind index");
+   const Kind &k = is_light ? r->lk[kind_ix] : r->pk[kind_ix];
+   if (count_off) *count_off = k.count_off;
+   if (array_off) *array_off = k.array_off;
+   if (stride) *stride = k.stride;
+   if (elem_size) *elem_size = k.elem_size;
+   return MDH_OK;
+}
+extern "C" int32_t mdh_scene_buffer_size(mdh_renderer *r, int32_t *size, int32_t *total_light_off)
+{
+   if (!r) return seterr(MDH_E_INVALID, "null renderer");
+   if (size) *size = (int32_t)r->scene_ubo.size();
+   if (total_light_off) *total_light_off = r->total_light_off;
+   return MDH_OK;
+}
+extern "C" int32_t mdh_read_scene_buffer(mdh_renderer *r, void *out, int32_t nbytes)
+{
+   if (!r || !out || nbytes < 0 || (size_t)nbytes > r->scene_ubo.size()) return seterr(MDH_E_INVALID, "bad argument");
+   memcpy(out, r->scene_ubo.data(), (size_t)nbytes);
+   return MDH_OK;
+}
+extern "C" int32_t mdh_read_partitioning(mdh_renderer *r, int32_t *out, int32_t n_ints)
+{
+   if (!r || !out) return seterr(MDH_E_INVALID, "bad argument");
+   if (!r->part.enable) return seterr(MDH_E_STATE, "partitioning disabled");
+   size_t total = (size_t)r->part_cells * (r->npk + r->part.index_count);
+   if ((size_t)n_ints != total) return seterr(MDH_E_INVALID, "size mismatch");
+   HIP_TRY(hipSetDevice(r->device));
+   HIP_TRY(hipMemcpyAsync(out, r->d_part, total * 4, hipMemcpyDeviceToHost, r->stream));
+   HIP_TRY(hipStreamSynchronize(r->stream));
+   return MDH_OK;
+}
+extern "C" int32_t mdh_partition_warnings(mdh_renderer *r) { return r ? r->part_warnings : 0; }

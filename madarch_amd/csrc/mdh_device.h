@@ -1,0 +1,765 @@
+// mdh_device.h -- hand-written gfx950 device code of the Madarch render path.
+//
+// What the reference expresses as GLSL (static shaders under madarch/glsl/ plus
+// the scene code Madarch.Scenes generates, madarch-scenes.adb:1189-1266) is
+// written here directly for CDNA4: one lane per ray, 64 rays per wavefront,
+// scene tables (primitives, lights, materials) staged once per workgroup into
+// LDS and read with wave-uniform addresses (broadcast reads, no bank conflicts),
+// the uniform scene header in SGPRs through the kernel argument block.  The
+// sphere-tracing loops have no step cap, as in the reference: every iteration
+// advances by >= epsilon, so a ray ends within max_dist / epsilon iterations and
+// a wave leaves a loop as soon as the ballot of live lanes is empty.
+//
+// Arithmetic contract (DESIGN.md "Numerics"): fp32, one IEEE operation per source
+// operation in the order written (built with -ffp-contract=off, correctly
+// rounded division and square root), min/max = IEEE minNum/maxNum.  Reference
+// file:line citations are relative to /root/reference/madarch/.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define MDH_DEV static __device__ __forceinline__
+
+#define MDH_MAX_KINDS 4
+#define MDH_MAX_LIGHT_KINDS 4
+
+enum { PK_SPHERE = 0, PK_PLANE = 1, PK_BOX = 2, PK_TRIANGLE = 3 };
+enum { LK_POINT = 0, LK_SPOT = 1 };
+
+// ---------------------------------------------------------------- kernel argument blocks
+// Uniform scene header: lives in SGPRs.  `slot` values index the float4 table in LDS.
+struct KScene {
+   int nk;
+   int ktype[MDH_MAX_KINDS];  // PK_*
+   int kcount[MDH_MAX_KINDS]; // runtime count  (prim_<K>_count, scenes.adb:560-565)
+   int kbase[MDH_MAX_KINDS];  // flat index base = sum of earlier DECLARED counts (scenes.adb:656-666)
+   int kmax[MDH_MAX_KINDS];   // declared count
+   int kslot[MDH_MAX_KINDS];  // first float4 of the kind's primitives in the table
+   int nl;
+   int ltype[MDH_MAX_LIGHT_KINDS];
+   int lcount[MDH_MAX_LIGHT_KINDS];
+   int lslot[MDH_MAX_LIGHT_KINDS];
+   int total_lights; // total_light_count (scenes.adb:594)
+   int mat_slot;     // first float4 of the materials (2 per material)
+   int table_f4;     // float4 count of the whole table
+   float max_dist;
+   // space partition (scenes.adb:799-1118)
+   int part_enable, part_border, part_index_count, part_cells;
+   int part_dims[3];
+   float part_sp[3], part_off[3];
+   const float4 *table; // HBM image of the table (staged to LDS by every workgroup)
+   const int *part_table; // [cell][nk + index_count]
+};
+
+struct KProbes {
+   int pcx, pcy;      // probe_count
+   int gx, gy, gz;    // grid_dimensions
+   float sx, sy, sz;  // grid_spacing
+   int rres, ires;    // radiance / irradiance resolution
+   int fmt;           // 0 = RGBA8 unorm texels, 1 = float4 texels
+   void *rad;         // probe-major [probe][y][x]
+   void *irr;
+   int probe_begin, probe_end; // slice this rank updates
+};
+
+struct KCamera {
+   float px, py, pz;
+   float m[9]; // column-major
+};
+
+struct KVolumetrics {
+   int enabled;
+   int vw, vh, vz; // visibility texture is vw x (vh * vz)
+   int sw, sh;
+   float vstep, sstep;
+   float *vis;   // 3 floats per texel
+   float4 *scat; // rgb + ray length
+};
+
+// ------------------------------------------------------------------------------ vec math
+struct f3 { float x, y, z; };
+struct f2 { float x, y; };
+struct i3 { int x, y, z; };
+
+#define MDH_PI 3.14159265358f // maths.glsl:1
+#define MDH_EPS 0.001f        // maths.glsl:3
+#define MDH_MIN_STEP 0.05f    // raymarching.glsl:1
+
+MDH_DEV f3 F3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+MDH_DEV f3 F3s(float s) { return F3(s, s, s); }
+MDH_DEV f2 F2(float x, float y) { f2 r; r.x = x; r.y = y; return r; }
+MDH_DEV f3 xyz(float4 v) { return F3(v.x, v.y, v.z); }
+
+MDH_DEV float min_(float a, float b) { return __builtin_fminf(a, b); } // v_min_f32: minNum
+MDH_DEV float max_(float a, float b) { return __builtin_fmaxf(a, b); }
+MDH_DEV float clamp_(float x, float lo, float hi) { return min_(max_(x, lo), hi); }
+MDH_DEV int iclamp_(int x, int lo, int hi) { return min(max(x, lo), hi); }
+MDH_DEV float sign_(float x) { return x < 0.0f ? -1.0f : (x > 0.0f ? 1.0f : 0.0f); }
+MDH_DEV float fract_(float x) { return x - __builtin_floorf(x); }
+MDH_DEV float mix_(float x, float y, float a) { return x * (1.0f - a) + y * a; }
+
+MDH_DEV f3 operator+(f3 a, f3 b) { return F3(a.x + b.x, a.y + b.y, a.z + b.z); }
+MDH_DEV f3 operator-(f3 a, f3 b) { return F3(a.x - b.x, a.y - b.y, a.z - b.z); }
+MDH_DEV f3 operator*(f3 a, f3 b) { return F3(a.x * b.x, a.y * b.y, a.z * b.z); }
+MDH_DEV f3 operator/(f3 a, f3 b) { return F3(a.x / b.x, a.y / b.y, a.z / b.z); }
+MDH_DEV f3 operator*(f3 a, float s) { return F3(a.x * s, a.y * s, a.z * s); }
+MDH_DEV f3 operator/(f3 a, float s) { return F3(a.x / s, a.y / s, a.z / s); }
+MDH_DEV f3 operator-(f3 a) { return F3(-a.x, -a.y, -a.z); }
+MDH_DEV f3 abs3(f3 a) { return F3(__builtin_fabsf(a.x), __builtin_fabsf(a.y), __builtin_fabsf(a.z)); }
+MDH_DEV f3 max3s(f3 a, float s) { return F3(max_(a.x, s), max_(a.y, s), max_(a.z, s)); }
+MDH_DEV f3 min3s(f3 a, float s) { return F3(min_(a.x, s), min_(a.y, s), min_(a.z, s)); }
+MDH_DEV f3 floor3(f3 a) { return F3(__builtin_floorf(a.x), __builtin_floorf(a.y), __builtin_floorf(a.z)); }
+MDH_DEV f3 sqrt3(f3 a) { return F3(__builtin_sqrtf(a.x), __builtin_sqrtf(a.y), __builtin_sqrtf(a.z)); }
+// dot = (x*x' + y*y') + z*z'
+MDH_DEV float dot(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+MDH_DEV float dot2(f3 a) { return dot(a, a); } // maths.glsl:5-7
+MDH_DEV float length(f3 a) { return __builtin_sqrtf(dot2(a)); }
+MDH_DEV f3 normalize(f3 a) { return a / length(a); } // support/math_utils.ads:81-83
+MDH_DEV f3 cross(f3 a, f3 b) { return F3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+MDH_DEV f3 reflect(f3 i, f3 n) { return i - n * (2.0f * dot(n, i)); }
+
+// transcendentals: correctly rounded fp32 through one fp64 evaluation
+MDH_DEV float exp_(float x) { return (float)exp((double)x); }
+MDH_DEV float acos_(float x) { return (float)acos((double)x); }
+MDH_DEV float pow_(float x, float y) { return (float)pow((double)x, (double)y); }
+MDH_DEV float pow5_(float x) { float x2 = x * x; return (x2 * x2) * x; }                 // cook_torrance_brdf.glsl:2
+MDH_DEV float pow8_(float x) { float x2 = x * x; float x4 = x2 * x2; return x4 * x4; } // spot_lights.adb:18
+MDH_DEV float pow1_5_(float x) { return x * __builtin_sqrtf(x); }                        // volumetrics.glsl:25-28
+
+// ---------------------------------------------------------------------- LDS scene table
+// One float4 array per workgroup: primitives (2 float4 each, 3 for a triangle), lights
+// (2 for a point light, 3 for a spot light), materials (2 each).
+//   Sphere   {center.xyz, radius}            {-, -, -, material}
+//   Plane    {normal.xyz, offset}            {-, -, -, material}
+//   Box      {center.xyz, -}                 {side.xyz, material}
+//   Triangle {v1.xyz, material} {v2.xyz, -}  {v3.xyz, -}
+//   PointLight {position.xyz, -} {color.xyz, -}
+//   SpotLight  {position.xyz, aperture} {direction.xyz, -} {color.xyz, -}
+//   Material {albedo.xyz, metallic} {roughness, -, -, -}
+extern __shared__ float4 s_tab[];
+
+MDH_DEV void stage_table(const KScene &sc)
+{
+   for (int i = threadIdx.x; i < sc.table_f4; i += blockDim.x) s_tab[i] = sc.table[i];
+   __syncthreads();
+}
+MDH_DEV int prim_slots(int type) { return type == PK_TRIANGLE ? 3 : 2; }
+
+// ---------------------------------------------------------------------------- the SDFs
+// madarch-primitives-spheres.ads:13-14
+MDH_DEV float sd_sphere(float4 a, f3 p) { return length(xyz(a) - p) - a.w; }
+// madarch-primitives-planes.ads:13-14
+MDH_DEV float sd_plane(float4 a, f3 p) { return dot(xyz(a), p) + a.w; }
+// madarch-primitives-boxes.adb:7-15
+MDH_DEV float sd_box(float4 a, float4 b, f3 p)
+{
+   f3 q = abs3(xyz(a) - p) - xyz(b);
+   return length(max3s(q, 0.0f)) + min_(max_(q.x, max_(q.y, q.z)), 0.0f);
+}
+// madarch-primitives-triangles.adb:16-48; ADA_DIV reproduces Madarch.Values."/" (L + R)
+template <bool ADA_DIV> MDH_DEV float tdiv(float a, float b) { return ADA_DIV ? a + b : a / b; }
+template <bool ADA_DIV> MDH_DEV float sd_triangle(f3 a, f3 b, f3 c, f3 p)
+{
+   f3 v21 = b - a, v32 = c - b, v13 = a - c;
+   f3 p1 = p - a, p2 = p - b, p3 = p - c;
+   f3 nor = cross(v21, v13);
+   float s = (sign_(dot(cross(v21, nor), p1)) + sign_(dot(cross(v32, nor), p2))) + sign_(dot(cross(v13, nor), p3));
+   float r;
+   if (s < 2.0f) {
+      float e1 = dot2(v21 * clamp_(tdiv<ADA_DIV>(dot(v21, p1), dot2(v21)), 0.0f, 1.0f) - p1);
+      float e2 = dot2(v32 * clamp_(tdiv<ADA_DIV>(dot(v32, p2), dot2(v32)), 0.0f, 1.0f) - p2);
+      float e3 = dot2(v13 * clamp_(tdiv<ADA_DIV>(dot(v13, p3), dot2(v13)), 0.0f, 1.0f) - p3);
+      r = min_(min_(e1, e2), e3);
+   } else {
+      r = tdiv<ADA_DIV>(dot(nor, p1) * dot(nor, p1), dot2(nor));
+   }
+   return __builtin_sqrtf(r);
+}
+// madarch-primitives-boxes.adb:5,17-41
+MDH_DEV f3 nrm_box(float4 a, float4 b, f3 p)
+{
+   const float e = 0.002f;
+   f3 d = (p - xyz(a)) / xyz(b);
+   float rx = __builtin_fabsf(d.x), ry = __builtin_fabsf(d.y), rz = __builtin_fabsf(d.z);
+   f3 n = F3(((rx > ry - e ? 1.0f : 0.0f) * (rx > rz - e ? 1.0f : 0.0f)) * sign_(d.x),
+             ((ry > rx - e ? 1.0f : 0.0f) * (ry > rz - e ? 1.0f : 0.0f)) * sign_(d.y),
+             ((rz > rx - e ? 1.0f : 0.0f) * (rz > ry - e ? 1.0f : 0.0f)) * sign_(d.z));
+   return normalize(n);
+}
+// madarch-primitives-triangles.adb:50-56 + madarch-exprs-derivatives.adb:12-45
+template <bool ADA_DIV> MDH_DEV f3 nrm_triangle(f3 a, f3 b, f3 c, f3 p)
+{
+   const float eps = 0.000001f;
+   float fp = sd_triangle<ADA_DIV>(a, b, c, p);
+   float fx = sd_triangle<ADA_DIV>(a, b, c, p + F3(eps, 0.0f, 0.0f)) - fp;
+   float fy = sd_triangle<ADA_DIV>(a, b, c, p + F3(0.0f, eps, 0.0f)) - fp;
+   float fz = sd_triangle<ADA_DIV>(a, b, c, p + F3(0.0f, 0.0f, eps)) - fp;
+   return normalize(F3(fx, fy, fz));
+}
+
+// dist_to_<Kind>(prims[i], x); `slot` = first float4 of the primitive (any lane value)
+MDH_DEV float prim_dist(int type, int slot, f3 x)
+{
+   switch (type) {
+   case PK_SPHERE: return sd_sphere(s_tab[slot], x);
+   case PK_PLANE: return sd_plane(s_tab[slot], x);
+   case PK_BOX: return sd_box(s_tab[slot], s_tab[slot + 1], x);
+   default: return sd_triangle<false>(xyz(s_tab[slot]), xyz(s_tab[slot + 1]), xyz(s_tab[slot + 2]), x);
+   }
+}
+
+// closest_primitive (scenes.adb:602-629): kinds in scene order, wave-uniform loop
+MDH_DEV float closest_primitive(const KScene &sc, f3 x)
+{
+   float closest = sc.max_dist;
+#pragma unroll
+   for (int k = 0; k < MDH_MAX_KINDS; ++k) {
+      if (k >= sc.nk) break;
+      const int n = sc.kcount[k], s0 = sc.kslot[k];
+      switch (sc.ktype[k]) {
+      case PK_SPHERE:
+         for (int i = 0; i < n; ++i) closest = min_(closest, sd_sphere(s_tab[s0 + 2 * i], x));
+         break;
+      case PK_PLANE:
+         for (int i = 0; i < n; ++i) closest = min_(closest, sd_plane(s_tab[s0 + 2 * i], x));
+         break;
+      case PK_BOX:
+         for (int i = 0; i < n; ++i) closest = min_(closest, sd_box(s_tab[s0 + 2 * i], s_tab[s0 + 2 * i + 1], x));
+         break;
+      default:
+         for (int i = 0; i < n; ++i)
+            closest = min_(closest, sd_triangle<false>(xyz(s_tab[s0 + 3 * i]), xyz(s_tab[s0 + 3 * i + 1]), xyz(s_tab[s0 + 3 * i + 2]), x));
+         break;
+      }
+   }
+   return closest;
+}
+// closest_primitive_info (scenes.adb:631-674)
+MDH_DEV float closest_primitive_info(const KScene &sc, f3 x, int &index)
+{
+   float closest = sc.max_dist;
+#pragma unroll
+   for (int k = 0; k < MDH_MAX_KINDS; ++k) {
+      if (k >= sc.nk) break;
+      const int n = sc.kcount[k], s0 = sc.kslot[k], base = sc.kbase[k], type = sc.ktype[k];
+      for (int i = 0; i < n; ++i) {
+         float d = prim_dist(type, s0 + prim_slots(type) * i, x);
+         if (d < closest) { closest = d; index = base + i; }
+      }
+   }
+   return closest;
+}
+
+// material id and normal of a flat index: primitive_info (scenes.adb:676-729),
+// kind found by successive subtraction of the DECLARED counts
+MDH_DEV void primitive_info(const KScene &sc, int index, f3 pos, f3 &normal, int &material_id)
+{
+   normal = F3(0.0f, 0.0f, 0.0f);
+   material_id = 0;
+#pragma unroll
+   for (int k = 0; k < MDH_MAX_KINDS; ++k) {
+      if (k >= sc.nk) break;
+      if (index < sc.kmax[k]) {
+         const int type = sc.ktype[k];
+         const int slot = sc.kslot[k] + prim_slots(type) * index; // per-lane LDS gather
+         float4 a = s_tab[slot], b = s_tab[slot + 1];
+         switch (type) {
+         case PK_SPHERE: normal = normalize(pos - xyz(a)); material_id = __float_as_int(b.w); break; // spheres.ads:16-17
+         case PK_PLANE: normal = xyz(a); material_id = __float_as_int(b.w); break;                   // planes.ads:16-17
+         case PK_BOX: normal = nrm_box(a, b, pos); material_id = __float_as_int(b.w); break;
+         default: normal = nrm_triangle<false>(xyz(a), xyz(b), xyz(s_tab[slot + 2]), pos); material_id = __float_as_int(a.w); break;
+         }
+         return;
+      }
+      index -= sc.kmax[k];
+   }
+}
+
+// ------------------------------------------------------------------- space partition
+// partitioning index (scenes.adb:799-837); the reference clamps to `dims`, an index
+// past the table reads an empty cell
+MDH_DEV int partition_cell(const KScene &sc, f3 x, bool &fallback)
+{
+   f3 fx = floor3((x - F3(sc.part_off[0], sc.part_off[1], sc.part_off[2])) / F3(sc.part_sp[0], sc.part_sp[1], sc.part_sp[2]));
+   f3 cfx = F3(clamp_(fx.x, 0.0f, (float)sc.part_dims[0]), clamp_(fx.y, 0.0f, (float)sc.part_dims[1]), clamp_(fx.z, 0.0f, (float)sc.part_dims[2]));
+   fallback = false;
+   if (sc.part_border == 0) fx = cfx;
+   else if (fx.x != cfx.x || fx.y != cfx.y || fx.z != cfx.z) { fallback = true; return -1; }
+   float yz = (float)(sc.part_dims[1] * sc.part_dims[2]), zz = (float)sc.part_dims[2];
+   return (int)((fx.x * yz + fx.y * zz) + fx.z);
+}
+// partitioning_closest[_info] (scenes.adb:839-1118): per-lane cell record from HBM/L2,
+// per-lane primitive gather from LDS
+template <bool INFO> MDH_DEV float partitioning_lookup(const KScene &sc, f3 x, int &index)
+{
+   bool fb;
+   int cell = partition_cell(sc, x, fb);
+   if (fb) return INFO ? closest_primitive_info(sc, x, index) : closest_primitive(sc, x);
+   float closest = sc.max_dist;
+   if (cell < 0 || cell >= sc.part_cells) return closest;
+   const int *rec = sc.part_table + (size_t)cell * (sc.nk + sc.part_index_count);
+   int i = 0;
+#pragma unroll
+   for (int k = 0; k < MDH_MAX_KINDS; ++k) {
+      if (k >= sc.nk) break;
+      const int size = i + rec[k], type = sc.ktype[k], s0 = sc.kslot[k], base = sc.kbase[k];
+      const int stop = min(size, sc.part_index_count);
+      for (; i < stop; ++i) {
+         int pi = rec[sc.nk + i];
+         float d = prim_dist(type, s0 + prim_slots(type) * pi, x);
+         if (INFO) { if (d < closest) { closest = d; index = base + pi; } }
+         else closest = min_(closest, d);
+      }
+      i = size;
+   }
+   return closest;
+}
+template <bool PART> MDH_DEV float sdf(const KScene &sc, f3 x)
+{
+   int dummy;
+   if (PART) return partitioning_lookup<false>(sc, x, dummy);
+   return closest_primitive(sc, x);
+}
+template <bool PART> MDH_DEV float sdf_info(const KScene &sc, f3 x, int &index)
+{
+   if (PART) return partitioning_lookup<true>(sc, x, index);
+   return closest_primitive_info(sc, x, index);
+}
+
+// ------------------------------------------------------------------------- raymarching
+// glsl/raymarching.glsl:4-23
+template <bool PART> MDH_DEV float softshadows(const KScene &sc, f3 from, f3 dir, float min_dist, float max_dist, float k)
+{
+   float res = 1.0f, prev_dist = 1e20f;
+   for (float total = min_dist; total < max_dist;) {
+      float dist = sdf<PART>(sc, from + dir * total);
+      if (dist < MDH_EPS) return 0.0f;
+      float y = dist * dist / (2.0f * prev_dist);
+      float d = __builtin_sqrtf(dist * dist - y * y);
+      res = min_(res, k * d / max_(0.0f, total - y));
+      prev_dist = dist;
+      total += dist;
+   }
+   return res;
+}
+// glsl/raymarching.glsl:25-37
+template <bool PART> MDH_DEV bool raycast(const KScene &sc, f3 from, f3 dir, int &index, f3 &coll, float &t_out, int &steps)
+{
+   int n = 0;
+   for (float total = 0.0f; total < sc.max_dist;) {
+      float dist = sdf_info<PART>(sc, from + dir * total, index);
+      ++n;
+      if (dist < MDH_EPS) {
+         coll = from + dir * total;
+         t_out = total;
+         steps = n;
+         return true;
+      }
+      total += dist;
+   }
+   steps = n;
+   return false;
+}
+// glsl/raymarching.glsl:39-56: raycast_visibility = 1 - float(hit)
+template <bool PART> MDH_DEV float raycast_visibility(const KScene &sc, f3 from, f3 dir, float max_dist)
+{
+   for (float total = 0.0f; total < max_dist;) {
+      float dist = sdf<PART>(sc, from + dir * total);
+      if (dist < MDH_EPS) return 0.0f;
+      total += dist;
+   }
+   return 1.0f;
+}
+
+// ------------------------------------------------------------------------------ lights
+// sample_<Light> (scenes.adb:497-549) dispatched by cumulative RUNTIME counts (scenes.adb:731-764)
+MDH_DEV f3 sample_light(const KScene &sc, int index, f3 pos, f3 &dir, float &dist)
+{
+#pragma unroll
+   for (int k = 0; k < MDH_MAX_LIGHT_KINDS; ++k) {
+      if (k >= sc.nl) break;
+      const int n = sc.lcount[k];
+      if (index < n) {
+         if (sc.ltype[k] == LK_POINT) { // madarch-lights-point_lights.ads:20-22
+            const int s = sc.lslot[k] + 2 * index;
+            dir = xyz(s_tab[s]) - pos;
+            dist = length(dir);
+            dir = dir / dist;
+            return xyz(s_tab[s + 1]) / ((dist * dist) * 0.03f);
+         }
+         const int s = sc.lslot[k] + 3 * index; // madarch-lights-spot_lights.adb:5-24
+         float4 a = s_tab[s];
+         dir = xyz(a) - pos;
+         dist = length(dir);
+         dir = dir / dist;
+         float attenuation = 1.0f / ((dist * dist) * 0.03f);
+         float theta = acos_(max_(dot(-dir, xyz(s_tab[s + 1])), 0.0f));
+         float ratio = clamp_(theta / a.w, 0.0f, 1.0f);
+         float visible = 1.0f - pow8_(ratio);
+         return (xyz(s_tab[s + 2]) * min_(attenuation, 1.5f)) * visible;
+      }
+      index -= n;
+   }
+   dir = F3(0.0f, 0.0f, 0.0f);
+   dist = 0.0f;
+   return F3(0.0f, 0.0f, 0.0f);
+}
+
+// -------------------------------------------------------------------------------- BRDF
+struct Material { f3 albedo; float metallic, roughness; };
+MDH_DEV Material get_material(const KScene &sc, int id) // glsl/materials.glsl:1-10
+{
+   float4 a = s_tab[sc.mat_slot + 2 * id], b = s_tab[sc.mat_slot + 2 * id + 1];
+   Material m;
+   m.albedo = xyz(a); m.metallic = a.w; m.roughness = b.x;
+   return m;
+}
+// glsl/cook_torrance_brdf.glsl:1-52
+MDH_DEV void cook_torrance(f3 N, f3 V, f3 L, float NdotL, f3 albedo, float metallic, float roughness, f3 &kD, f3 &kS)
+{
+   f3 H = normalize(V + L);
+   float NdotV = max_(dot(N, V), 0.0f);
+   f3 F0 = F3(mix_(0.04f, albedo.x, metallic), mix_(0.04f, albedo.y, metallic), mix_(0.04f, albedo.z, metallic));
+   float a = roughness * roughness;
+   float a2 = a * a;
+   float NdotH = max_(dot(N, H), 0.0f);
+   float NdotH2 = NdotH * NdotH;
+   float denom = NdotH2 * (a2 - 1.0f) + 1.0f;
+   denom = MDH_PI * denom * denom;
+   float NDF = a2 / denom;
+   float rr = roughness + 1.0f;
+   float kk = (rr * rr) / 8.0f;
+   float ggx2 = NdotV / (NdotV * (1.0f - kk) + kk);
+   float ggx1 = NdotL / (NdotL * (1.0f - kk) + kk);
+   float G = ggx1 * ggx2;
+   float p5 = pow5_(1.001f - max_(dot(H, V), 0.0f));
+   f3 F = F3(F0.x + (1.0f - F0.x) * p5, F0.y + (1.0f - F0.y) * p5, F0.z + (1.0f - F0.z) * p5);
+   f3 numerator = F * (NDF * G);
+   float denominator = 4.0f * NdotV * NdotL;
+   float dm = max_(denominator, 0.001f);
+   kD = F3(1.0f - F.x, 1.0f - F.y, 1.0f - F.z) * (1.0f - metallic);
+   kS = min3s(numerator / dm, 1.0f);
+}
+// glsl/lighting.glsl:1-40
+template <bool PART>
+MDH_DEV f3 compute_direct_lighting(const KScene &sc, f3 pos, f3 normal, f3 dir, f3 albedo, float metallic, float roughness, bool direct_specular)
+{
+   f3 N = normal, V = -dir, Lo = F3(0.0f, 0.0f, 0.0f);
+   for (int i = 0; i < sc.total_lights; ++i) {
+      f3 L;
+      float L_dist;
+      f3 radiance = sample_light(sc, i, pos, L, L_dist);
+      float NdotL = max_(dot(N, L), 0.0f);
+      f3 kD, kS;
+      cook_torrance(N, V, L, NdotL, albedo, metallic, roughness, kD, kS);
+      float shadows = 0.0f;
+      if (NdotL > MDH_EPS) shadows = softshadows<PART>(sc, pos + (normal * MDH_MIN_STEP) * 5.0f, L, 0.0f, L_dist, 64.0f);
+      if (!direct_specular) kS = F3(0.0f, 0.0f, 0.0f);
+      f3 brdf = (kD * albedo) / MDH_PI + kS;
+      Lo = Lo + ((brdf * radiance) * NdotL) * shadows;
+   }
+   return Lo;
+}
+// glsl/lighting.glsl:42-49
+MDH_DEV f3 compute_indirect_lighting(f3 irradiance, f3 radiance, f3 V, f3 N, f3 L, f3 albedo, float metallic, float roughness)
+{
+   f3 kD, kS;
+   float NdotL = max_(dot(N, L), 0.0f);
+   cook_torrance(N, V, L, NdotL, albedo, metallic, roughness, kD, kS);
+   return (kD * irradiance) / MDH_PI + (kS * radiance) * NdotL;
+}
+// glsl/lighting.glsl:51-69
+template <bool PART> MDH_DEV float compute_ambient_occlusion(const KScene &sc, f3 pos, f3 normal, int steps)
+{
+   if (steps <= 0) return 1.0f;
+   const float ao_step_size = 0.1f;
+   float ao_sum = 0.0f, max_ao_sum = 0.0f, factor = 1.0f;
+   for (int i = 0; i < steps; ++i) {
+      f3 p = pos + (normal * (float)(i + 1)) * ao_step_size;
+      ao_sum += factor * sdf<PART>(sc, p);
+      max_ao_sum += factor * (float)(i + 1) * ao_step_size;
+      factor = factor * 0.5f;
+   }
+   return 0.6f + 0.4f * ao_sum / max_ao_sum;
+}
+
+// ------------------------------------------------------------------------- probe utils
+// glsl/probe_utils.glsl:19-56
+MDH_DEV i3 probe_id_to_grid(const KProbes &pr, int id)
+{
+   int xy = pr.gx * pr.gy;
+   i3 g;
+   g.z = id / xy;
+   g.y = (id - g.z * xy) / pr.gx;
+   g.x = id - g.z * xy - g.y * pr.gx;
+   return g;
+}
+MDH_DEV f3 grid_to_world(const KProbes &pr, i3 g) { return F3((float)g.x * pr.sx, (float)g.y * pr.sy, (float)g.z * pr.sz); }
+MDH_DEV i3 world_to_grid(const KProbes &pr, f3 p)
+{
+   f3 f = floor3(p / F3(pr.sx, pr.sy, pr.sz));
+   i3 g;
+   g.x = (int)f.x; g.y = (int)f.y; g.z = (int)f.z;
+   return g;
+}
+MDH_DEV int grid_to_probe_id(const KProbes &pr, i3 g) { return g.z * pr.gx * pr.gy + g.y * pr.gx + g.x; }
+MDH_DEV f2 probe_id_to_coord(const KProbes &pr, int id)
+{
+   int y = id / pr.pcx, x = id - y * pr.pcx;
+   return F2((float)x / (float)pr.pcx, (float)y / (float)pr.pcy);
+}
+// glsl/probe_utils.glsl:58-92
+MDH_DEV float sign_not_zero(float v) { return v >= 0.0f ? 1.0f : -1.0f; }
+MDH_DEV f2 float32x3_to_oct(f3 v)
+{
+   float s = 1.0f / ((__builtin_fabsf(v.x) + __builtin_fabsf(v.y)) + __builtin_fabsf(v.z));
+   f2 p = F2(v.x * s, v.y * s);
+   if (v.z <= 0.0f) return F2((1.0f - __builtin_fabsf(p.y)) * sign_not_zero(p.x), (1.0f - __builtin_fabsf(p.x)) * sign_not_zero(p.y));
+   return p;
+}
+MDH_DEV f3 oct_to_float32x3(f2 e)
+{
+   f3 v = F3(e.x, e.y, (1.0f - __builtin_fabsf(e.x)) - __builtin_fabsf(e.y));
+   if (v.z < 0.0f) {
+      float nx = (1.0f - __builtin_fabsf(v.y)) * sign_not_zero(v.x);
+      float ny = (1.0f - __builtin_fabsf(v.x)) * sign_not_zero(v.y);
+      v.x = nx;
+      v.y = ny;
+   }
+   return normalize(v);
+}
+MDH_DEV f3 ray_id_to_ray_dir(f2 id) { return oct_to_float32x3(F2(id.x * 2.0f - 1.0f, id.y * 2.0f - 1.0f)); }
+MDH_DEV f2 ray_dir_to_ray_id(f3 d)
+{
+   f2 raw = float32x3_to_oct(d);
+   return F2((raw.x + 1.0f) * 0.5f, (raw.y + 1.0f) * 0.5f);
+}
+
+// -------------------------------------------------------------------------- textures
+// GL_MIRRORED_REPEAT (support/render_passes.adb:111-112)
+MDH_DEV int mirror(int i, int n)
+{
+   int m = i % (2 * n);
+   if (m < 0) m += 2 * n;
+   return m >= n ? 2 * n - 1 - m : m;
+}
+MDH_DEV float unorm8(float x) { return (x != x) ? 0.0f : __builtin_rintf(clamp_(x, 0.0f, 1.0f) * 255.0f); }
+
+// Probe atlases are stored probe-major -- [probe][y][x], RGBA8 or float4 texels -- so a
+// rank's probe slice is one contiguous range (DESIGN.md "HBM layout").  (X, Y) are texel
+// coordinates of the reference's 2-D atlas image, X = tile_x * res + x.
+MDH_DEV size_t atlas_index(int pcx, int res, int X, int Y)
+{
+   int tx = X / res, ty = Y / res;
+   return ((size_t)(ty * pcx + tx) * res + (Y - ty * res)) * res + (X - tx * res);
+}
+MDH_DEV f3 atlas_texel(const void *base, int fmt, size_t idx)
+{
+   if (fmt == 0) {
+      uchar4 t = ((const uchar4 *)base)[idx];
+      return F3((float)t.x / 255.0f, (float)t.y / 255.0f, (float)t.z / 255.0f);
+   }
+   float4 t = ((const float4 *)base)[idx];
+   return F3(t.x, t.y, t.z);
+}
+MDH_DEV void atlas_store(void *base, int fmt, size_t idx, f3 v)
+{
+   if (fmt == 0) {
+      uchar4 t;
+      t.x = (unsigned char)unorm8(v.x); t.y = (unsigned char)unorm8(v.y); t.z = (unsigned char)unorm8(v.z); t.w = 255;
+      ((uchar4 *)base)[idx] = t;
+   } else {
+      float4 t;
+      t.x = (v.x != v.x) ? 0.0f : v.x; t.y = (v.y != v.y) ? 0.0f : v.y; t.z = (v.z != v.z) ? 0.0f : v.z; t.w = 1.0f;
+      ((float4 *)base)[idx] = t;
+   }
+}
+// GL_LINEAR on the atlas image of pcx*res x pcy*res texels (render_passes.adb:113-114)
+MDH_DEV f3 atlas_sample(const void *base, int fmt, int pcx, int pcy, int res, float cx, float cy)
+{
+   const int W = pcx * res, H = pcy * res;
+   float px = cx * (float)W - 0.5f, py = cy * (float)H - 0.5f;
+   float fx0 = __builtin_floorf(px), fy0 = __builtin_floorf(py);
+   float fx = px - fx0, fy = py - fy0;
+   int x0 = mirror((int)fx0, W), x1 = mirror((int)fx0 + 1, W), y0 = mirror((int)fy0, H), y1 = mirror((int)fy0 + 1, H);
+   float w00 = (1.0f - fx) * (1.0f - fy), w10 = fx * (1.0f - fy), w01 = (1.0f - fx) * fy, w11 = fx * fy;
+   f3 a = atlas_texel(base, fmt, atlas_index(pcx, res, x0, y0)), b = atlas_texel(base, fmt, atlas_index(pcx, res, x1, y0));
+   f3 c = atlas_texel(base, fmt, atlas_index(pcx, res, x0, y1)), d = atlas_texel(base, fmt, atlas_index(pcx, res, x1, y1));
+   return ((a * w00 + b * w10) + c * w01) + d * w11;
+}
+
+// ------------------------------------------------------------------ probes: sampling
+// glsl/render_probes.glsl:6-69
+template <bool PART> MDH_DEV f3 sample_irradiance(const KScene &sc, const KProbes &pr, f3 pos, f3 normal)
+{
+   i3 gp = world_to_grid(pr, pos);
+   f3 irradiance = F3(0.0f, 0.0f, 0.0f);
+   float total_weight = 0.0f;
+   f3 alpha = pos / F3(pr.sx, pr.sy, pr.sz) - F3((float)gp.x, (float)gp.y, (float)gp.z);
+   const float irr_min = 0.5f / (float)pr.ires, irr_max = 1.0f - irr_min;
+   f2 rid = ray_dir_to_ray_id(normal);
+   rid = F2(clamp_(rid.x, irr_min, irr_max), clamp_(rid.y, irr_min, irr_max));
+   const f3 from = pos + (normal * MDH_MIN_STEP) * 5.0f;
+   for (int i = 0; i < 8; ++i) {
+      const int ox = i & 1, oy = (i >> 1) & 1, oz = (i >> 2) & 1;
+      i3 q;
+      q.x = iclamp_(gp.x + ox, 0, pr.gx - 1); q.y = iclamp_(gp.y + oy, 0, pr.gy - 1); q.z = iclamp_(gp.z + oz, 0, pr.gz - 1);
+      f3 hit_to_probe = grid_to_world(pr, q) - pos;
+      float probe_distance = length(hit_to_probe);
+      f3 dir_to_probe = hit_to_probe / probe_distance;
+      float weight = 1.0f;
+      float angle = (dot(dir_to_probe, normal) + 1.0f) * 0.5f;
+      weight *= angle * angle + 0.2f;
+      weight *= raycast_visibility<PART>(sc, from, dir_to_probe, probe_distance - MDH_MIN_STEP * 5.0f);
+      const float crush = 0.2f;
+      if (weight < crush) weight *= weight * weight * (1.0f / (crush * crush));
+      f3 tri = F3(mix_(1.0f - alpha.x, alpha.x, (float)ox), mix_(1.0f - alpha.y, alpha.y, (float)oy), mix_(1.0f - alpha.z, alpha.z, (float)oz));
+      weight *= tri.x * tri.y * tri.z;
+      f2 base = probe_id_to_coord(pr, grid_to_probe_id(pr, q));
+      f3 tx = atlas_sample(pr.irr, pr.fmt, pr.pcx, pr.pcy, pr.ires, base.x + rid.x / (float)pr.pcx, base.y + rid.y / (float)pr.pcy);
+      irradiance = irradiance + sqrt3(tx) * weight;
+      total_weight += weight;
+   }
+   if (total_weight == 0.0f) return F3(0.0f, 0.0f, 0.0f); // render_probes.glsl:65 is 0/0 here
+   irradiance = irradiance / total_weight;
+   return irradiance * irradiance;
+}
+// glsl/render_probes.glsl:138-209, M_COMPUTE_INDIRECT_SPECULAR == 2 with M_ADD_INDIRECT_SPECULAR == 1
+template <bool PART> MDH_DEV f3 sample_radiance_no_specular(const KScene &sc, const KProbes &pr, f3 pos, f3 normal, f3 dir)
+{
+   int prim_index = -1, steps;
+   float t;
+   f3 spec_pos;
+   if (!raycast<PART>(sc, pos + (normal * MDH_MIN_STEP) * 5.0f, dir, prim_index, spec_pos, t, steps)) return F3(0.0f, 0.0f, 0.0f);
+   f3 spec_normal;
+   int spec_mat;
+   primitive_info(sc, prim_index, spec_pos, spec_normal, spec_mat);
+   i3 gp = world_to_grid(pr, spec_pos);
+   float max_weight = -2.0f;
+   i3 best_q;
+   best_q.x = 0; best_q.y = 0; best_q.z = 0;
+   f3 best_pts = F3(0.0f, 0.0f, 1.0f);
+   const f3 from = spec_pos + (spec_normal * MDH_MIN_STEP) * 5.0f;
+   for (int i = 0; i < 8; ++i) {
+      i3 q;
+      q.x = iclamp_(gp.x + (i & 1), 0, pr.gx - 1); q.y = iclamp_(gp.y + ((i >> 1) & 1), 0, pr.gy - 1); q.z = iclamp_(gp.z + ((i >> 2) & 1), 0, pr.gz - 1);
+      f3 probe_to_spec = spec_pos - grid_to_world(pr, q);
+      float distance = length(probe_to_spec);
+      probe_to_spec = probe_to_spec / distance;
+      float weight = dot(probe_to_spec, -spec_normal);
+      weight *= raycast_visibility<PART>(sc, from, -probe_to_spec, distance - MDH_MIN_STEP * 5.0f);
+      if (weight > max_weight) { max_weight = weight; best_q = q; best_pts = probe_to_spec; }
+   }
+   f2 base = probe_id_to_coord(pr, grid_to_probe_id(pr, best_q));
+   const float rmin = 0.5f / (float)pr.rres, rmax = 1.0f - rmin;
+   f2 rid = ray_dir_to_ray_id(best_pts);
+   rid = F2(clamp_(rid.x, rmin, rmax), clamp_(rid.y, rmin, rmax));
+   // textureLod(.., 1.0) on a single-level texture samples level 0
+   f3 radiance = atlas_sample(pr.rad, pr.fmt, pr.pcx, pr.pcy, pr.rres, base.x + rid.x / (float)pr.pcx, base.y + rid.y / (float)pr.pcy);
+   Material m = get_material(sc, spec_mat);
+   return radiance + compute_direct_lighting<PART>(sc, spec_pos, spec_normal, dir, F3(0.0f, 0.0f, 0.0f), m.metallic, m.roughness, true);
+}
+
+// ------------------------------------------------------------------------ volumetrics
+#define MDH_TAU 0.1f // glsl/volumetrics.glsl:12
+// glsl/volumetrics.glsl:21-30
+MDH_DEV float henvey_greenstein_phase(f3 in_dir, f3 out_dir)
+{
+   float cos_angle = dot(in_dir, out_dir);
+   float t2 = MDH_TAU * MDH_TAU;
+   float result = 1.0f - t2;
+   result /= 4.0f * MDH_PI * pow1_5_(1.0f + t2 - 2.0f * MDH_TAU * cos_angle);
+   return result;
+}
+// bilinear tap of a plain row-major texture with C floats per texel
+template <int C> MDH_DEV void tex_sample(const float *data, int W, int H, float cx, float cy, float *out)
+{
+   float px = cx * (float)W - 0.5f, py = cy * (float)H - 0.5f;
+   float fx0 = __builtin_floorf(px), fy0 = __builtin_floorf(py);
+   float fx = px - fx0, fy = py - fy0;
+   int x0 = mirror((int)fx0, W), x1 = mirror((int)fx0 + 1, W), y0 = mirror((int)fy0, H), y1 = mirror((int)fy0 + 1, H);
+   float w00 = (1.0f - fx) * (1.0f - fy), w10 = fx * (1.0f - fy), w01 = (1.0f - fx) * fy, w11 = fx * fy;
+   const float *a = data + ((size_t)y0 * W + x0) * C, *b = data + ((size_t)y0 * W + x1) * C;
+   const float *c = data + ((size_t)y1 * W + x0) * C, *d = data + ((size_t)y1 * W + x1) * C;
+#pragma unroll
+   for (int k = 0; k < C; ++k) out[k] = ((a[k] * w00 + b[k] * w10) + c[k] * w01) + d[k] * w11;
+}
+// glsl/volumetrics.glsl:34-54; on a miss len = max_dist
+MDH_DEV f3 render_volumetrics(const KScene &sc, const KVolumetrics &vol, f3 L, f3 from, f3 to, bool hit, f2 frag_pos)
+{
+   f2 tc = F2((frag_pos.x + 1.0f) * 0.5f, (frag_pos.y + 1.0f) * 0.5f);
+   float len = hit ? length(to - from) : sc.max_dist;
+   float closest = sc.max_dist;
+   f3 fog = F3(0.0f, 0.0f, 0.0f);
+   const float sx = 1.0f / (float)vol.sw, sy = 1.0f / (float)vol.sh;
+   for (int x = -1; x <= 1; ++x)
+      for (int y = -1; y <= 1; ++y) {
+         float d[4];
+         tex_sample<4>((const float *)vol.scat, vol.sw, vol.sh, tc.x + (float)x * sx, tc.y + (float)y * sy, d);
+         float dist = __builtin_fabsf(d[3] - len);
+         if (dist < closest) { closest = dist; fog = F3(d[0], d[1], d[2]); }
+      }
+   return L * exp_(-len * MDH_TAU) + fog;
+}
+
+// ----------------------------------------------------------------- pixel_color_probes
+struct PassCfg {
+   bool direct_specular;   // M_COMPUTE_DIRECT_SPECULAR
+   bool indirect_specular; // M_COMPUTE_INDIRECT_SPECULAR == 2
+   int ao_steps;           // M_AMBIENT_OCCLUSION_STEPS
+   bool volumetrics;       // M_RENDER_VOLUMETRICS
+};
+struct PrimaryHit { int index; float t; int steps; };
+
+// glsl/render_probes.glsl:246-291.  MODE: 0 reference, 1 primary ray only, 2 direct + AO
+template <bool PART, int MODE>
+MDH_DEV f3 pixel_color_probes(const KScene &sc, const KProbes &pr, const KVolumetrics &vol, const PassCfg cfg, f3 from, f3 dir, f2 frag_pos, PrimaryHit &ph)
+{
+   int prim_index = -1, steps = 0;
+   float t = 0.0f;
+   f3 pos = F3(0.0f, 0.0f, 0.0f), result;
+   const bool hit = raycast<PART>(sc, from, dir, prim_index, pos, t, steps);
+   ph.index = hit ? prim_index : -1;
+   ph.t = hit ? t : 0.0f;
+   ph.steps = steps;
+   if (hit) {
+      int material_id;
+      f3 normal;
+      primitive_info(sc, prim_index, pos, normal, material_id);
+      if (MODE == 1) return normal * 0.5f + F3s(0.5f);
+      Material m = get_material(sc, material_id);
+      f3 direct = compute_direct_lighting<PART>(sc, pos, normal, dir, m.albedo, m.metallic, m.roughness, cfg.direct_specular);
+      if (MODE == 2) {
+         result = direct * compute_ambient_occlusion<PART>(sc, pos, normal, cfg.ao_steps);
+      } else {
+         f3 irradiance = sample_irradiance<PART>(sc, pr, pos, normal);
+         f3 specular_col = F3(0.0f, 0.0f, 0.0f);
+         f3 specular_dir = reflect(dir, normal);
+         if (cfg.indirect_specular && m.roughness < 0.75f) specular_col = sample_radiance_no_specular<PART>(sc, pr, pos, normal, specular_dir);
+         f3 indirect = compute_indirect_lighting(irradiance, specular_col, -dir, normal, specular_dir, m.albedo, m.metallic, m.roughness);
+         float ao = compute_ambient_occlusion<PART>(sc, pos, normal, cfg.ao_steps);
+         result = (direct + indirect) * ao;
+      }
+   } else {
+      float s = dir.y * 0.7f;
+      result = F3(0.30f - s, 0.36f - s, 0.60f - s);
+   }
+   if (MODE == 0 && cfg.volumetrics) result = render_volumetrics(sc, vol, result, from, pos, hit, frag_pos);
+   return result;
+}
+
+// camera ray (glsl/draw_screen.glsl:21-24)
+MDH_DEV f3 mat_mul(const float *m, f3 v)
+{
+   return F3((m[0] * v.x + m[3] * v.y) + m[6] * v.z, (m[1] * v.x + m[4] * v.y) + m[7] * v.z, (m[2] * v.x + m[5] * v.y) + m[8] * v.z);
+}
+MDH_DEV void camera_ray(const KCamera &cam, float u, float v, f3 &origin, f3 &dir)
+{
+   f3 frag = F3(u, v, 0.0f);
+   f3 d = normalize(frag - F3(0.0f, 0.0f, -1.5f));
+   dir = mat_mul(cam.m, d);
+   origin = mat_mul(cam.m, frag) + F3(cam.px, cam.py, cam.pz);
+}
+// texel / pixel centre in [-1, 1]
+MDH_DEV float centre(int i, int n) { return (float)(2 * i + 1) / (float)n - 1.0f; }

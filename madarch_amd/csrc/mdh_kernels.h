@@ -1,0 +1,334 @@
+// mdh_kernels.h -- the gfx950 kernels, one per pass of Renderers.Render
+// (reference madarch/madarch-renderers.adb:302-321) plus the partition-table build
+// and the batched distance query.  See mdh_device.h for the device functions and
+// DESIGN.md for the launch shapes and the HBM layout.
+#pragma once
+
+#include "mdh_device.h"
+
+#define MDH_BLOCK 256 // 4 wavefronts; every wavefront owns one 8x8 tile
+
+// ------------------------------------------------------------------------ screen pass
+struct ScreenArgs {
+   int W, H;
+   int tiles_x, n_tiles; // 8x8 tiles of the whole image
+   int rank, world;      // this launch draws tiles rank, rank + world, ...
+   int ao_steps;
+   float4 *fb; // W*H, row 0 = top
+   int *gb_index;
+   float *gb_t;
+   int *gb_steps;
+};
+
+// draw_screen.glsl:20-30.  One wavefront per 8x8 pixel tile: lane = (y & 7) * 8 + (x & 7).
+template <bool PART, int MODE, bool GBUF>
+__global__ __launch_bounds__(MDH_BLOCK) void k_screen(KScene sc, KProbes pr, KVolumetrics vol, KCamera cam, ScreenArgs a)
+{
+   stage_table(sc);
+   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+   const int own = blockIdx.x * (MDH_BLOCK / 64) + wave;
+   const int tile = a.rank + own * a.world;
+   if (tile >= a.n_tiles) return;
+   const int i = (tile % a.tiles_x) * 8 + (lane & 7), j = (tile / a.tiles_x) * 8 + (lane >> 3);
+   if (i >= a.W || j >= a.H) return;
+   const float u = centre(i, a.W), v = -centre(j, a.H); // row 0 = top
+   f3 origin, dir;
+   camera_ray(cam, u, v, origin, dir);
+   PassCfg cfg; // renderers.adb:136-143
+   cfg.direct_specular = true;
+   cfg.indirect_specular = true;
+   cfg.ao_steps = a.ao_steps;
+   cfg.volumetrics = vol.enabled != 0;
+   PrimaryHit ph;
+   f3 c = pixel_color_probes<PART, MODE>(sc, pr, vol, cfg, origin, dir, F2(u, v), ph);
+   if (MODE != 1) // draw_screen.glsl:29
+      c = F3(pow_(c.x / (c.x + 1.0f), 0.4545f), pow_(c.y / (c.y + 1.0f), 0.4545f), pow_(c.z / (c.z + 1.0f), 0.4545f));
+   const size_t px = (size_t)j * a.W + i;
+   a.fb[px] = make_float4(c.x, c.y, c.z, 1.0f);
+   if (GBUF) {
+      a.gb_index[px] = ph.index;
+      a.gb_t[px] = ph.t;
+      a.gb_steps[px] = ph.steps;
+   }
+}
+
+// ---------------------------------------------------------------------- radiance pass
+// compute_probe_radiance.glsl:16-27.  One wavefront per 8x8 texel tile of one probe's
+// octahedral map; all 64 rays of a wave leave the same probe position.
+template <bool PART> __global__ __launch_bounds__(MDH_BLOCK) void k_radiance(KScene sc, KProbes pr)
+{
+   stage_table(sc);
+   const int per_probe = pr.rres * pr.rres;
+   const long lin = (long)blockIdx.x * MDH_BLOCK + threadIdx.x;
+   const int probe = pr.probe_begin + (int)(lin / per_probe);
+   if (probe >= pr.probe_end) return;
+   const int rem = (int)(lin % per_probe);
+   int x, y;
+   if ((pr.rres & 7) == 0) {
+      const int tile = rem >> 6, l = rem & 63, tpr = pr.rres >> 3;
+      x = (tile % tpr) * 8 + (l & 7);
+      y = (tile / tpr) * 8 + (l >> 3);
+   } else {
+      y = rem / pr.rres;
+      x = rem - y * pr.rres;
+   }
+   const int ty = probe / pr.pcx, tx = probe - ty * pr.pcx;
+   const int i = tx * pr.rres + x, j = ty * pr.rres + y; // texel of the reference's 2-D atlas image
+   const f2 nc = F2((centre(i, pr.pcx * pr.rres) + 1.0f) * 0.5f, (centre(j, pr.pcy * pr.rres) + 1.0f) * 0.5f);
+   // coord_to_probe_id / probe position (probe_utils.glsl:19-40)
+   const int probe_id = (int)(nc.y * (float)pr.pcy) * pr.pcx + (int)(nc.x * (float)pr.pcx);
+   const f3 world = grid_to_world(pr, probe_id_to_grid(pr, probe_id));
+   const f3 ray_dir = ray_id_to_ray_dir(F2(fract_(nc.x * (float)pr.pcx), fract_(nc.y * (float)pr.pcy)));
+   PassCfg cfg; // renderers.adb:115-117: no specular; AO and volumetrics macros undefined
+   cfg.direct_specular = false;
+   cfg.indirect_specular = false;
+   cfg.ao_steps = 0;
+   cfg.volumetrics = false;
+   KVolumetrics novol = {};
+   PrimaryHit ph;
+   f3 c = pixel_color_probes<PART, 0>(sc, pr, novol, cfg, world, ray_dir, nc, ph);
+   atlas_store(pr.rad, pr.fmt, atlas_index(pr.pcx, pr.rres, i, j), c);
+}
+
+// -------------------------------------------------------------------- irradiance pass
+// update_probe_irradiance.glsl:8-43: every irradiance texel sums its probe's rres x rres
+// radiance taps (bilinear, at texel corners, so the first row/column bleed in from the
+// neighbouring tiles) in the reference's order.
+__global__ __launch_bounds__(64) void k_irradiance(KProbes pr)
+{
+   const int per_probe = pr.ires * pr.ires;
+   const long lin = (long)blockIdx.x * 64 + threadIdx.x;
+   const int probe = pr.probe_begin + (int)(lin / per_probe);
+   if (probe >= pr.probe_end) return;
+   const int rem = (int)(lin % per_probe);
+   const int y = rem / pr.ires, x = rem - y * pr.ires;
+   const int ty = probe / pr.pcx, tx = probe - ty * pr.pcx;
+   const int i = tx * pr.ires + x, j = ty * pr.ires + y;
+   const f2 nc = F2((centre(i, pr.pcx * pr.ires) + 1.0f) * 0.5f, (centre(j, pr.pcy * pr.ires) + 1.0f) * 0.5f);
+   const f3 irr_dir = ray_id_to_ray_dir(F2(fract_(nc.x * (float)pr.pcx), fract_(nc.y * (float)pr.pcy)));
+   const int probe_id = (int)(nc.y * (float)pr.pcy) * pr.pcx + (int)(nc.x * (float)pr.pcx);
+   const f2 rad_coord = probe_id_to_coord(pr, probe_id);
+   const float pcx = (float)pr.pcx, pcy = (float)pr.pcy;
+   const f2 step = F2(1.0f / pcx / (float)pr.rres, 1.0f / pcy / (float)pr.rres);
+   f3 irradiance = F3(0.0f, 0.0f, 0.0f);
+   float total_weight = 0.0f;
+   for (int yy = 0; yy < pr.rres; ++yy)
+      for (int xx = 0; xx < pr.rres; ++xx) {
+         f2 c = F2(clamp_(rad_coord.x + (float)xx * step.x, step.x, 1.0f - step.x), clamp_(rad_coord.y + (float)yy * step.y, step.y, 1.0f - step.y));
+         f3 rad = atlas_sample(pr.rad, pr.fmt, pr.pcx, pr.pcy, pr.rres, c.x, c.y);
+         f3 rad_dir = ray_id_to_ray_dir(F2(fract_(c.x * pcx), fract_(c.y * pcy)));
+         float w = max_(dot(irr_dir, rad_dir), 0.0f);
+         irradiance = irradiance + rad * w;
+         total_weight += w;
+      }
+   irradiance = irradiance / total_weight;
+   atlas_store(pr.irr, pr.fmt, atlas_index(pr.pcx, pr.ires, i, j), irradiance);
+}
+
+// -------------------------------------------------------------------- visibility pass
+// compute_frustrum_visibility.glsl:8-42: one froxel (x, y, depth slice) per lane
+template <bool PART> __global__ __launch_bounds__(MDH_BLOCK) void k_visibility(KScene sc, KVolumetrics vol, KCamera cam)
+{
+   stage_table(sc);
+   const int W = vol.vw, H = vol.vh * vol.vz;
+   const long lin = (long)blockIdx.x * MDH_BLOCK + threadIdx.x;
+   if (lin >= (long)W * H) return;
+   // 8x8 tiles when the width allows it, so a wave's rays are neighbours on the image plane
+   int i, j;
+   if ((W & 7) == 0 && (H & 7) == 0) {
+      const long tile = lin >> 6;
+      const int l = (int)(lin & 63), tpr = W >> 3;
+      i = (int)(tile % tpr) * 8 + (l & 7);
+      j = (int)(tile / tpr) * 8 + (l >> 3);
+   } else {
+      j = (int)(lin / W);
+      i = (int)(lin - (long)j * W);
+   }
+   const float px = centre(i, W), py = centre(j, H);
+   const float norm_height = (py + 1.0f) * 0.5f;
+   const float tex_height = norm_height * (float)vol.vz;
+   const float depth = __builtin_floorf(tex_height);
+   const float fract_height = tex_height - depth;
+   const float frag_height = fract_height * 2.0f - 1.0f;
+   f3 origin, dir;
+   camera_ray(cam, px, frag_height, origin, dir);
+   const f3 pos = origin + (dir * depth) * vol.vstep;
+   f3 result = F3(0.0f, 0.0f, 0.0f);
+   for (int l = 0; l < sc.total_lights; ++l) { // sample_lights :8-19
+      f3 L;
+      float L_dist;
+      f3 radiance = sample_light(sc, l, pos, L, L_dist);
+      float visibility = raycast_visibility<PART>(sc, pos, L, L_dist);
+      f3 L_in = radiance * (exp_(-L_dist * MDH_TAU) * visibility);
+      result = result + (L_in * MDH_TAU) * henvey_greenstein_phase(L, dir);
+   }
+   float *o = vol.vis + ((size_t)j * W + i) * 3;
+   o[0] = result.x; o[1] = result.y; o[2] = result.z;
+}
+
+// -------------------------------------------------------------------- scattering pass
+// accumulate_scattering.glsl:9-48
+template <bool PART> __global__ __launch_bounds__(MDH_BLOCK) void k_scattering(KScene sc, KVolumetrics vol, KCamera cam)
+{
+   stage_table(sc);
+   const int W = vol.sw, H = vol.sh;
+   const long lin = (long)blockIdx.x * MDH_BLOCK + threadIdx.x;
+   if (lin >= (long)W * H) return;
+   const int j = (int)(lin / W), i = (int)(lin - (long)j * W);
+   const float px = centre(i, W), py = centre(j, H);
+   f3 from, dir;
+   camera_ray(cam, px, py, from, dir);
+   const f2 norm_pos = F2(0.5f * (px + 1.0f), 0.5f * (py + 1.0f));
+   const float max_depth = vol.vstep * (float)vol.vz; // volumetrics.glsl:3-4
+   f3 to = from + dir * max_depth;
+   int idx = -1, steps;
+   float t;
+   f3 coll;
+   if (raycast<PART>(sc, from, dir, idx, coll, t, steps)) to = coll;
+   const float len = min_(length(to - from), max_depth);
+   f3 L = F3(0.0f, 0.0f, 0.0f);
+   for (float f = 0.0f; f < len; f += vol.sstep) {
+      const float rel = __builtin_floorf(f / vol.vstep); // sample_visibility :9-15
+      float tx[3];
+      tex_sample<3>(vol.vis, vol.vw, vol.vh * vol.vz, norm_pos.x, (norm_pos.y + rel) / (float)vol.vz, tx);
+      L = L + F3(tx[0], tx[1], tx[2]) * exp_(-f * MDH_TAU);
+   }
+   L = L * vol.sstep;
+   vol.scat[(size_t)j * W + i] = make_float4(L.x, L.y, L.z, len);
+}
+
+// ---------------------------------------------------------------- partition-table build
+struct PartBuildArgs {
+   int method;     // 0 CPU_Best, 1 CPU_Fast, 2 GPU_Fast (renderers.ads:93)
+   int gx, gy, gz; // cells visited; GPU_Fast: 2 * (dims / 2), the compute dispatch of renderers.adb:539-549
+   float sp[3], off[3];
+   float gpu_diag; // Length(spacing) as the generated GLSL text carries it (scenes.adb:1140-1143)
+   int *table;     // [cell][nk + index_count]
+   int *warnings;
+};
+#define MDH_PART_MAX_PRE 256
+
+// distance of primitive i of kind k through the table; ADA_DIV for the CPU builders, which
+// go through Primitives.Eval_Dist (madarch-primitives.adb:90-108)
+template <bool ADA_DIV> MDH_DEV float part_dist(const KScene &sc, int k, int i, f3 x)
+{
+   const int type = sc.ktype[k], slot = sc.kslot[k] + prim_slots(type) * i;
+   if (type == PK_TRIANGLE) return sd_triangle<ADA_DIV>(xyz(s_tab[slot]), xyz(s_tab[slot + 1]), xyz(s_tab[slot + 2]), x);
+   return prim_dist(type, slot, x);
+}
+
+// One lane per grid cell.  Update_Partitioning_CPU (renderers.adb:551-755) for methods
+// 0/1, partitioning_compute_grid_cell (scenes.adb:1120-1187) for method 2.
+__global__ __launch_bounds__(64) void k_partition_build(KScene sc, PartBuildArgs a)
+{
+   stage_table(sc);
+   const int lin = blockIdx.x * 64 + threadIdx.x;
+   if (lin >= a.gx * a.gy * a.gz) return;
+   const int X = lin / (a.gy * a.gz), Y = (lin / a.gz) % a.gy, Z = lin % a.gz;
+   const int cell = X * a.gy * a.gz + Y * a.gz + Z;
+   if (cell >= sc.part_cells) return;
+   const f3 sp = F3(a.sp[0], a.sp[1], a.sp[2]), off = F3(a.off[0], a.off[1], a.off[2]);
+   unsigned short pre[MDH_PART_MAX_PRE]; // (kind << 12) | index
+   int npre = 0;
+   unsigned char accepted[MDH_PART_MAX_PRE];
+   if (a.method == 2) {
+      const f3 center = (F3((float)X, (float)Y, (float)Z) + F3s(0.5f)) * sp + off;
+      const float thr = closest_primitive(sc, center) + a.gpu_diag;
+      for (int k = 0; k < sc.nk; ++k)
+         for (int i = 0; i < sc.kcount[k]; ++i)
+            if (part_dist<false>(sc, k, i, center) < thr && npre < MDH_PART_MAX_PRE) { pre[npre] = (unsigned short)((k << 12) | i); accepted[npre++] = 1; }
+   } else {
+      const f3 grid_pos = F3((float)X, (float)Y, (float)Z) * sp + off;
+      const float cell_diag = length(sp);
+      const f3 center = grid_pos + sp * 0.5f;
+      float closest = 1.0e10f;
+      for (int k = 0; k < sc.nk; ++k)
+         for (int i = 0; i < sc.kcount[k]; ++i) closest = min_(closest, part_dist<true>(sc, k, i, center));
+      for (int k = 0; k < sc.nk; ++k)
+         for (int i = 0; i < sc.kcount[k]; ++i)
+            if (part_dist<true>(sc, k, i, center) < closest + cell_diag && npre < MDH_PART_MAX_PRE) { pre[npre] = (unsigned short)((k << 12) | i); accepted[npre++] = (a.method == 1); }
+      if (a.method == 0) { // Find_Candidates, renderers.adb:669-723: 3x3x3 sample points
+         // acceptance ORDER defines the order of a kind's indices: keep a sequence number
+         int seq = 0;
+         for (int sx = 1; sx <= 3; ++sx)
+            for (int sy = 1; sy <= 3; ++sy)
+               for (int sz = 1; sz <= 3; ++sz) {
+                  f3 offv = (F3((float)sx, (float)sy, (float)sz) - F3s(1.0f)) / (F3s(3.0f) - F3s(1.0f));
+                  f3 pt = offv * sp + grid_pos;
+                  float c = 1.0e10f;
+                  int ci = -1;
+                  for (int q = 0; q < npre; ++q) {
+                     float d = part_dist<true>(sc, pre[q] >> 12, pre[q] & 0xfff, pt);
+                     if (d < c) { c = d; ci = q; }
+                  }
+                  if (ci >= 0 && !accepted[ci]) accepted[ci] = (unsigned char)(++seq);
+               }
+      }
+   }
+   // write counts and indices kind by kind (Write_Partitioning_Info, renderers.adb:578-608);
+   // the reference only warns when a cell overflows Index_Count, here the list is cut
+   int *rec = a.table + (size_t)cell * (sc.nk + sc.part_index_count);
+   int written = 0;
+   for (int k = 0; k < sc.nk; ++k) {
+      int n = 0;
+      if (a.method == 0) {
+         for (int s = 1; s <= 27; ++s)
+            for (int q = 0; q < npre; ++q)
+               if (accepted[q] == s && (pre[q] >> 12) == k) {
+                  if (written + n < sc.part_index_count) rec[sc.nk + written + n] = pre[q] & 0xfff;
+                  ++n;
+               }
+      } else {
+         for (int q = 0; q < npre; ++q)
+            if (accepted[q] && (pre[q] >> 12) == k) {
+               if (written + n < sc.part_index_count) rec[sc.nk + written + n] = pre[q] & 0xfff;
+               ++n;
+            }
+      }
+      if (written + n > sc.part_index_count) {
+         atomicAdd(a.warnings, 1);
+         n = sc.part_index_count - written;
+      }
+      rec[k] = n;
+      written += n;
+   }
+}
+
+// ------------------------------------------------------------------- Eval_Distance_To
+// renderers.adb:499-526, one query point per lane
+struct EvalArgs {
+   int n, n_kinds;
+   int kinds[MDH_MAX_KINDS];
+   int host_count[MDH_MAX_KINDS];
+   const float *pts;
+   float *normals;
+   float *dist;
+};
+template <bool ADA_DIV> __global__ __launch_bounds__(64) void k_eval_distance(KScene sc, EvalArgs a)
+{
+   stage_table(sc);
+   const int q = blockIdx.x * 64 + threadIdx.x;
+   if (q >= a.n) return;
+   const f3 p = F3(a.pts[3 * q], a.pts[3 * q + 1], a.pts[3 * q + 2]);
+   float closest = 1.0e10f;
+   f3 normal = F3(0.0f, 0.0f, 0.0f);
+   for (int kk = 0; kk < a.n_kinds; ++kk) {
+      const int k = a.kinds[kk], type = sc.ktype[k];
+      for (int i = 0; i < a.host_count[k]; ++i) {
+         float d = part_dist<ADA_DIV>(sc, k, i, p);
+         if (d < closest) {
+            closest = d;
+            const int slot = sc.kslot[k] + prim_slots(type) * i;
+            float4 A = s_tab[slot], B = s_tab[slot + 1];
+            switch (type) {
+            case PK_SPHERE: normal = normalize(p - xyz(A)); break;
+            case PK_PLANE: normal = xyz(A); break;
+            case PK_BOX: normal = nrm_box(A, B, p); break;
+            default: normal = nrm_triangle<ADA_DIV>(xyz(A), xyz(B), xyz(s_tab[slot + 2]), p); break;
+            }
+         }
+      }
+   }
+   a.dist[q] = closest;
+   if (a.normals) { a.normals[3 * q] = normal.x; a.normals[3 * q + 1] = normal.y; a.normals[3 * q + 2] = normal.z; }
+}

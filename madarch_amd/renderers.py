@@ -201,6 +201,9 @@ class Renderer:
         self._b.check(self._b.read_partitioning(self._h, _fp(out), out.size))
         return out
 
+    def Partition_Warnings(self):
+        return self._b.partition_warnings(self._h)
+
     def Destroy(self):
         if self._h is not None:
             self._b.destroy(self._h)
