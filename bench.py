@@ -1,0 +1,171 @@
+"""bench.py -- Mpixels/s of one full frame (Renderers.Render: DDGI radiance + irradiance
+passes, then the per-pixel screen pass) of the global_illumination scene at 1920x1080,
+BASELINE.json's metric and config 3, on N MI355X of one node.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one frame.  The scene, atlases and tables are resident in HBM before the timed
+region; frame read-back is excluded.  N > 1: image tiles and probe slices are split over
+the ranks (fixed frame => strong scaling) with two in-place RCCL all-gathers per frame
+(madarch_amd/sharding.py).  Prints one JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+WORKLOADS = {
+    # name: (scene, width, height, probes, screen mode)
+    "global_illumination_1080p_ddgi8x8x8": ("global_illumination", 1920, 1080, "gi8", 0),
+    "simple_scene_1080p_direct": ("simple_scene", 1920, 1080, None, 2),
+    "light_shafts_1080p": ("light_shafts", 1920, 1080, None, 0),
+    "global_illumination_4096sq_ddgi8x8x8": ("global_illumination", 4096, 4096, "gi8", 0),
+}
+
+
+def make_renderer(workload, binding, device=0):
+    from madarch_amd import _binding as B
+    from madarch_amd import examples
+    scene, W, H, probes, mode = WORKLOADS[workload]
+    P = examples.GI_8X8X8_PROBES if probes == "gi8" else None
+    R = examples.SCENES[scene](W, H, Probes=P, Binding=binding, Device=device)
+    R.Set_Option(B.OPT_SCREEN_MODE, mode)
+    return R
+
+
+def algorithmic_bytes_screen(R):
+    """Compulsory HBM bytes of ONE screen-pass launch (with the
+    reference's RGB8 atlases as RGBA8 texels): per pixel 16 B written + 8 bilinear
+    irradiance taps + 1 bilinear radiance tap (4 texels x 4 B each) + the scene tables
+    staged once per 256-pixel workgroup."""
+    from madarch_amd import _binding as B
+    texel = 4 if R.Get_Option(B.OPT_ATLAS_FORMAT) == 0 else 16
+    mode = R.Get_Option(B.OPT_SCREEN_MODE)
+    per_px = 16 + ((8 * 4 + 4) * texel if mode == 0 else 0)
+    n_ubo, _ = R.Scene_Buffer_Size()
+    tables = n_ubo + 656  # scene block + materials block (std140 sizes of the reference)
+    world = R.Get_Option(B.OPT_WORLD)
+    px = R.Width * R.Height / world
+    return px * per_px + (px / 256.0) * tables, per_px, tables
+
+
+def cpu_baseline(workload):
+    """The CPU oracle (a C restatement of the reference's path -- the Ada/GLSL reference
+    cannot be built here) on the host cores: one warm-up frame, one timed frame."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_engine import ORC_OPT_THREADS, oracle_binding
+    R = make_renderer(workload, oracle_binding())
+    cores = R.Get_Option(ORC_OPT_THREADS)
+    R.Render()
+    t = time.perf_counter()
+    R.Render()
+    dt = time.perf_counter() - t
+    mpix = R.Width * R.Height / dt / 1e6
+    R.Destroy()
+    return {"value": round(mpix, 4), "unit": "Mpixels/s", "cores": cores, "kind": "port",
+            "sample": "1 full %dx%d frame of the same workload after 1 warm-up frame, all passes, OpenMP over rows" % (R.Width, R.Height)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--workload", default="global_illumination_1080p_ddgi8x8x8", choices=sorted(WORKLOADS))
+    ap.add_argument("--atlas", default="rgb8", choices=("rgb8", "f32"))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    from madarch_amd import _binding as B
+    from madarch_amd import sharding
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    R = make_renderer(args.workload, B.hip_binding(), device=local_rank)
+    R.Set_Option(B.OPT_ATLAS_FORMAT, 0 if args.atlas == "rgb8" else 1)
+    exchange = sharding.DeviceExchange(dist, R, torch.device("cuda", local_rank)) if world > 1 else None
+    frame = sharding.ShardedFrame(R, rank, world, exchange)
+
+    def sync():
+        R.Finish()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        frame.Render()
+    sync()
+    R.Set_Option(B.OPT_TIMING, 1)
+    R.Reset_Pass_Times()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        frame.Render()
+    R.Finish()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    passes = {}
+    for p, name in enumerate(B.PASS_NAMES):
+        ms, n = R.Pass_Time(p)
+        if n:
+            passes[name] = {"ms_avg": round(ms / n, 4), "launches": n}
+
+    if rank == 0:
+        W, H = R.Width, R.Height
+        scene, _, _, probes, mode = WORKLOADS[args.workload]
+        value = W * H * args.steps / dt / 1e6
+        alg_bytes, per_px, tables = algorithmic_bytes_screen(R)
+        screen_ms = passes.get("screen", {}).get("ms_avg", float("nan"))
+        achieved = alg_bytes / (screen_ms * 1e-3) / 1e9
+        out = {
+            "metric": "Mpixels/sec at 1920x1080 global_illumination scene (one Renderers.Render frame: DDGI radiance + irradiance passes + screen pass)",
+            "value": round(value, 3), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": args.workload, "scene": scene, "width": W, "height": H,
+                       "probe_grid": "8x8x8" if probes == "gi8" else "4x3x3", "atlas": args.atlas,
+                       "screen_mode": mode, "parallelism": "tiles+probes/%d" % world},
+            "roofline": {"bound": "hbm", "kernel": "k_screen", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                         "algorithmic_bytes_per_launch": int(alg_bytes), "bytes_per_pixel": per_px,
+                         "kernel_ms_avg": screen_ms,
+                         "note": "the path is fp32-VALU bound (sphere tracing), not HBM bound; see DESIGN.md 'Roofline'"},
+            "passes": passes,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args.workload)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -222,6 +222,9 @@ int32_t mdh_atlas_device_ptr(mdh_renderer *r, int32_t tex, void **dptr, int64_t 
                              int64_t *own_offset, int64_t *own_bytes);
 /* the HIP stream (hipStream_t) every pass is enqueued on */
 int32_t mdh_stream(mdh_renderer *r, void **stream);
+/* enqueue on the caller's stream instead (e.g. the one an RCCL communicator is
+ * ordered with); NULL returns to the renderer's own stream */
+int32_t mdh_set_stream(mdh_renderer *r, void *stream);
 
 /* Renderers.Eval_Distance_To (madarch-renderers.adb:499-526), batched: for
  * each of n points the closest distance over the listed kinds (initial

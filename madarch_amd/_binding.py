@@ -114,6 +114,7 @@ HIP_ONLY_ABI = {
     "atlas_device_ptr": (_I, [_P, _I, C.POINTER(_P), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
                               C.POINTER(C.c_int64)]),
     "stream": (_I, [_P, C.POINTER(_P)]),
+    "set_stream": (_I, [_P, _P]),
 }
 
 

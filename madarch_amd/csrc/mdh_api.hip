@@ -137,11 +137,38 @@ struct mdh_renderer {
    int *d_gb_index = nullptr, *d_gb_steps = nullptr;
    float *d_gb_t = nullptr;
    KScene ks{};
-   // timing
-   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+   // timing: event pairs recorded around every pass, resolved lazily (no host sync per pass)
+   struct Pending { int pass; hipEvent_t e0, e1; };
+   std::vector<Pending> pending;
+   std::vector<hipEvent_t> free_events;
    double pass_ms[MDH_PASS_COUNT] = {0};
    long long pass_n[MDH_PASS_COUNT] = {0};
+   hipStream_t own_stream = nullptr;
 };
+
+static hipEvent_t get_event(mdh_renderer *r)
+{
+   if (!r->free_events.empty()) { hipEvent_t e = r->free_events.back(); r->free_events.pop_back(); return e; }
+   hipEvent_t e = nullptr;
+   if (hipEventCreate(&e) != hipSuccess) return nullptr;
+   return e;
+}
+// fold every finished event pair into the per-pass totals (waits for the stream)
+static int resolve_timing(mdh_renderer *r)
+{
+   if (r->pending.empty()) return MDH_OK;
+   HIP_TRY(hipStreamSynchronize(r->stream));
+   for (auto &p : r->pending) {
+      float ms = 0.0f;
+      HIP_TRY(hipEventElapsedTime(&ms, p.e0, p.e1));
+      r->pass_ms[p.pass] += ms;
+      r->pass_n[p.pass] += 1;
+      r->free_events.push_back(p.e0);
+      r->free_events.push_back(p.e1);
+   }
+   r->pending.clear();
+   return MDH_OK;
+}
 
 static int probe_total(const mdh_renderer *r) { return r->probes.probe_count[0] * r->probes.probe_count[1]; }
 static size_t texel_bytes(const mdh_renderer *r) { return r->opt_atlas == 0 ? 4 : 16; }
@@ -279,14 +306,14 @@ static int alloc_atlases(mdh_renderer *r)
 extern "C" int32_t mdh_destroy(mdh_renderer *r)
 {
    if (!r) return MDH_OK;
-   hipSetDevice(r->device);
-   if (r->stream) hipStreamSynchronize(r->stream);
+   (void)hipSetDevice(r->device);
+   if (r->stream) (void)hipStreamSynchronize(r->stream);
    void *ptrs[] = {r->d_table, r->d_part, r->d_warn, r->d_rad, r->d_irr, r->d_vis, r->d_scat, r->d_fb, r->d_gb_index, r->d_gb_steps, r->d_gb_t};
    for (void *p : ptrs)
-      if (p) hipFree(p);
-   if (r->ev0) hipEventDestroy(r->ev0);
-   if (r->ev1) hipEventDestroy(r->ev1);
-   if (r->stream) hipStreamDestroy(r->stream);
+      if (p) (void)hipFree(p);
+   for (auto &p : r->pending) { (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1); }
+   for (auto e : r->free_events) (void)hipEventDestroy(e);
+   if (r->own_stream) (void)hipStreamDestroy(r->own_stream);
    delete r;
    return MDH_OK;
 }
@@ -352,9 +379,8 @@ extern "C" int32_t mdh_create(int32_t width, int32_t height, const mdh_scene_des
       }                                                                                                            \
    } while (0)
    TRY_OR_FAIL(hipSetDevice(device));
-   TRY_OR_FAIL(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking));
-   TRY_OR_FAIL(hipEventCreate(&r->ev0));
-   TRY_OR_FAIL(hipEventCreate(&r->ev1));
+   TRY_OR_FAIL(hipStreamCreateWithFlags(&r->own_stream, hipStreamNonBlocking));
+   r->stream = r->own_stream;
    if ((rc = alloc_atlases(r)) != MDH_OK) return fail(rc);
    size_t px = (size_t)width * height;
    TRY_OR_FAIL(hipMalloc(&r->d_fb, px * sizeof(float4)));
@@ -554,7 +580,13 @@ static int run_pass(mdh_renderer *r, int pass)
    const bool part = r->part.enable != 0;
    KProbes pr = make_probes(r);
    KCamera cam = make_camera(r);
-   if (r->opt_timing) HIP_TRY(hipEventRecord(r->ev0, r->stream));
+   hipEvent_t e0 = nullptr, e1 = nullptr;
+   if (r->opt_timing) {
+      e0 = get_event(r);
+      e1 = get_event(r);
+      if (!e0 || !e1) return seterr(MDH_E_DEVICE, "hipEventCreate failed");
+      HIP_TRY(hipEventRecord(e0, r->stream));
+   }
    switch (pass) {
    case MDH_PASS_RADIANCE: {
       long n = (long)(pr.probe_end - pr.probe_begin) * pr.rres * pr.rres;
@@ -612,12 +644,9 @@ static int run_pass(mdh_renderer *r, int pass)
    }
    HIP_TRY(hipGetLastError());
    if (r->opt_timing) {
-      HIP_TRY(hipEventRecord(r->ev1, r->stream));
-      HIP_TRY(hipEventSynchronize(r->ev1));
-      float ms = 0.0f;
-      HIP_TRY(hipEventElapsedTime(&ms, r->ev0, r->ev1));
-      r->pass_ms[pass] += ms;
-      r->pass_n[pass] += 1;
+      HIP_TRY(hipEventRecord(e1, r->stream));
+      r->pending.push_back({pass, e0, e1});
+      if (r->pending.size() >= 4096) return resolve_timing(r);
    }
    return MDH_OK;
 }
@@ -650,7 +679,7 @@ extern "C" int32_t mdh_finish(mdh_renderer *r)
    if (!r) return seterr(MDH_E_INVALID, "null renderer");
    HIP_TRY(hipSetDevice(r->device));
    HIP_TRY(hipStreamSynchronize(r->stream));
-   return MDH_OK;
+   return resolve_timing(r);
 }
 
 extern "C" int32_t mdh_read_framebuffer(mdh_renderer *r, float *rgb_out)
@@ -823,6 +852,16 @@ extern "C" int32_t mdh_stream(mdh_renderer *r, void **stream)
    *stream = (void *)r->stream;
    return MDH_OK;
 }
+extern "C" int32_t mdh_set_stream(mdh_renderer *r, void *stream)
+{
+   if (!r) return seterr(MDH_E_INVALID, "null renderer");
+   HIP_TRY(hipSetDevice(r->device));
+   HIP_TRY(hipStreamSynchronize(r->stream));
+   int rc = resolve_timing(r);
+   if (rc != MDH_OK) return rc;
+   r->stream = stream ? (hipStream_t)stream : r->own_stream;
+   return MDH_OK;
+}
 
 // Eval_Distance_To (renderers.adb:499-526), batched on the device
 extern "C" int32_t mdh_eval_distance_to(mdh_renderer *r, int32_t n, const float *pts, const int32_t *kind_ixs, int32_t n_kinds,
@@ -849,13 +888,16 @@ extern "C" int32_t mdh_eval_distance_to(mdh_renderer *r, int32_t n, const float 
    HIP_TRY(hipMemcpyAsync(dist_out, d_d, (size_t)n * 4, hipMemcpyDeviceToHost, r->stream));
    if (normals_out) HIP_TRY(hipMemcpyAsync(normals_out, d_n, (size_t)n * 12, hipMemcpyDeviceToHost, r->stream));
    HIP_TRY(hipStreamSynchronize(r->stream));
-   hipFree(d_pts); hipFree(d_n); hipFree(d_d);
+   (void)hipFree(d_pts); (void)hipFree(d_n); (void)hipFree(d_d);
    return MDH_OK;
 }
 
 extern "C" int32_t mdh_pass_time(mdh_renderer *r, int32_t pass, double *ms, int64_t *launches)
 {
    if (!r || pass < 0 || pass >= MDH_PASS_COUNT) return seterr(MDH_E_INVALID, "bad argument");
+   HIP_TRY(hipSetDevice(r->device));
+   int rc = resolve_timing(r);
+   if (rc != MDH_OK) return rc;
    if (ms) *ms = r->pass_ms[pass];
    if (launches) *launches = r->pass_n[pass];
    return MDH_OK;
@@ -863,6 +905,9 @@ extern "C" int32_t mdh_pass_time(mdh_renderer *r, int32_t pass, double *ms, int6
 extern "C" int32_t mdh_reset_pass_times(mdh_renderer *r)
 {
    if (!r) return seterr(MDH_E_INVALID, "null renderer");
+   HIP_TRY(hipSetDevice(r->device));
+   int rc = resolve_timing(r);
+   if (rc != MDH_OK) return rc;
    for (int i = 0; i < MDH_PASS_COUNT; ++i) { r->pass_ms[i] = 0; r->pass_n[i] = 0; }
    return MDH_OK;
 }

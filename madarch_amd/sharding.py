@@ -1,0 +1,119 @@
+"""One frame of Renderers.Render split over the GPUs of a node, one process per GPU.
+
+The reference is a single-GPU program (madarch/madarch-renderers.adb:302-321 runs
+its passes back to back); what follows is the build's own design (DESIGN.md
+"Multi-GPU").  Per frame and rank r of N:
+
+  1. radiance pass for the probes [r P/N, (r+1) P/N)        -- no communication
+  2. all-gather of the radiance atlas slices                 -- RCCL over xGMI
+  3. irradiance pass for the same probes (needs the whole radiance atlas because
+     of the corner-sample bleed, update_probe_irradiance.glsl:26-31)
+  4. all-gather of the irradiance atlas slices
+  5. volumetric passes, replicated (they depend on the camera only)
+  6. screen pass for the 8x8 tiles t with t mod N == r       -- no communication
+
+The atlases are probe-major in HBM, so a rank's slice is one contiguous byte
+range and the all-gather runs in place on the atlas itself.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _binding as B
+
+
+class HostExchange:
+    """Atlas exchange through host memory and a torch.distributed group (gloo on
+    CPU, or any backend): used by the CPU tests of the sharded path and as the
+    fall-back when P is not divisible by N."""
+
+    def __init__(self, dist, group=None):
+        self.dist, self.group = dist, group
+
+    def all_gather(self, renderer, tex, rank, world):
+        import torch
+        P = renderer.Probe_Total()
+        bounds = [(P * r // world, P * (r + 1) // world) for r in range(world)]
+        b, e = bounds[rank]
+        mine = torch.from_numpy(renderer.Read_Atlas_Slice(tex, b, e - b))
+        res = mine.shape[1]
+        outs = [torch.empty((hi - lo, res, res, 3), dtype=torch.float32) for lo, hi in bounds]
+        self.dist.all_gather(outs, mine, group=self.group)
+        for (lo, hi), t in zip(bounds, outs):
+            if hi > lo and lo != b:
+                renderer.Write_Atlas_Slice(tex, lo, t.numpy())
+
+
+class _DevicePtr:
+    """Exposes a raw HIP allocation to torch without a copy (array interface v2)."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False),
+                                         "version": 2, "strides": None}
+
+
+class DeviceExchange:
+    """In-place RCCL all-gather on the probe-major atlases (backend "nccl" = RCCL).
+    The renderer is switched to torch's current stream so that kernels and
+    collectives are ordered on one stream."""
+
+    def __init__(self, dist, renderer, device, group=None):
+        import torch
+        self.dist, self.group, self.torch = dist, group, torch
+        self.device = device
+        b = renderer._b
+        stream = torch.cuda.current_stream(device).cuda_stream
+        b.check(b.set_stream(renderer._h, C.c_void_p(stream)))
+        self._views = {}
+
+    def _view(self, renderer, tex):
+        # (re)query: the atlas is reallocated when the format option changes
+        b = renderer._b
+        ptr, total, off, own = C.c_void_p(), C.c_int64(), C.c_int64(), C.c_int64()
+        b.check(b.atlas_device_ptr(renderer._h, tex, C.byref(ptr), C.byref(total), C.byref(off), C.byref(own)))
+        key = (tex, ptr.value, total.value)
+        if key not in self._views:
+            t = self.torch.as_tensor(_DevicePtr(ptr.value, total.value), device=self.device)
+            self._views = {k: v for k, v in self._views.items() if k[0] != tex}
+            self._views[key] = t
+        return self._views[key], off.value, own.value, total.value
+
+    def all_gather(self, renderer, tex, rank, world):
+        full, off, own, total = self._view(renderer, tex)
+        if own * world != total:
+            raise ValueError("probe count %d is not divisible by the world size %d" % (renderer.Probe_Total(), world))
+        self.dist.all_gather_into_tensor(full, full[off:off + own], group=self.group)
+
+
+class ShardedFrame:
+    """Drives one renderer per rank through the six steps above."""
+
+    def __init__(self, renderer, rank, world, exchange):
+        self.R, self.rank, self.world, self.exchange = renderer, rank, world, exchange
+        renderer.Set_Option(B.OPT_RANK, rank)
+        renderer.Set_Option(B.OPT_WORLD, world)
+
+    def Render(self):
+        R = self.R
+        if R.Get_Option(B.OPT_SCREEN_MODE) == 0:
+            R.Render_Pass(B.PASS_RADIANCE)
+            if self.world > 1:
+                self.exchange.all_gather(R, B.TEX_RADIANCE, self.rank, self.world)
+            R.Render_Pass(B.PASS_IRRADIANCE)
+            if self.world > 1:
+                self.exchange.all_gather(R, B.TEX_IRRADIANCE, self.rank, self.world)
+            if R.Volumetrics.Enabled:
+                R.Render_Pass(B.PASS_VISIBILITY)
+                R.Render_Pass(B.PASS_SCATTERING)
+        R.Render_Pass(B.PASS_SCREEN)
+
+    def Gather_Framebuffer(self, dist=None, group=None):
+        """Sum of the ranks' framebuffers (each pixel is non-zero on one rank only);
+        not part of the timed frame."""
+        img = self.R.Read_Framebuffer()
+        if self.world == 1 or dist is None:
+            return img
+        import torch
+        t = torch.from_numpy(np.ascontiguousarray(img))
+        dist.all_reduce(t, group=group)
+        return t.numpy()

@@ -1,0 +1,160 @@
+"""Parity of the HIP path with the CPU oracle on the same seeded inputs, through the C ABI
+(run with -m gpu on the MI355X box).  Small frames are compared whole; at BASELINE.json's
+full size (1920x1080, DDGI 8x8x8) the oracle renders a sample of the 8x8 tiles of the very
+same frame, and size-independent properties are checked on the whole frame."""
+import numpy as np
+import pytest
+
+from helpers import SMALL_PROBES, assert_parity, make, same_bits, snapshot
+from madarch_amd import _binding as B
+from madarch_amd import examples, renderers, sharding
+
+pytestmark = pytest.mark.gpu
+
+CASES = [  # scene, W, H, mode, atlas, frames, probes
+    ("simple_scene", 96, 64, 1, 0, 1, None),              # BASELINE config 1: primary rays only
+    ("simple_scene", 96, 64, 2, 0, 1, None),              # config 2: direct PBR + AO, partitioned
+    ("global_illumination", 80, 56, 0, 0, 3, None),       # config 3 shape, reference-default 4x3x3 probes
+    ("global_illumination", 80, 56, 0, 1, 3, None),       # fp32 atlases
+    ("global_illumination", 61, 37, 0, 0, 2, SMALL_PROBES),  # ragged: sizes that are no multiple of 8
+    ("light_shafts", 64, 48, 0, 0, 2, SMALL_PROBES),      # config 4: volumetrics
+    ("simple_scene", 64, 48, 0, 0, 2, SMALL_PROBES),      # partitioned scene through the full path
+]
+
+
+@pytest.mark.parametrize("scene,W,H,mode,atlas,frames,probes", CASES)
+def test_frame_parity(hip, orc, scene, W, H, mode, atlas, frames, probes):
+    got = snapshot(make(scene, W, H, hip, mode=mode, atlas=atlas, probes=probes), frames)
+    want = snapshot(make(scene, W, H, orc, mode=mode, atlas=atlas, probes=probes), frames)
+    assert_parity(got, want)
+    # stronger than the stated tolerance: the two images agree to the bit almost everywhere
+    assert (got["image"].view(np.uint32) == want["image"].view(np.uint32)).mean() > 0.999
+
+
+def test_moved_camera_and_light(hip, orc):
+    """A rotated camera (column-major matrix through the ABI) and a moved light."""
+    from madarch_amd.lights import spot_lights
+    outs = []
+    c, s = np.float32(np.cos(0.4)), np.float32(np.sin(0.4))
+    rot_y = [[c, 0, s], [0, 1, 0], [-s, 0, c]]
+    for b in (hip, orc):
+        R = make("global_illumination", 64, 40, b, probes=SMALL_PROBES)
+        R.Set_Camera_Position((3.0, 2.5, -2.0))
+        R.Set_Camera_Orientation(rot_y)
+        R.Set_Light(1, spot_lights.Spot_Light, spot_lights.Create((3.5, 5.0, 2.0), (-1.0, 0.0, 0.0), 3.1415 / 4.0, (0.9, 0.9, 0.8)))
+        outs.append(snapshot(R, 3))
+    assert_parity(*outs)
+
+
+def test_empty_scene_and_sky(hip, orc):
+    """No primitive added: every ray misses and returns the sky (render_probes.glsl:287)."""
+    from madarch_amd import scenes, windows
+    from madarch_amd.lights import point_lights
+    from madarch_amd.primitives import spheres
+    outs = []
+    for b in (hip, orc):
+        scene = scenes.Compile([(spheres.Sphere, 4)], [(point_lights.Point_Light, 2)],
+                               Partitioning=scenes.Partitioning_Settings(Enable=False))
+        R = renderers.Create(windows.Open(32, 24), scene, Volumetrics=renderers.No_Volumetrics, Binding=b)
+        R.Set_Option(B.OPT_GBUFFER, 1)
+        outs.append(snapshot(R, 1))
+    assert_parity(*outs)
+    assert (outs[0]["gb_index"] == -1).all()
+
+
+def test_set_primitive_updates_device_tables(hip, orc):
+    """Set_Primitive between frames (what the examples' loops do with lights) reaches the kernels."""
+    from madarch_amd.primitives import spheres
+    outs = []
+    for b in (hip, orc):
+        R = make("global_illumination", 48, 32, b, probes=SMALL_PROBES)
+        R.Render()
+        R.Set_Primitive(spheres.Sphere, 1, spheres.Create((2.0, 2.0, 3.0), 0.8, 4))
+        outs.append(snapshot(R, 2))
+    assert_parity(*outs)
+
+
+def test_sharded_frame_equals_whole_frame(hip):
+    """Two ranks' worth of tiles and probe slices, exchanged through the host, give the whole
+    frame bit for bit (the multi-GPU path with both 'ranks' on this one GPU)."""
+    whole = snapshot(make("global_illumination", 72, 40, hip, probes=SMALL_PROBES), 2)
+    Rs = [make("global_illumination", 72, 40, hip, probes=SMALL_PROBES) for _ in range(2)]
+    for r, R in enumerate(Rs):
+        R.Set_Option(B.OPT_RANK, r)
+        R.Set_Option(B.OPT_WORLD, 2)
+    P = Rs[0].Probe_Total()
+    for _ in range(2):
+        for p, tex in ((B.PASS_RADIANCE, B.TEX_RADIANCE), (B.PASS_IRRADIANCE, B.TEX_IRRADIANCE)):
+            for R in Rs:
+                R.Render_Pass(p)
+            lo = Rs[0].Read_Atlas_Slice(tex, 0, P // 2)
+            hi = Rs[1].Read_Atlas_Slice(tex, P // 2, P - P // 2)
+            Rs[0].Write_Atlas_Slice(tex, P // 2, hi)
+            Rs[1].Write_Atlas_Slice(tex, 0, lo)
+        for R in Rs:
+            R.Render_Pass(B.PASS_SCREEN)
+    img = Rs[0].Read_Framebuffer() + Rs[1].Read_Framebuffer()
+    assert same_bits(img, whole["image"])
+    assert same_bits(Rs[0].Read_Texture(B.TEX_IRRADIANCE), whole["irradiance"])
+    assert same_bits(Rs[1].Read_Texture(B.TEX_RADIANCE), whole["radiance"])
+
+
+# ---------------------------------------------------------------- BASELINE.json's full size
+@pytest.fixture(scope="module")
+def full_size(hip):
+    R = examples.global_illumination(1920, 1080, Probes=examples.GI_8X8X8_PROBES, Binding=hip)
+    R.Set_Option(B.OPT_GBUFFER, 1)
+    for _ in range(2):
+        R.Render()
+    return R
+
+
+def test_full_size_sampled_tiles_against_oracle(full_size, orc):
+    """1920x1080, DDGI 8x8x8: the oracle runs both DDGI passes in full for the same two frames
+    and then only every 499th 8x8 tile of the screen (65 tiles); those pixels, the whole
+    irradiance atlas and the whole radiance atlas must match."""
+    Rg = full_size
+    Ro = examples.global_illumination(1920, 1080, Probes=examples.GI_8X8X8_PROBES, Binding=orc)
+    Ro.Set_Option(B.OPT_GBUFFER, 1)
+    for _ in range(2):
+        Ro.Render_Pass(B.PASS_RADIANCE)
+        Ro.Render_Pass(B.PASS_IRRADIANCE)
+    assert same_bits(Rg.Read_Texture(B.TEX_IRRADIANCE), Ro.Read_Texture(B.TEX_IRRADIANCE))
+    assert same_bits(Rg.Read_Texture(B.TEX_RADIANCE), Ro.Read_Texture(B.TEX_RADIANCE))
+    Ro.Set_Option(B.OPT_WORLD, 499)
+    Ro.Set_Option(B.OPT_RANK, 7)
+    Ro.Render_Pass(B.PASS_SCREEN)
+    img_o, img_g = Ro.Read_Framebuffer(), Rg.Read_Framebuffer()
+    ty, tx = np.meshgrid(np.arange(1080) // 8, np.arange(1920) // 8, indexing="ij")
+    mine = (ty * 240 + tx) % 499 == 7
+    assert mine.sum() == 65 * 64
+    ok = np.isclose(img_g[mine], img_o[mine], rtol=1e-4, atol=1e-5, equal_nan=True)
+    assert ok.all()
+    assert (img_g[mine].view(np.uint32) == img_o[mine].view(np.uint32)).mean() > 0.999
+    for a, b in zip(Rg.Read_Gbuffer(), Ro.Read_Gbuffer()):
+        assert same_bits(a[mine], b[mine])
+
+
+def test_full_size_properties(full_size, hip):
+    """Size-independent properties on the whole 1080p frame: rendering is deterministic; the
+    image does not depend on how tiles are dealt to ranks; every pixel of a closed room hits;
+    the tonemapped image is in [0, 1]."""
+    Rg = full_size
+    img = Rg.Read_Framebuffer()
+    idx, t, steps = Rg.Read_Gbuffer()
+    assert (idx >= 0).all() and (steps >= 1).all()
+    finite = np.isfinite(img)
+    assert finite.mean() > 0.9999
+    assert (img[finite] >= 0).all() and (img[finite] <= 1).all()
+    # determinism + tile dealing: 3 'ranks' render their tiles of the same frame from the same atlases
+    Rg.Render_Pass(B.PASS_SCREEN)
+    assert same_bits(Rg.Read_Framebuffer(), img)
+    acc = np.zeros_like(img)
+    for r in range(3):
+        Rg.Set_Option(B.OPT_WORLD, 3)
+        Rg.Set_Option(B.OPT_RANK, r)
+        Rg.Render_Pass(B.PASS_SCREEN)
+        acc += Rg.Read_Framebuffer()
+    Rg.Set_Option(B.OPT_WORLD, 1)
+    Rg.Set_Option(B.OPT_RANK, 0)
+    assert same_bits(acc, img)

@@ -1,0 +1,81 @@
+"""Host-side behaviour of the Renderers mirror, driven against the oracle binding (CPU) and
+-- marked gpu -- against the HIP library: same calls, same errors as the reference."""
+import numpy as np
+import pytest
+
+from madarch_amd import _binding as B
+from madarch_amd import examples, materials, renderers, scenes, windows
+from madarch_amd.lights import point_lights
+from madarch_amd.primitives import planes, spheres
+
+
+def _api_checks(binding):
+    # Setup_Probe_Layout raises Program_Error when Probe_Count /= grid (renderers.adb:63-65)
+    scene = scenes.Compile([(spheres.Sphere, 4)], [(point_lights.Point_Light, 2)],
+                           Partitioning=scenes.Partitioning_Settings(Enable=False))
+    with pytest.raises(B.MadarchError) as e:
+        renderers.Create(windows.Open(8, 8), scene, Probes=renderers.Probe_Settings(Probe_Count=(5, 5)),
+                         Volumetrics=renderers.No_Volumetrics, Binding=binding)
+    assert e.value.status == B.MDH_E_PROBE_MISMATCH
+    R = renderers.Create(windows.Open(8, 8), scene, Volumetrics=renderers.No_Volumetrics, Binding=binding)
+    # Add_Material hands out consecutive ids from Last_Material_Index (renderers.adb:369-377)
+    assert R.Add_Material(materials.Create((1, 0, 0), 0.0, 0.5)) == 0
+    assert R.Add_Material(materials.Create((0, 1, 0), 0.0, 0.5)) == 1
+    R.Set_Material(5, materials.Create((0, 0, 1), 0.0, 0.5))
+    assert R.Add_Material(materials.Create((0, 0, 1), 0.0, 0.5)) == 6
+    # Add_Primitive returns the running count and writes it at the count offset
+    assert R.Add_Primitive(spheres.Sphere, spheres.Create((0, 0, 5), 1.0, 0)) == 1
+    assert R.Add_Primitive(spheres.Sphere, spheres.Create((2, 0, 5), 1.0, 1)) == 2
+    ubo = R.Read_Scene_Buffer()
+    assert int(np.frombuffer(ubo[0:4].tobytes(), dtype=np.int32)[0]) == 2
+    assert np.frombuffer(ubo[16 + 32:16 + 32 + 16].tobytes(), dtype=np.float32).tolist() == [2.0, 0.0, 5.0, 1.0]
+    # past the declared count: Constraint_Error
+    for i in range(2):
+        R.Add_Primitive(spheres.Sphere, spheres.Create((0, i, 9), 1.0, 0))
+    with pytest.raises(B.MadarchError) as e:
+        R.Add_Primitive(spheres.Sphere, spheres.Create((0, 0, 9), 1.0, 0))
+    assert e.value.status == B.MDH_E_INDEX
+    with pytest.raises(B.MadarchError):
+        R.Set_Primitive(spheres.Sphere, 9, spheres.Create((0, 0, 9), 1.0, 0))
+    # Set_Light sets the kind count and total_light_count to Index (renderers.adb:478-482)
+    R.Set_Light(2, point_lights.Point_Light, point_lights.Create((0, 3, 0), (1, 1, 1)))
+    size, total_off = R.Scene_Buffer_Size()
+    ubo = R.Read_Scene_Buffer()
+    assert int(np.frombuffer(ubo[total_off:total_off + 4].tobytes(), dtype=np.int32)[0]) == 2
+    # a kind that is not built in is refused
+    bad = scenes.Compile([(type(spheres.Sphere)("Torus", spheres.Sphere.comps), 4)], [(point_lights.Point_Light, 2)],
+                         Partitioning=scenes.Partitioning_Settings(Enable=False))
+    with pytest.raises(B.MadarchError) as e:
+        renderers.Create(windows.Open(8, 8), bad, Volumetrics=renderers.No_Volumetrics, Binding=binding)
+    assert e.value.status == B.MDH_E_UNSUPPORTED_KIND
+    # Update_Partitioning is a no-op when partitioning is disabled (renderers.adb:763-765)
+    R.Update_Partitioning(renderers.CPU_Best)
+
+
+def test_api_behaviour_oracle(orc):
+    _api_checks(orc)
+
+
+@pytest.mark.gpu
+def test_api_behaviour_hip(hip):
+    _api_checks(hip)
+
+
+def test_missing_library_is_loud(monkeypatch):
+    monkeypatch.setattr(B, "HIP_LIBRARY", "/nonexistent/libmadarch_hip.so")
+    monkeypatch.setattr(B, "_hip", None)
+    with pytest.raises(ImportError):
+        B.hip_binding()
+
+
+def test_product_never_imports_the_oracle():
+    """No import, dlopen or path of the oracle anywhere in the product package."""
+    import os
+    import re
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "madarch_amd")
+    pat = re.compile(r"^\s*(from|import)\s+\S*oracle|libmadarch_oracle|[\"'/]oracle[\"'/]|#include\s+\".*orc_")
+    for dirpath, _, files in os.walk(root):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp")) or f == "Makefile":
+                for line in open(os.path.join(dirpath, f), errors="replace"):
+                    assert not pat.search(line), (f, line)

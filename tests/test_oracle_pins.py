@@ -1,0 +1,230 @@
+"""Pins of the CPU oracle.  The reference holds no numeric fixture for this path (SURVEY.md
+section 8c: parity unpinned), so the oracle is pinned here by
+  (i)  hand-computed known answers of the closed forms the reference's sources state,
+  (ii) an independent numpy float32 restatement of those forms (same operation order =>
+       bit-identical), and
+  (iii) the two interpretations of the expression trees agreeing: the tree evaluator
+       (Madarch.Exprs.Eval) against the closed forms (what To_GLSL emits).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from helpers import SEED, seeded_points
+from madarch_amd import examples
+
+f32 = np.float32
+
+
+def cf(a):
+    return np.ascontiguousarray(a, dtype=np.float32).ctypes.data_as(C.POINTER(C.c_float))
+
+
+def orc_sdf(orc, type_, a, b, c, p):
+    return orc.lib.orc_sdf(type_, cf(a), cf(b), cf(c), cf(p))
+
+
+def orc_normal(orc, type_, a, b, c, p):
+    out = np.zeros(3, dtype=np.float32)
+    orc.lib.orc_sdf_normal(type_, cf(a), cf(b), cf(c), cf(p), cf(out))
+    return out
+
+
+def orc_exprs(orc, type_, a, b, c, p, ada_div=1):
+    n = np.zeros(3, dtype=np.float32)
+    d = orc.lib.orc_exprs_sdf(type_, cf(a), cf(b), cf(c), cf(p), ada_div, cf(n))
+    return d, n
+
+
+Z3 = np.zeros(3, dtype=np.float32)
+
+# ---- numpy float32 restatement (every operation rounds to binary32, same order) ----------
+
+
+def np_dot(a, b):
+    return f32(f32(f32(a[0] * b[0]) + f32(a[1] * b[1])) + f32(a[2] * b[2]))
+
+
+def np_length(a):
+    return np.sqrt(np_dot(a, a), dtype=np.float32)
+
+
+def np_sphere(c, r, p):  # madarch-primitives-spheres.ads:13-14
+    return f32(np_length((c - p).astype(np.float32)) - f32(r))
+
+
+def np_plane(n, o, p):  # madarch-primitives-planes.ads:13-14
+    return f32(np_dot(n, p) + f32(o))
+
+
+def np_box(c, s, p):  # madarch-primitives-boxes.adb:7-15
+    q = (np.abs((c - p).astype(np.float32)) - s).astype(np.float32)
+    outside = np_length(np.maximum(q, f32(0)))
+    inside = min(max(q[0], max(q[1], q[2])), f32(0))
+    return f32(outside + f32(inside))
+
+
+def test_known_answers(orc):
+    one = np.array([1, 0, 0], dtype=np.float32)
+    assert orc_sdf(orc, 0, Z3, [1.0], Z3, [3, 4, 0]) == 4.0            # |(3,4,0)| - 1
+    assert orc_sdf(orc, 0, Z3, [1.0], Z3, [0, 0, 0]) == -1.0
+    assert orc_sdf(orc, 1, [0, 1, 0], [1.0], Z3, [5, 2, 7]) == 3.0     # y + 1
+    assert orc_sdf(orc, 2, Z3, [1, 1, 1], Z3, [2, 0, 0]) == 1.0        # outside a face
+    assert orc_sdf(orc, 2, Z3, [1, 1, 1], Z3, [0.5, 0, 0]) == -0.5     # inside
+    assert orc_sdf(orc, 2, Z3, [1, 1, 1], Z3, [4, 5, 1]) == 5.0        # edge: |(3,4,0)|
+    assert np.array_equal(orc_normal(orc, 0, Z3, [1.0], Z3, [0, 0, 2]), [0, 0, 1])
+    assert np.array_equal(orc_normal(orc, 1, [0, 1, 0], [1.0], Z3, [5, 2, 7]), [0, 1, 0])
+    assert np.array_equal(orc_normal(orc, 2, Z3, [1, 1, 1], Z3, [2, 0.1, 0.2]), one)
+    # box normal near an edge: both axes within 0.002 of the largest (boxes.adb:5,23-26)
+    n = orc_normal(orc, 2, Z3, [1, 1, 1], Z3, [1.0, 0.999, 0.0])
+    assert np.allclose(n, [2 ** -0.5, 2 ** -0.5, 0], atol=1e-7)
+    # triangle in the z = 0 plane: distance of a point above its interior is its height
+    tri = ([0, 0, 0], [1, 0, 0], [0, 1, 0])
+    assert abs(orc_sdf(orc, 3, *tri, [0.25, 0.25, 2.0]) - 2.0) < 1e-6
+    assert abs(orc_sdf(orc, 3, *tri, [-3.0, 0.0, 4.0]) - 5.0) < 1e-6   # nearest is vertex v1
+
+
+def test_numpy_restatement_is_bit_identical(orc):
+    pts = seeded_points(256, -8.0, (8.0, 8.0, 8.0))
+    rng = np.random.RandomState(7)
+    for p in pts:
+        c = rng.uniform(-3, 3, 3).astype(np.float32)
+        s = rng.uniform(0.1, 2, 3).astype(np.float32)
+        r = f32(rng.uniform(0.1, 2))
+        n = rng.normal(size=3).astype(np.float32)
+        assert orc_sdf(orc, 0, c, [r], Z3, p) == np_sphere(c, r, p)
+        assert orc_sdf(orc, 1, n, [r], Z3, p) == np_plane(n, r, p)
+        assert orc_sdf(orc, 2, c, s, Z3, p) == np_box(c, s, p)
+
+
+def test_tree_evaluator_agrees_with_closed_forms(orc):
+    """Exprs.Eval (madarch-exprs.adb:322-716) == the closed forms, bit for bit, on
+    Sphere / Plane / Box, distance and normal."""
+    pts = seeded_points(192, -6.0, (6.0, 6.0, 6.0), seed=SEED + 1)
+    rng = np.random.RandomState(11)
+    for p in pts:
+        c = rng.uniform(-3, 3, 3).astype(np.float32)
+        s = rng.uniform(0.2, 2, 3).astype(np.float32)
+        r = f32(rng.uniform(0.2, 2))
+        for type_, a, b in ((0, c, [r]), (1, s, [r]), (2, c, s)):
+            d, n = orc_exprs(orc, type_, a, b, Z3, p)
+            assert d == orc_sdf(orc, type_, a, b, Z3, p)
+            assert np.array_equal(n, orc_normal(orc, type_, a, b, Z3, p), equal_nan=True)
+
+
+def test_values_division_bug_is_reproduced(orc):
+    """Madarch.Values."/" on two floats returns L + R (madarch-values.adb:112): the Ada
+    evaluator's Triangle distance differs from the GLSL one; with a true division the tree
+    evaluator and the closed form agree."""
+    tri = ([0, 0, 0], [2, 0, 0], [0, 2, 0])
+    p = [1.0, -1.0, 0.5]  # projects onto the middle of edge v1-v2: the quotient matters
+    glsl = orc_sdf(orc, 3, *tri, p)
+    d_true, _ = orc_exprs(orc, 3, *tri, p, ada_div=0)
+    d_ada, _ = orc_exprs(orc, 3, *tri, p, ada_div=1)
+    assert d_true == glsl
+    assert d_ada != glsl
+
+
+def test_octahedral_map_round_trip(orc):
+    rng = np.random.RandomState(3)
+    v = rng.normal(size=(512, 3)).astype(np.float32)
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    for d in v:
+        e = np.zeros(2, dtype=np.float32)
+        orc.lib.orc_oct_encode(cf(d), cf(e))
+        assert 0.0 <= e[0] <= 1.0 and 0.0 <= e[1] <= 1.0
+        back = np.zeros(3, dtype=np.float32)
+        orc.lib.orc_oct_decode(cf(e), cf(back))
+        assert np.allclose(back, d, atol=2e-6)
+    # the pole and a lower-hemisphere direction (probe_utils.glsl:64-78)
+    e = np.zeros(2, dtype=np.float32)
+    orc.lib.orc_oct_encode(cf([0, 0, 1]), cf(e))
+    assert np.array_equal(e, [0.5, 0.5])
+
+
+def test_cook_torrance_against_float64(orc):
+    """glsl/cook_torrance_brdf.glsl:1-52 restated in float64 numpy."""
+    rng = np.random.RandomState(5)
+    PI = 3.14159265358
+    for _ in range(128):
+        N = rng.normal(size=3); N /= np.linalg.norm(N)
+        V = rng.normal(size=3); V /= np.linalg.norm(V)
+        L = rng.normal(size=3); L /= np.linalg.norm(L)
+        if N @ V < 0.05 or N @ L < 0.05:
+            continue
+        albedo = rng.uniform(0, 1, 3); metallic = rng.uniform(0, 1); rough = rng.uniform(0.05, 1)
+        H = (V + L) / np.linalg.norm(V + L)
+        NdotV, NdotL = max(N @ V, 0), max(N @ L, 0)
+        F0 = 0.04 * (1 - metallic) + albedo * metallic
+        a2 = rough ** 4
+        NDF = a2 / (PI * (max(N @ H, 0) ** 2 * (a2 - 1) + 1) ** 2)
+        k = (rough + 1) ** 2 / 8
+        G = (NdotV / (NdotV * (1 - k) + k)) * (NdotL / (NdotL * (1 - k) + k))
+        F = F0 + (1 - F0) * (1.001 - max(H @ V, 0)) ** 5
+        kD = (1 - F) * (1 - metallic)
+        kS = np.minimum(NDF * G * F / max(4 * NdotV * NdotL, 0.001), 1.0)
+        okD, okS = np.zeros(3, np.float32), np.zeros(3, np.float32)
+        orc.lib.orc_cook_torrance(cf(N), cf(V), cf(L), cf(albedo), C.c_float(metallic), C.c_float(rough), cf(okD), cf(okS))
+        assert np.allclose(okD, kD, rtol=2e-5, atol=1e-6)
+        assert np.allclose(okS, kS, rtol=2e-5, atol=1e-6)
+
+
+def test_lights_known_answers(orc):
+    # point light: color / (dist^2 * 0.03)  (madarch-lights-point_lights.ads:20-22)
+    R = examples.simple_scene(8, 8, Binding=orc, Partitioning_Method=None)
+    rad, d, dist = np.zeros(3, np.float32), np.zeros(3, np.float32), C.c_float()
+    orc.lib.orc_probe_light(R._h, 0, cf([0, 0, 0]), cf(rad), cf(d), C.byref(dist))
+    assert dist.value == 3.0 and np.array_equal(d, [0, 1, 0])
+    assert np.allclose(rad, 0.9 / (9 * 0.03), rtol=1e-6)
+    # spot light on its axis: min(1/(d^2 0.03), 1.5) * color (madarch-lights-spot_lights.adb:5-24)
+    R = examples.global_illumination(8, 8, Binding=orc)
+    orc.lib.orc_probe_light(R._h, 0, cf([5.5, 5.0, 2.0]), cf(rad), cf(d), C.byref(dist))
+    assert dist.value == 2.0 and np.array_equal(d, [-1, 0, 0])
+    assert np.allclose(rad, np.array([0.9, 0.9, 0.8]) * 1.5, rtol=1e-6)
+    # outside the cone (angle >= aperture): no light
+    orc.lib.orc_probe_light(R._h, 0, cf([3.5, 0.0, 2.0]), cf(rad), cf(d), C.byref(dist))
+    assert np.array_equal(rad, [0, 0, 0])
+
+
+def test_raycast_known_answers(orc):
+    """The camera's centre ray of the global_illumination scene runs down +z from (2,2,0)
+    to the wall z = 7 (plane 6 of 6 => flat index 20 + 5, madarch-scenes.adb:656-666)."""
+    R = examples.global_illumination(8, 8, Binding=orc)
+    org = np.array([[2, 2, 0]], np.float32); d = np.array([[0, 0, 1]], np.float32)
+    hit, idx, steps = np.zeros(1, np.int32), np.zeros(1, np.int32), np.zeros(1, np.int32)
+    t = np.zeros(1, np.float32)
+    orc.lib.orc_probe_raycast(R._h, 1, cf(org), cf(d), hit.ctypes.data_as(C.c_void_p), idx.ctypes.data_as(C.c_void_p),
+                              cf(t), steps.ctypes.data_as(C.c_void_p))
+    assert hit[0] == 1 and idx[0] == 25
+    assert 7.0 - 1e-3 - 1e-5 <= t[0] <= 7.0  # stops within epsilon of the surface (raymarching.glsl:29)
+    # a ray that leaves through nothing: straight up from above the ceiling plane
+    org[0] = [2, 8, 0]; d[0] = [0, 1, 0]
+    orc.lib.orc_probe_raycast(R._h, 1, cf(org), cf(d), hit.ctypes.data_as(C.c_void_p), idx.ctypes.data_as(C.c_void_p),
+                              cf(t), steps.ctypes.data_as(C.c_void_p))
+    assert hit[0] == 1  # starts behind the ceiling plane: negative distance is an immediate hit
+
+
+def test_partitioning_lookup_agrees_with_full_scan(orc):
+    """simple_scene: the grid lookup (scenes.adb:839-1118) returns the full-scan distance at
+    points near surfaces, for the three table builders."""
+    from madarch_amd import renderers
+    pts = seeded_points(400, -0.9, (6.9, 6.9, 6.9), seed=SEED + 2)
+    pts[:, 2] = pts[:, 2] * 1.8 - 5.5
+    n = len(pts)
+    for method in (renderers.CPU_Best, renderers.CPU_Fast, renderers.GPU_Fast):
+        R = examples.simple_scene(8, 8, Binding=orc, Partitioning_Method=method)
+        # CPU_Best (what examples/simple_scene uses) fits Index_Count = 20; the two fast builders
+        # overflow a few cells (the reference only prints a warning there, renderers.adb:593-598)
+        assert R.Partition_Warnings() == (0 if method == renderers.CPU_Best else 5)
+        table = R.Read_Partitioning()
+        cell = np.floor(pts - np.array([-1.5, -1.5, -10.0], np.float32)).astype(int)
+        full_cell = table[cell[:, 0] * 200 + cell[:, 1] * 20 + cell[:, 2], :3].sum(axis=1) >= 20
+        d_full, i_full = np.zeros(n, np.float32), np.zeros(n, np.int32)
+        d_part, i_part = np.zeros(n, np.float32), np.zeros(n, np.int32)
+        orc.lib.orc_probe_closest(R._h, n, cf(pts), 0, cf(d_full), i_full.ctypes.data_as(C.c_void_p))
+        orc.lib.orc_probe_closest(R._h, n, cf(pts), 1, cf(d_part), i_part.ctypes.data_as(C.c_void_p))
+        near = (d_full < 0.4) & ~full_cell  # the table keeps everything within a cell diagonal of the closest
+        assert near.sum() > 50
+        assert np.array_equal(d_full[near], d_part[near])
+        assert np.array_equal(i_full[near], i_part[near])
