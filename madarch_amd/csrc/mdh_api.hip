@@ -598,8 +598,10 @@ static int run_pass(mdh_renderer *r, int pass)
       break;
    }
    case MDH_PASS_IRRADIANCE: {
-      long n = (long)(pr.probe_end - pr.probe_begin) * pr.ires * pr.ires;
-      if (n > 0) hipLaunchKernelGGL(k_irradiance, dim3((int)((n + 63) / 64)), dim3(64), 0, r->stream, pr);
+      int n = pr.probe_end - pr.probe_begin; // one workgroup per probe, its taps staged in LDS
+      size_t lds = (size_t)2 * pr.rres * pr.rres * sizeof(float4);
+      if (lds > 64 * 1024) return seterr(MDH_E_INVALID, "radiance resolution too large for the irradiance pass (LDS)");
+      if (n > 0) hipLaunchKernelGGL(k_irradiance, dim3(n), dim3(MDH_IRR_BLOCK), lds, r->stream, pr);
       break;
    }
    case MDH_PASS_VISIBILITY: {

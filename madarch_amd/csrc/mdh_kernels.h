@@ -5,8 +5,12 @@
 #pragma once
 
 #include "mdh_device.h"
+#include "mdh_march.h"
 
 #define MDH_BLOCK 256 // 4 wavefronts; every wavefront owns one 8x8 tile
+#ifndef MDH_WAVES_PER_SIMD
+#define MDH_WAVES_PER_SIMD 4 // register budget of the march kernels: 512 / 4 = 128 VGPRs
+#endif
 
 // ------------------------------------------------------------------------ screen pass
 struct ScreenArgs {
@@ -20,27 +24,31 @@ struct ScreenArgs {
    int *gb_steps;
 };
 
-// draw_screen.glsl:20-30.  One wavefront per 8x8 pixel tile: lane = (y & 7) * 8 + (x & 7).
+// draw_screen.glsl:20-30.  One wavefront per 8x8 pixel tile: lane = (y & 7) * 8 + (x & 7);
+// the tile's 64 pixels run through the ray state machine of mdh_march.h together.
 template <bool PART, int MODE, bool GBUF>
-__global__ __launch_bounds__(MDH_BLOCK) void k_screen(KScene sc, KProbes pr, KVolumetrics vol, KCamera cam, ScreenArgs a)
+__global__ __launch_bounds__(MDH_BLOCK, MDH_WAVES_PER_SIMD) void k_screen(KScene sc, KProbes pr, KVolumetrics vol, KCamera cam, ScreenArgs a)
 {
    stage_table(sc);
    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
    const int own = blockIdx.x * (MDH_BLOCK / 64) + wave;
    const int tile = a.rank + own * a.world;
-   if (tile >= a.n_tiles) return;
+   if (tile >= a.n_tiles) return; // wave-uniform
    const int i = (tile % a.tiles_x) * 8 + (lane & 7), j = (tile / a.tiles_x) * 8 + (lane >> 3);
-   if (i >= a.W || j >= a.H) return;
+   const bool valid = i < a.W && j < a.H;
    const float u = centre(i, a.W), v = -centre(j, a.H); // row 0 = top
    f3 origin, dir;
    camera_ray(cam, u, v, origin, dir);
-   PassCfg cfg; // renderers.adb:136-143
+   MachineCfg cfg; // renderers.adb:136-143
    cfg.direct_specular = true;
    cfg.indirect_specular = true;
    cfg.ao_steps = a.ao_steps;
-   cfg.volumetrics = vol.enabled != 0;
    PrimaryHit ph;
-   f3 c = pixel_color_probes<PART, MODE>(sc, pr, vol, cfg, origin, dir, F2(u, v), ph);
+   bool hit;
+   f3 pos;
+   f3 c = shade_machine<PART, MODE>(sc, pr, cfg, valid, origin, dir, ph, hit, pos);
+   if (!valid) return;
+   if (MODE == 0 && vol.enabled) c = render_volumetrics(sc, vol, c, origin, pos, hit, F2(u, v));
    if (MODE != 1) // draw_screen.glsl:29
       c = F3(pow_(c.x / (c.x + 1.0f), 0.4545f), pow_(c.y / (c.y + 1.0f), 0.4545f), pow_(c.z / (c.z + 1.0f), 0.4545f));
    const size_t px = (size_t)j * a.W + i;
@@ -55,13 +63,14 @@ __global__ __launch_bounds__(MDH_BLOCK) void k_screen(KScene sc, KProbes pr, KVo
 // ---------------------------------------------------------------------- radiance pass
 // compute_probe_radiance.glsl:16-27.  One wavefront per 8x8 texel tile of one probe's
 // octahedral map; all 64 rays of a wave leave the same probe position.
-template <bool PART> __global__ __launch_bounds__(MDH_BLOCK) void k_radiance(KScene sc, KProbes pr)
+template <bool PART> __global__ __launch_bounds__(MDH_BLOCK, MDH_WAVES_PER_SIMD) void k_radiance(KScene sc, KProbes pr)
 {
    stage_table(sc);
    const int per_probe = pr.rres * pr.rres;
    const long lin = (long)blockIdx.x * MDH_BLOCK + threadIdx.x;
-   const int probe = pr.probe_begin + (int)(lin / per_probe);
-   if (probe >= pr.probe_end) return;
+   const int probe_raw = pr.probe_begin + (int)(lin / per_probe);
+   const bool valid = probe_raw < pr.probe_end;
+   const int probe = valid ? probe_raw : pr.probe_begin;
    const int rem = (int)(lin % per_probe);
    int x, y;
    if ((pr.rres & 7) == 0) {
@@ -79,50 +88,64 @@ template <bool PART> __global__ __launch_bounds__(MDH_BLOCK) void k_radiance(KSc
    const int probe_id = (int)(nc.y * (float)pr.pcy) * pr.pcx + (int)(nc.x * (float)pr.pcx);
    const f3 world = grid_to_world(pr, probe_id_to_grid(pr, probe_id));
    const f3 ray_dir = ray_id_to_ray_dir(F2(fract_(nc.x * (float)pr.pcx), fract_(nc.y * (float)pr.pcy)));
-   PassCfg cfg; // renderers.adb:115-117: no specular; AO and volumetrics macros undefined
+   MachineCfg cfg; // renderers.adb:115-117: no specular; AO and volumetrics macros undefined
    cfg.direct_specular = false;
    cfg.indirect_specular = false;
    cfg.ao_steps = 0;
-   cfg.volumetrics = false;
-   KVolumetrics novol = {};
    PrimaryHit ph;
-   f3 c = pixel_color_probes<PART, 0>(sc, pr, novol, cfg, world, ray_dir, nc, ph);
-   atlas_store(pr.rad, pr.fmt, atlas_index(pr.pcx, pr.rres, i, j), c);
+   bool hit;
+   f3 pos;
+   f3 c = shade_machine<PART, 0>(sc, pr, cfg, valid, world, ray_dir, ph, hit, pos);
+   if (valid) atlas_store(pr.rad, pr.fmt, atlas_index(pr.pcx, pr.rres, i, j), c);
 }
 
 // -------------------------------------------------------------------- irradiance pass
 // update_probe_irradiance.glsl:8-43: every irradiance texel sums its probe's rres x rres
-// radiance taps (bilinear, at texel corners, so the first row/column bleed in from the
+// radiance taps (bilinear, at texel CORNERS, so the first row/column bleed in from the
 // neighbouring tiles) in the reference's order.
-__global__ __launch_bounds__(64) void k_irradiance(KProbes pr)
+//
+// One workgroup per probe.  A tap's radiance and its ray direction depend on the probe and
+// the tap only, not on the output texel: the workgroup evaluates each of the rres^2 taps
+// once (bilinear fetch + octahedral decode, spread over all lanes) into LDS, then every
+// lane owns one output texel and folds the taps in the reference's y, x order with LDS
+// broadcast reads -- ~13 VALU per tap and lane instead of ~370.
+#define MDH_IRR_BLOCK 64
+__global__ __launch_bounds__(MDH_IRR_BLOCK) void k_irradiance(KProbes pr)
 {
-   const int per_probe = pr.ires * pr.ires;
-   const long lin = (long)blockIdx.x * 64 + threadIdx.x;
-   const int probe = pr.probe_begin + (int)(lin / per_probe);
+   extern __shared__ float4 s_taps[]; // [2 * rres * rres]: {rad.xyz, -} {dir.xyz, -}
+   const int probe = pr.probe_begin + blockIdx.x;
    if (probe >= pr.probe_end) return;
-   const int rem = (int)(lin % per_probe);
-   const int y = rem / pr.ires, x = rem - y * pr.ires;
+   const int ntaps = pr.rres * pr.rres;
    const int ty = probe / pr.pcx, tx = probe - ty * pr.pcx;
-   const int i = tx * pr.ires + x, j = ty * pr.ires + y;
-   const f2 nc = F2((centre(i, pr.pcx * pr.ires) + 1.0f) * 0.5f, (centre(j, pr.pcy * pr.ires) + 1.0f) * 0.5f);
-   const f3 irr_dir = ray_id_to_ray_dir(F2(fract_(nc.x * (float)pr.pcx), fract_(nc.y * (float)pr.pcy)));
-   const int probe_id = (int)(nc.y * (float)pr.pcy) * pr.pcx + (int)(nc.x * (float)pr.pcx);
-   const f2 rad_coord = probe_id_to_coord(pr, probe_id);
    const float pcx = (float)pr.pcx, pcy = (float)pr.pcy;
    const f2 step = F2(1.0f / pcx / (float)pr.rres, 1.0f / pcy / (float)pr.rres);
-   f3 irradiance = F3(0.0f, 0.0f, 0.0f);
-   float total_weight = 0.0f;
-   for (int yy = 0; yy < pr.rres; ++yy)
-      for (int xx = 0; xx < pr.rres; ++xx) {
-         f2 c = F2(clamp_(rad_coord.x + (float)xx * step.x, step.x, 1.0f - step.x), clamp_(rad_coord.y + (float)yy * step.y, step.y, 1.0f - step.y));
-         f3 rad = atlas_sample(pr.rad, pr.fmt, pr.pcx, pr.pcy, pr.rres, c.x, c.y);
-         f3 rad_dir = ray_id_to_ray_dir(F2(fract_(c.x * pcx), fract_(c.y * pcy)));
-         float w = max_(dot(irr_dir, rad_dir), 0.0f);
-         irradiance = irradiance + rad * w;
+   // probe_id_to_coord of the probe the output texels belong to (probe_utils.glsl:52-56)
+   const f2 rad_coord = F2((float)tx / pcx, (float)ty / pcy);
+   for (int tap = threadIdx.x; tap < ntaps; tap += MDH_IRR_BLOCK) {
+      const int yy = tap / pr.rres, xx = tap - yy * pr.rres;
+      f2 c = F2(clamp_(rad_coord.x + (float)xx * step.x, step.x, 1.0f - step.x), clamp_(rad_coord.y + (float)yy * step.y, step.y, 1.0f - step.y));
+      f3 rad = atlas_sample(pr.rad, pr.fmt, pr.pcx, pr.pcy, pr.rres, c.x, c.y);
+      f3 rad_dir = ray_id_to_ray_dir(F2(fract_(c.x * pcx), fract_(c.y * pcy)));
+      s_taps[2 * tap] = make_float4(rad.x, rad.y, rad.z, 0.0f);
+      s_taps[2 * tap + 1] = make_float4(rad_dir.x, rad_dir.y, rad_dir.z, 0.0f);
+   }
+   __syncthreads();
+   for (int rem = threadIdx.x; rem < pr.ires * pr.ires; rem += MDH_IRR_BLOCK) {
+      const int y = rem / pr.ires, x = rem - y * pr.ires;
+      const int i = tx * pr.ires + x, j = ty * pr.ires + y;
+      const f2 nc = F2((centre(i, pr.pcx * pr.ires) + 1.0f) * 0.5f, (centre(j, pr.pcy * pr.ires) + 1.0f) * 0.5f);
+      const f3 irr_dir = ray_id_to_ray_dir(F2(fract_(nc.x * pcx), fract_(nc.y * pcy)));
+      f3 irradiance = F3(0.0f, 0.0f, 0.0f);
+      float total_weight = 0.0f;
+      for (int tap = 0; tap < ntaps; ++tap) {
+         const float4 r = s_taps[2 * tap], d = s_taps[2 * tap + 1];
+         float w = max_(dot(irr_dir, xyz(d)), 0.0f);
+         irradiance = irradiance + xyz(r) * w;
          total_weight += w;
       }
-   irradiance = irradiance / total_weight;
-   atlas_store(pr.irr, pr.fmt, atlas_index(pr.pcx, pr.ires, i, j), irradiance);
+      irradiance = irradiance / total_weight;
+      atlas_store(pr.irr, pr.fmt, atlas_index(pr.pcx, pr.ires, i, j), irradiance);
+   }
 }
 
 // -------------------------------------------------------------------- visibility pass
