@@ -200,23 +200,33 @@ static int commit_scene(mdh_renderer *r)
    s.max_dist = r->max_dist;
    std::vector<float4> &t = r->table_host;
    t.clear();
+   for (int ty = 0; ty < 4; ++ty) { s.tcount[ty] = 0; s.tslot[ty] = 0; }
+   // geometry: kind by kind, the elements below the runtime count
    for (int k = 0; k < r->npk; ++k) {
       const Kind &kd = r->pk[k];
       int n = rd_i(r, kd.count_off);
       if (n < 0) n = 0;
       if (n > kd.max_count) n = kd.max_count;
       s.ktype[k] = kd.type; s.kcount[k] = n; s.kbase[k] = r->prim_base[k]; s.kmax[k] = kd.max_count; s.kslot[k] = (int)t.size();
-      // every DECLARED element is packed: primitive_info gathers by flat index and the
-      // partition table may name any element below the count
-      for (int i = 0; i < kd.max_count; ++i) {
+      s.tcount[kd.type] = n; s.tslot[kd.type] = (int)t.size();
+      for (int i = 0; i < n; ++i) {
          int b = kd.array_off + kd.stride * i;
-         float mat = i_as_f(rd_i(r, b + kd.f_d));
          switch (kd.type) {
-         case PK_SPHERE: t.push_back(rd_v3w(r, b + kd.f_a, rd_f(r, b + kd.f_b))); t.push_back(mk4(0, 0, 0, mat)); break;
-         case PK_PLANE: t.push_back(rd_v3w(r, b + kd.f_a, rd_f(r, b + kd.f_b))); t.push_back(mk4(0, 0, 0, mat)); break;
-         case PK_BOX: t.push_back(rd_v3w(r, b + kd.f_a, 0.0f)); t.push_back(rd_v3w(r, b + kd.f_b, mat)); break;
-         default: t.push_back(rd_v3w(r, b + kd.f_a, mat)); t.push_back(rd_v3w(r, b + kd.f_b, 0.0f)); t.push_back(rd_v3w(r, b + kd.f_c, 0.0f)); break;
+         case PK_SPHERE: t.push_back(rd_v3w(r, b + kd.f_a, rd_f(r, b + kd.f_b))); break;
+         case PK_PLANE: t.push_back(rd_v3w(r, b + kd.f_a, rd_f(r, b + kd.f_b))); break;
+         case PK_BOX: t.push_back(rd_v3w(r, b + kd.f_a, 0.0f)); t.push_back(rd_v3w(r, b + kd.f_b, 0.0f)); break;
+         default: t.push_back(rd_v3w(r, b + kd.f_a, 0.0f)); t.push_back(rd_v3w(r, b + kd.f_b, 0.0f)); t.push_back(rd_v3w(r, b + kd.f_c, 0.0f)); break;
          }
+      }
+   }
+   // material ids (int32), 4 per float4
+   for (int k = 0; k < r->npk; ++k) {
+      const Kind &kd = r->pk[k];
+      s.kmat[k] = (int)t.size() * 4;
+      for (int i0 = 0; i0 < s.kcount[k]; i0 += 4) {
+         float m[4] = {0, 0, 0, 0};
+         for (int j = 0; j < 4 && i0 + j < s.kcount[k]; ++j) m[j] = i_as_f(rd_i(r, kd.array_off + kd.stride * (i0 + j) + kd.f_d));
+         t.push_back(mk4(m[0], m[1], m[2], m[3]));
       }
    }
    for (int k = 0; k < r->nlk; ++k) {
@@ -225,7 +235,7 @@ static int commit_scene(mdh_renderer *r)
       if (n < 0) n = 0;
       if (n > kd.max_count) n = kd.max_count;
       s.ltype[k] = kd.type; s.lcount[k] = n; s.lslot[k] = (int)t.size();
-      for (int i = 0; i < kd.max_count; ++i) {
+      for (int i = 0; i < n; ++i) {
          int b = kd.array_off + kd.stride * i;
          if (kd.type == LK_POINT) { t.push_back(rd_v3w(r, b + kd.f_a, 0.0f)); t.push_back(rd_v3w(r, b + kd.f_b, 0.0f)); }
          else { t.push_back(rd_v3w(r, b + kd.f_a, rd_f(r, b + kd.f_c))); t.push_back(rd_v3w(r, b + kd.f_b, 0.0f)); t.push_back(rd_v3w(r, b + kd.f_d, 0.0f)); }
@@ -239,6 +249,9 @@ static int commit_scene(mdh_renderer *r)
       t.push_back(mk4(f[0], f[1], f[2], f[3]));
       t.push_back(mk4(f[4], 0, 0, 0));
    }
+   // k / 255 for k = 0..255: the RGB8 texel decode, one correctly rounded division each
+   s.u8_slot = (int)t.size();
+   for (int k = 0; k < 256; k += 4) t.push_back(mk4((float)k / 255.0f, (float)(k + 1) / 255.0f, (float)(k + 2) / 255.0f, (float)(k + 3) / 255.0f));
    s.table_f4 = (int)t.size();
    if ((size_t)s.table_f4 * 16 > 64 * 1024) return seterr(MDH_E_INVALID, "scene tables exceed the 64 KiB LDS budget of a workgroup");
    if (t.size() > r->table_cap) {

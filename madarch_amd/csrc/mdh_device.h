@@ -20,6 +20,10 @@
 #include <stdint.h>
 
 #define MDH_DEV static __device__ __forceinline__
+// Triangle code is kept out of line: it is cold in every benchmark scene and register hungry
+#ifndef MDH_TRI
+#define MDH_TRI static __device__ __noinline__
+#endif
 
 #define MDH_MAX_KINDS 4
 #define MDH_MAX_LIGHT_KINDS 4
@@ -43,6 +47,11 @@ struct KScene {
    int total_lights; // total_light_count (scenes.adb:594)
    int mat_slot;     // first float4 of the materials (2 per material)
    int table_f4;     // float4 count of the whole table
+   // the same primitives by TYPE, for the order-free min of closest_primitive
+   int tcount[4];    // runtime count of Sphere / Plane / Box / Triangle
+   int tslot[4];     // = kslot of the kind of that type (0 when the type is absent)
+   int kmat[MDH_MAX_KINDS]; // first int of the kind's material ids (int index into the table)
+   int u8_slot;      // float4 index of the 256-entry k / 255 table
    float max_dist;
    // space partition (scenes.adb:799-1118)
    int part_enable, part_border, part_index_count, part_cells;
@@ -128,15 +137,16 @@ MDH_DEV float pow8_(float x) { float x2 = x * x; float x4 = x2 * x2; return x4 *
 MDH_DEV float pow1_5_(float x) { return x * __builtin_sqrtf(x); }                        // volumetrics.glsl:25-28
 
 // ---------------------------------------------------------------------- LDS scene table
-// One float4 array per workgroup: primitives (2 float4 each, 3 for a triangle), lights
-// (2 for a point light, 3 for a spot light), materials (2 each).
-//   Sphere   {center.xyz, radius}            {-, -, -, material}
-//   Plane    {normal.xyz, offset}            {-, -, -, material}
-//   Box      {center.xyz, -}                 {side.xyz, material}
-//   Triangle {v1.xyz, material} {v2.xyz, -}  {v3.xyz, -}
-//   PointLight {position.xyz, -} {color.xyz, -}
-//   SpotLight  {position.xyz, aperture} {direction.xyz, -} {color.xyz, -}
+// One float4 array per workgroup, staged from HBM by stage_table():
+//   geometry, kind by kind, only the elements below the runtime count:
+//     Sphere   {center.xyz, radius}                       1 float4
+//     Plane    {normal.xyz, offset}                       1 float4
+//     Box      {center.xyz, -} {side.xyz, -}              2 float4
+//     Triangle {v1.xyz, -} {v2.xyz, -} {v3.xyz, -}        3 float4
+//   material ids of the primitives (int32, same order)
+//   PointLight {position.xyz, -} {color.xyz, -}; SpotLight {position.xyz, aperture} {direction.xyz, -} {color.xyz, -}
 //   Material {albedo.xyz, metallic} {roughness, -, -, -}
+//   u8 -> float table: 256 entries k / 255 (RGB8 texel decode without a division)
 extern __shared__ float4 s_tab[];
 
 MDH_DEV void stage_table(const KScene &sc)
@@ -144,7 +154,9 @@ MDH_DEV void stage_table(const KScene &sc)
    for (int i = threadIdx.x; i < sc.table_f4; i += blockDim.x) s_tab[i] = sc.table[i];
    __syncthreads();
 }
-MDH_DEV int prim_slots(int type) { return type == PK_TRIANGLE ? 3 : 2; }
+MDH_DEV int prim_slots(int type) { return type == PK_TRIANGLE ? 3 : (type == PK_BOX ? 2 : 1); }
+MDH_DEV int tab_int(int int_index) { return ((const int *)s_tab)[int_index]; }
+MDH_DEV float tab_float(int float_index) { return ((const float *)s_tab)[float_index]; }
 
 // ---------------------------------------------------------------------------- the SDFs
 // madarch-primitives-spheres.ads:13-14
@@ -159,7 +171,7 @@ MDH_DEV float sd_box(float4 a, float4 b, f3 p)
 }
 // madarch-primitives-triangles.adb:16-48; ADA_DIV reproduces Madarch.Values."/" (L + R)
 template <bool ADA_DIV> MDH_DEV float tdiv(float a, float b) { return ADA_DIV ? a + b : a / b; }
-template <bool ADA_DIV> MDH_DEV float sd_triangle(f3 a, f3 b, f3 c, f3 p)
+template <bool ADA_DIV> MDH_TRI float sd_triangle(f3 a, f3 b, f3 c, f3 p)
 {
    f3 v21 = b - a, v32 = c - b, v13 = a - c;
    f3 p1 = p - a, p2 = p - b, p3 = p - c;
@@ -188,7 +200,7 @@ MDH_DEV f3 nrm_box(float4 a, float4 b, f3 p)
    return normalize(n);
 }
 // madarch-primitives-triangles.adb:50-56 + madarch-exprs-derivatives.adb:12-45
-template <bool ADA_DIV> MDH_DEV f3 nrm_triangle(f3 a, f3 b, f3 c, f3 p)
+template <bool ADA_DIV> MDH_TRI f3 nrm_triangle(f3 a, f3 b, f3 c, f3 p)
 {
    const float eps = 0.000001f;
    float fp = sd_triangle<ADA_DIV>(a, b, c, p);
@@ -209,40 +221,43 @@ MDH_DEV float prim_dist(int type, int slot, f3 x)
    }
 }
 
-// closest_primitive (scenes.adb:602-629): kinds in scene order, wave-uniform loop
+// closest_primitive (scenes.adb:602-629).  min is order-free, so the primitives are
+// visited by TYPE: four plain loops, wave-uniform trip counts, LDS broadcast reads.
 MDH_DEV float closest_primitive(const KScene &sc, f3 x)
 {
    float closest = sc.max_dist;
-#pragma unroll
-   for (int k = 0; k < MDH_MAX_KINDS; ++k) {
-      if (k >= sc.nk) break;
-      const int n = sc.kcount[k], s0 = sc.kslot[k];
-      switch (sc.ktype[k]) {
-      case PK_SPHERE:
-         for (int i = 0; i < n; ++i) closest = min_(closest, sd_sphere(s_tab[s0 + 2 * i], x));
-         break;
-      case PK_PLANE:
-         for (int i = 0; i < n; ++i) closest = min_(closest, sd_plane(s_tab[s0 + 2 * i], x));
-         break;
-      case PK_BOX:
-         for (int i = 0; i < n; ++i) closest = min_(closest, sd_box(s_tab[s0 + 2 * i], s_tab[s0 + 2 * i + 1], x));
-         break;
-      default:
-         for (int i = 0; i < n; ++i)
-            closest = min_(closest, sd_triangle<false>(xyz(s_tab[s0 + 3 * i]), xyz(s_tab[s0 + 3 * i + 1]), xyz(s_tab[s0 + 3 * i + 2]), x));
-         break;
-      }
+   {
+      const int n = sc.tcount[PK_SPHERE], s0 = sc.tslot[PK_SPHERE];
+#pragma unroll 2
+      for (int i = 0; i < n; ++i) closest = min_(closest, sd_sphere(s_tab[s0 + i], x));
+   }
+   {
+      const int n = sc.tcount[PK_PLANE], s0 = sc.tslot[PK_PLANE];
+#pragma unroll 2
+      for (int i = 0; i < n; ++i) closest = min_(closest, sd_plane(s_tab[s0 + i], x));
+   }
+   {
+      const int n = sc.tcount[PK_BOX], s0 = sc.tslot[PK_BOX];
+#pragma unroll 2
+      for (int i = 0; i < n; ++i) closest = min_(closest, sd_box(s_tab[s0 + 2 * i], s_tab[s0 + 2 * i + 1], x));
+   }
+   {
+      const int n = sc.tcount[PK_TRIANGLE], s0 = sc.tslot[PK_TRIANGLE];
+#pragma unroll 1
+      for (int i = 0; i < n; ++i)
+         closest = min_(closest, sd_triangle<false>(xyz(s_tab[s0 + 3 * i]), xyz(s_tab[s0 + 3 * i + 1]), xyz(s_tab[s0 + 3 * i + 2]), x));
    }
    return closest;
 }
-// closest_primitive_info (scenes.adb:631-674)
+// closest_primitive_info (scenes.adb:631-674): kinds in SCENE order (the arg-min keeps the
+// first of equal distances).  Only evaluated at hit points, so compact rather than fast.
 MDH_DEV float closest_primitive_info(const KScene &sc, f3 x, int &index)
 {
    float closest = sc.max_dist;
-#pragma unroll
-   for (int k = 0; k < MDH_MAX_KINDS; ++k) {
-      if (k >= sc.nk) break;
+#pragma unroll 1
+   for (int k = 0; k < sc.nk; ++k) {
       const int n = sc.kcount[k], s0 = sc.kslot[k], base = sc.kbase[k], type = sc.ktype[k];
+#pragma unroll 1
       for (int i = 0; i < n; ++i) {
          float d = prim_dist(type, s0 + prim_slots(type) * i, x);
          if (d < closest) { closest = d; index = base + i; }
@@ -257,18 +272,18 @@ MDH_DEV void primitive_info(const KScene &sc, int index, f3 pos, f3 &normal, int
 {
    normal = F3(0.0f, 0.0f, 0.0f);
    material_id = 0;
-#pragma unroll
-   for (int k = 0; k < MDH_MAX_KINDS; ++k) {
-      if (k >= sc.nk) break;
+#pragma unroll 1
+   for (int k = 0; k < sc.nk; ++k) {
       if (index < sc.kmax[k]) {
          const int type = sc.ktype[k];
          const int slot = sc.kslot[k] + prim_slots(type) * index; // per-lane LDS gather
-         float4 a = s_tab[slot], b = s_tab[slot + 1];
+         material_id = tab_int(sc.kmat[k] + index);
+         float4 a = s_tab[slot];
          switch (type) {
-         case PK_SPHERE: normal = normalize(pos - xyz(a)); material_id = __float_as_int(b.w); break; // spheres.ads:16-17
-         case PK_PLANE: normal = xyz(a); material_id = __float_as_int(b.w); break;                   // planes.ads:16-17
-         case PK_BOX: normal = nrm_box(a, b, pos); material_id = __float_as_int(b.w); break;
-         default: normal = nrm_triangle<false>(xyz(a), xyz(b), xyz(s_tab[slot + 2]), pos); material_id = __float_as_int(a.w); break;
+         case PK_SPHERE: normal = normalize(pos - xyz(a)); break; // spheres.ads:16-17
+         case PK_PLANE: normal = xyz(a); break;                   // planes.ads:16-17
+         case PK_BOX: normal = nrm_box(a, s_tab[slot + 1], pos); break;
+         default: normal = nrm_triangle<false>(xyz(a), xyz(s_tab[slot + 1]), xyz(s_tab[slot + 2]), pos); break;
          }
          return;
       }
@@ -300,9 +315,8 @@ template <bool INFO> MDH_DEV float partitioning_lookup(const KScene &sc, f3 x, i
    if (cell < 0 || cell >= sc.part_cells) return closest;
    const int *rec = sc.part_table + (size_t)cell * (sc.nk + sc.part_index_count);
    int i = 0;
-#pragma unroll
-   for (int k = 0; k < MDH_MAX_KINDS; ++k) {
-      if (k >= sc.nk) break;
+#pragma unroll 1
+   for (int k = 0; k < sc.nk; ++k) {
       const int size = i + rec[k], type = sc.ktype[k], s0 = sc.kslot[k], base = sc.kbase[k];
       const int stop = min(size, sc.part_index_count);
       for (; i < stop; ++i) {
@@ -376,9 +390,8 @@ template <bool PART> MDH_DEV float raycast_visibility(const KScene &sc, f3 from,
 // sample_<Light> (scenes.adb:497-549) dispatched by cumulative RUNTIME counts (scenes.adb:731-764)
 MDH_DEV f3 sample_light(const KScene &sc, int index, f3 pos, f3 &dir, float &dist)
 {
-#pragma unroll
-   for (int k = 0; k < MDH_MAX_LIGHT_KINDS; ++k) {
-      if (k >= sc.nl) break;
+#pragma unroll 1
+   for (int k = 0; k < sc.nl; ++k) {
       const int n = sc.lcount[k];
       if (index < n) {
          if (sc.ltype[k] == LK_POINT) { // madarch-lights-point_lights.ads:20-22
@@ -554,10 +567,12 @@ MDH_DEV size_t atlas_index(int pcx, int res, int X, int Y)
    int tx = X / res, ty = Y / res;
    return ((size_t)(ty * pcx + tx) * res + (Y - ty * res)) * res + (X - tx * res);
 }
-MDH_DEV f3 atlas_texel(const void *base, int fmt, size_t idx)
+// u8_tab = float index of the k / 255 table in LDS (KScene::u8_slot * 4), or < 0: divide
+MDH_DEV f3 atlas_texel(const void *base, int fmt, size_t idx, int u8_tab)
 {
    if (fmt == 0) {
       uchar4 t = ((const uchar4 *)base)[idx];
+      if (u8_tab >= 0) return F3(tab_float(u8_tab + t.x), tab_float(u8_tab + t.y), tab_float(u8_tab + t.z));
       return F3((float)t.x / 255.0f, (float)t.y / 255.0f, (float)t.z / 255.0f);
    }
    float4 t = ((const float4 *)base)[idx];
@@ -576,7 +591,7 @@ MDH_DEV void atlas_store(void *base, int fmt, size_t idx, f3 v)
    }
 }
 // GL_LINEAR on the atlas image of pcx*res x pcy*res texels (render_passes.adb:113-114)
-MDH_DEV f3 atlas_sample(const void *base, int fmt, int pcx, int pcy, int res, float cx, float cy)
+MDH_DEV f3 atlas_sample(const void *base, int fmt, int pcx, int pcy, int res, float cx, float cy, int u8_tab)
 {
    const int W = pcx * res, H = pcy * res;
    float px = cx * (float)W - 0.5f, py = cy * (float)H - 0.5f;
@@ -584,8 +599,8 @@ MDH_DEV f3 atlas_sample(const void *base, int fmt, int pcx, int pcy, int res, fl
    float fx = px - fx0, fy = py - fy0;
    int x0 = mirror((int)fx0, W), x1 = mirror((int)fx0 + 1, W), y0 = mirror((int)fy0, H), y1 = mirror((int)fy0 + 1, H);
    float w00 = (1.0f - fx) * (1.0f - fy), w10 = fx * (1.0f - fy), w01 = (1.0f - fx) * fy, w11 = fx * fy;
-   f3 a = atlas_texel(base, fmt, atlas_index(pcx, res, x0, y0)), b = atlas_texel(base, fmt, atlas_index(pcx, res, x1, y0));
-   f3 c = atlas_texel(base, fmt, atlas_index(pcx, res, x0, y1)), d = atlas_texel(base, fmt, atlas_index(pcx, res, x1, y1));
+   f3 a = atlas_texel(base, fmt, atlas_index(pcx, res, x0, y0), u8_tab), b = atlas_texel(base, fmt, atlas_index(pcx, res, x1, y0), u8_tab);
+   f3 c = atlas_texel(base, fmt, atlas_index(pcx, res, x0, y1), u8_tab), d = atlas_texel(base, fmt, atlas_index(pcx, res, x1, y1), u8_tab);
    return ((a * w00 + b * w10) + c * w01) + d * w11;
 }
 
@@ -617,7 +632,7 @@ template <bool PART> MDH_DEV f3 sample_irradiance(const KScene &sc, const KProbe
       f3 tri = F3(mix_(1.0f - alpha.x, alpha.x, (float)ox), mix_(1.0f - alpha.y, alpha.y, (float)oy), mix_(1.0f - alpha.z, alpha.z, (float)oz));
       weight *= tri.x * tri.y * tri.z;
       f2 base = probe_id_to_coord(pr, grid_to_probe_id(pr, q));
-      f3 tx = atlas_sample(pr.irr, pr.fmt, pr.pcx, pr.pcy, pr.ires, base.x + rid.x / (float)pr.pcx, base.y + rid.y / (float)pr.pcy);
+      f3 tx = atlas_sample(pr.irr, pr.fmt, pr.pcx, pr.pcy, pr.ires, base.x + rid.x / (float)pr.pcx, base.y + rid.y / (float)pr.pcy, sc.u8_slot * 4);
       irradiance = irradiance + sqrt3(tx) * weight;
       total_weight += weight;
    }
@@ -656,7 +671,7 @@ template <bool PART> MDH_DEV f3 sample_radiance_no_specular(const KScene &sc, co
    f2 rid = ray_dir_to_ray_id(best_pts);
    rid = F2(clamp_(rid.x, rmin, rmax), clamp_(rid.y, rmin, rmax));
    // textureLod(.., 1.0) on a single-level texture samples level 0
-   f3 radiance = atlas_sample(pr.rad, pr.fmt, pr.pcx, pr.pcy, pr.rres, base.x + rid.x / (float)pr.pcx, base.y + rid.y / (float)pr.pcy);
+   f3 radiance = atlas_sample(pr.rad, pr.fmt, pr.pcx, pr.pcy, pr.rres, base.x + rid.x / (float)pr.pcx, base.y + rid.y / (float)pr.pcy, sc.u8_slot * 4);
    Material m = get_material(sc, spec_mat);
    return radiance + compute_direct_lighting<PART>(sc, spec_pos, spec_normal, dir, F3(0.0f, 0.0f, 0.0f), m.metallic, m.roughness, true);
 }

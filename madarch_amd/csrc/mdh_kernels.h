@@ -8,6 +8,10 @@
 #include "mdh_march.h"
 
 #define MDH_BLOCK 256 // 4 wavefronts; every wavefront owns one 8x8 tile
+// which formulation of the pixel program the screen / radiance kernels run (mdh_march.h)
+#ifndef MDH_SHADE
+#define MDH_SHADE shade_structured
+#endif
 #ifndef MDH_WAVES_PER_SIMD
 #define MDH_WAVES_PER_SIMD 4 // register budget of the march kernels: 512 / 4 = 128 VGPRs
 #endif
@@ -46,7 +50,7 @@ __global__ __launch_bounds__(MDH_BLOCK, MDH_WAVES_PER_SIMD) void k_screen(KScene
    PrimaryHit ph;
    bool hit;
    f3 pos;
-   f3 c = shade_machine<PART, MODE>(sc, pr, cfg, valid, origin, dir, ph, hit, pos);
+   f3 c = MDH_SHADE<PART, MODE>(sc, pr, cfg, valid, origin, dir, ph, hit, pos);
    if (!valid) return;
    if (MODE == 0 && vol.enabled) c = render_volumetrics(sc, vol, c, origin, pos, hit, F2(u, v));
    if (MODE != 1) // draw_screen.glsl:29
@@ -95,7 +99,7 @@ template <bool PART> __global__ __launch_bounds__(MDH_BLOCK, MDH_WAVES_PER_SIMD)
    PrimaryHit ph;
    bool hit;
    f3 pos;
-   f3 c = shade_machine<PART, 0>(sc, pr, cfg, valid, world, ray_dir, ph, hit, pos);
+   f3 c = MDH_SHADE<PART, 0>(sc, pr, cfg, valid, world, ray_dir, ph, hit, pos);
    if (valid) atlas_store(pr.rad, pr.fmt, atlas_index(pr.pcx, pr.rres, i, j), c);
 }
 
@@ -124,7 +128,7 @@ __global__ __launch_bounds__(MDH_IRR_BLOCK) void k_irradiance(KProbes pr)
    for (int tap = threadIdx.x; tap < ntaps; tap += MDH_IRR_BLOCK) {
       const int yy = tap / pr.rres, xx = tap - yy * pr.rres;
       f2 c = F2(clamp_(rad_coord.x + (float)xx * step.x, step.x, 1.0f - step.x), clamp_(rad_coord.y + (float)yy * step.y, step.y, 1.0f - step.y));
-      f3 rad = atlas_sample(pr.rad, pr.fmt, pr.pcx, pr.pcy, pr.rres, c.x, c.y);
+      f3 rad = atlas_sample(pr.rad, pr.fmt, pr.pcx, pr.pcy, pr.rres, c.x, c.y, -1);
       f3 rad_dir = ray_id_to_ray_dir(F2(fract_(c.x * pcx), fract_(c.y * pcy)));
       s_taps[2 * tap] = make_float4(rad.x, rad.y, rad.z, 0.0f);
       s_taps[2 * tap + 1] = make_float4(rad_dir.x, rad_dir.y, rad_dir.z, 0.0f);
@@ -342,12 +346,12 @@ template <bool ADA_DIV> __global__ __launch_bounds__(64) void k_eval_distance(KS
          if (d < closest) {
             closest = d;
             const int slot = sc.kslot[k] + prim_slots(type) * i;
-            float4 A = s_tab[slot], B = s_tab[slot + 1];
+            float4 A = s_tab[slot];
             switch (type) {
             case PK_SPHERE: normal = normalize(p - xyz(A)); break;
             case PK_PLANE: normal = xyz(A); break;
-            case PK_BOX: normal = nrm_box(A, B, p); break;
-            default: normal = nrm_triangle<ADA_DIV>(xyz(A), xyz(B), xyz(s_tab[slot + 2]), p); break;
+            case PK_BOX: normal = nrm_box(A, s_tab[slot + 1], p); break;
+            default: normal = nrm_triangle<ADA_DIV>(xyz(A), xyz(s_tab[slot + 1]), xyz(s_tab[slot + 2]), p); break;
             }
          }
       }
