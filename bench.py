@@ -56,12 +56,25 @@ def algorithmic_bytes_screen(R):
     return px * per_px + (px / 256.0) * tables, per_px, tables
 
 
+def host_cpu_share():
+    """Threads this process may really use: the scheduler affinity, cut by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(workload):
     """The CPU oracle (a C restatement of the reference's path -- the Ada/GLSL reference
     cannot be built here) on the host cores: one warm-up frame, one timed frame."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle_engine import ORC_OPT_THREADS, oracle_binding
     R = make_renderer(workload, oracle_binding())
+    R.Set_Option(ORC_OPT_THREADS, host_cpu_share())
     cores = R.Get_Option(ORC_OPT_THREADS)
     R.Render()
     t = time.perf_counter()

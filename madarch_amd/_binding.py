@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-HIP_LIBRARY = os.path.join(_HERE, "csrc", "libmadarch_hip.so")
+# MADARCH_HIP_LIBRARY selects another build of the same library (kernel A/B runs)
+HIP_LIBRARY = os.environ.get("MADARCH_HIP_LIBRARY") or os.path.join(_HERE, "csrc", "libmadarch_hip.so")
 
 # status codes (include/madarch_hip.h)
 MDH_OK, MDH_E_INVALID, MDH_E_PROBE_MISMATCH, MDH_E_UNSUPPORTED_KIND = 0, 1, 2, 3

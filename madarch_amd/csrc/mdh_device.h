@@ -100,8 +100,42 @@ MDH_DEV f3 F3s(float s) { return F3(s, s, s); }
 MDH_DEV f2 F2(float x, float y) { f2 r; r.x = x; r.y = y; return r; }
 MDH_DEV f3 xyz(float4 v) { return F3(v.x, v.y, v.z); }
 
+// min/max = IEEE minNum/maxNum.  __builtin_fminf costs a canonicalising v_max_f32 per operand in
+// IEEE mode; issuing the instruction directly (MDH_ASM_MINMAX=1) removes it but measured 3 % SLOWER
+// on MI355X (the opaque asm defeats the scheduler), so the builtin stays the default.
+#ifndef MDH_ASM_MINMAX
+#define MDH_ASM_MINMAX 0
+#endif
+#if MDH_ASM_MINMAX
+MDH_DEV float min_(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+MDH_DEV float max_(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+#else
 MDH_DEV float min_(float a, float b) { return __builtin_fminf(a, b); } // v_min_f32: minNum
 MDH_DEV float max_(float a, float b) { return __builtin_fmaxf(a, b); }
+#endif
+
+// Correctly rounded sqrt.  hipcc's expansion (v_sqrt_f32 + two fma residual tests) also rescales
+// inputs below 2^-96 and re-selects 0/inf with a class test on every call; MDH_FAST_EXACT_SQRT=1
+// sends those inputs down a rare branch and keeps the 9-instruction core (same result for every
+// input).  Measured 5 % SLOWER on MI355X than the compiler's branch-free form: off by default.
+#ifndef MDH_FAST_EXACT_SQRT
+#define MDH_FAST_EXACT_SQRT 0
+#endif
+MDH_DEV float sqrt_(float x)
+{
+#if MDH_FAST_EXACT_SQRT
+   if (__builtin_expect(x < 0x1p-96f && x > 0.0f, 0)) return __builtin_sqrtf(x);
+   float s = __builtin_amdgcn_sqrtf(x);
+   const int si = __float_as_int(s);
+   const float sd = __int_as_float(si - 1), su = __int_as_float(si + 1);
+   const float vp = __builtin_fmaf(-sd, s, x), vs = __builtin_fmaf(-su, s, x);
+   s = (vp <= 0.0f) ? sd : s;
+   s = (vs > 0.0f) ? su : s;
+   return s;
+#else
+   return __builtin_sqrtf(x);
+#endif
+}
 MDH_DEV float clamp_(float x, float lo, float hi) { return min_(max_(x, lo), hi); }
 MDH_DEV int iclamp_(int x, int lo, int hi) { return min(max(x, lo), hi); }
 MDH_DEV float sign_(float x) { return x < 0.0f ? -1.0f : (x > 0.0f ? 1.0f : 0.0f); }
@@ -119,11 +153,11 @@ MDH_DEV f3 abs3(f3 a) { return F3(__builtin_fabsf(a.x), __builtin_fabsf(a.y), __
 MDH_DEV f3 max3s(f3 a, float s) { return F3(max_(a.x, s), max_(a.y, s), max_(a.z, s)); }
 MDH_DEV f3 min3s(f3 a, float s) { return F3(min_(a.x, s), min_(a.y, s), min_(a.z, s)); }
 MDH_DEV f3 floor3(f3 a) { return F3(__builtin_floorf(a.x), __builtin_floorf(a.y), __builtin_floorf(a.z)); }
-MDH_DEV f3 sqrt3(f3 a) { return F3(__builtin_sqrtf(a.x), __builtin_sqrtf(a.y), __builtin_sqrtf(a.z)); }
+MDH_DEV f3 sqrt3(f3 a) { return F3(sqrt_(a.x), sqrt_(a.y), sqrt_(a.z)); }
 // dot = (x*x' + y*y') + z*z'
 MDH_DEV float dot(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 MDH_DEV float dot2(f3 a) { return dot(a, a); } // maths.glsl:5-7
-MDH_DEV float length(f3 a) { return __builtin_sqrtf(dot2(a)); }
+MDH_DEV float length(f3 a) { return sqrt_(dot2(a)); }
 MDH_DEV f3 normalize(f3 a) { return a / length(a); } // support/math_utils.ads:81-83
 MDH_DEV f3 cross(f3 a, f3 b) { return F3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
 MDH_DEV f3 reflect(f3 i, f3 n) { return i - n * (2.0f * dot(n, i)); }
@@ -134,7 +168,7 @@ MDH_DEV float acos_(float x) { return (float)acos((double)x); }
 MDH_DEV float pow_(float x, float y) { return (float)pow((double)x, (double)y); }
 MDH_DEV float pow5_(float x) { float x2 = x * x; return (x2 * x2) * x; }                 // cook_torrance_brdf.glsl:2
 MDH_DEV float pow8_(float x) { float x2 = x * x; float x4 = x2 * x2; return x4 * x4; } // spot_lights.adb:18
-MDH_DEV float pow1_5_(float x) { return x * __builtin_sqrtf(x); }                        // volumetrics.glsl:25-28
+MDH_DEV float pow1_5_(float x) { return x * sqrt_(x); }                        // volumetrics.glsl:25-28
 
 // ---------------------------------------------------------------------- LDS scene table
 // One float4 array per workgroup, staged from HBM by stage_table():
@@ -186,7 +220,7 @@ template <bool ADA_DIV> MDH_TRI float sd_triangle(f3 a, f3 b, f3 c, f3 p)
    } else {
       r = tdiv<ADA_DIV>(dot(nor, p1) * dot(nor, p1), dot2(nor));
    }
-   return __builtin_sqrtf(r);
+   return sqrt_(r);
 }
 // madarch-primitives-boxes.adb:5,17-41
 MDH_DEV f3 nrm_box(float4 a, float4 b, f3 p)
@@ -221,6 +255,9 @@ MDH_DEV float prim_dist(int type, int slot, f3 x)
    }
 }
 
+#ifndef MDH_SDF_UNROLL
+#define MDH_SDF_UNROLL 2
+#endif
 // closest_primitive (scenes.adb:602-629).  min is order-free, so the primitives are
 // visited by TYPE: four plain loops, wave-uniform trip counts, LDS broadcast reads.
 MDH_DEV float closest_primitive(const KScene &sc, f3 x)
@@ -228,17 +265,17 @@ MDH_DEV float closest_primitive(const KScene &sc, f3 x)
    float closest = sc.max_dist;
    {
       const int n = sc.tcount[PK_SPHERE], s0 = sc.tslot[PK_SPHERE];
-#pragma unroll 2
+#pragma unroll MDH_SDF_UNROLL
       for (int i = 0; i < n; ++i) closest = min_(closest, sd_sphere(s_tab[s0 + i], x));
    }
    {
       const int n = sc.tcount[PK_PLANE], s0 = sc.tslot[PK_PLANE];
-#pragma unroll 2
+#pragma unroll MDH_SDF_UNROLL
       for (int i = 0; i < n; ++i) closest = min_(closest, sd_plane(s_tab[s0 + i], x));
    }
    {
       const int n = sc.tcount[PK_BOX], s0 = sc.tslot[PK_BOX];
-#pragma unroll 2
+#pragma unroll MDH_SDF_UNROLL
       for (int i = 0; i < n; ++i) closest = min_(closest, sd_box(s_tab[s0 + 2 * i], s_tab[s0 + 2 * i + 1], x));
    }
    {
@@ -350,7 +387,7 @@ template <bool PART> MDH_DEV float softshadows(const KScene &sc, f3 from, f3 dir
       float dist = sdf<PART>(sc, from + dir * total);
       if (dist < MDH_EPS) return 0.0f;
       float y = dist * dist / (2.0f * prev_dist);
-      float d = __builtin_sqrtf(dist * dist - y * y);
+      float d = sqrt_(dist * dist - y * y);
       res = min_(res, k * d / max_(0.0f, total - y));
       prev_dist = dist;
       total += dist;

@@ -13,7 +13,7 @@
 #define MDH_SHADE shade_structured
 #endif
 #ifndef MDH_WAVES_PER_SIMD
-#define MDH_WAVES_PER_SIMD 4 // register budget of the march kernels: 512 / 4 = 128 VGPRs
+#define MDH_WAVES_PER_SIMD 6 // register budget of the march kernels (measured: 6 > 5 > 8 > 4 > 3 > 2 waves/SIMD)
 #endif
 
 // ------------------------------------------------------------------------ screen pass

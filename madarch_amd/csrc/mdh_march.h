@@ -87,7 +87,7 @@ MDH_DEV f3 shade_machine(const KScene &sc, const KProbes &pr, const MachineCfg c
             } else {
                if (kind == RAY_SOFT) { // raymarching.glsl:15-19
                   float y = dist * dist / (2.0f * prev);
-                  float d = __builtin_sqrtf(dist * dist - y * y);
+                  float d = sqrt_(dist * dist - y * y);
                   res = min_(res, 64.0f * d / max_(0.0f, t - y));
                   prev = dist;
                }
@@ -388,7 +388,7 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
                         float dist = sdf<PART>(sc, from_off + L * total);
                         if (dist < MDH_EPS) { blocked = true; break; }
                         float y = dist * dist / (2.0f * prev);
-                        float d = __builtin_sqrtf(dist * dist - y * y);
+                        float d = sqrt_(dist * dist - y * y);
                         res = min_(res, 64.0f * d / max_(0.0f, total - y));
                         prev = dist;
                         total += dist;

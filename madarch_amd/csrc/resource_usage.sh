@@ -2,7 +2,7 @@
 # prints "kernel VGPRs SGPRs scratch occupancy LDS" for every kernel of mdh_api.hip
 cd "$(dirname "$0")"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math \
-  -fhip-fp32-correctly-rounded-divide-sqrt -fno-gpu-flush-denormals-to-zero -Wno-unused-value $EXTRA \
+  -fhip-fp32-correctly-rounded-divide-sqrt -fno-gpu-flush-denormals-to-zero -fno-vectorize -fno-slp-vectorize -Wno-unused-value $EXTRA \
   -Rpass-analysis=kernel-resource-usage --cuda-device-only -c -o /dev/null mdh_api.hip 2>&1 |
 python3 -c '
 import re,sys
