@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--workload", default="global_illumination_1080p_ddgi8x8x8", choices=sorted(WORKLOADS))
     ap.add_argument("--atlas", default="rgb8", choices=("rgb8", "f32"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", type=int, default=None, help="override the screen mode (ablation runs only)")
     args = ap.parse_args()
 
     import torch
@@ -116,6 +117,8 @@ def main():
 
     R = make_renderer(args.workload, B.hip_binding(), device=local_rank)
     R.Set_Option(B.OPT_ATLAS_FORMAT, 0 if args.atlas == "rgb8" else 1)
+    if args.mode is not None:
+        R.Set_Option(B.OPT_SCREEN_MODE, args.mode)
     exchange = sharding.DeviceExchange(dist, R, torch.device("cuda", local_rank)) if world > 1 else None
     frame = sharding.ShardedFrame(R, rank, world, exchange)
 

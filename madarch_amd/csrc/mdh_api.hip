@@ -195,11 +195,13 @@ static float i_as_f(int i) { float f; memcpy(&f, &i, 4); return f; }
 static int commit_scene(mdh_renderer *r)
 {
    KScene &s = r->ks;
-   s.nk = r->npk;
-   s.nl = r->nlk;
    s.max_dist = r->max_dist;
    std::vector<float4> &t = r->table_host;
    t.clear();
+   int H[H_INTS] = {0};
+   t.resize(H_INTS / 4); // the int header, filled in at the end
+   H[H_NK] = r->npk;
+   H[H_NL] = r->nlk;
    for (int ty = 0; ty < 4; ++ty) { s.tcount[ty] = 0; s.tslot[ty] = 0; }
    // geometry: kind by kind, the elements below the runtime count
    for (int k = 0; k < r->npk; ++k) {
@@ -207,7 +209,7 @@ static int commit_scene(mdh_renderer *r)
       int n = rd_i(r, kd.count_off);
       if (n < 0) n = 0;
       if (n > kd.max_count) n = kd.max_count;
-      s.ktype[k] = kd.type; s.kcount[k] = n; s.kbase[k] = r->prim_base[k]; s.kmax[k] = kd.max_count; s.kslot[k] = (int)t.size();
+      H[H_KTYPE + k] = kd.type; H[H_KCOUNT + k] = n; H[H_KBASE + k] = r->prim_base[k]; H[H_KMAX + k] = kd.max_count; H[H_KSLOT + k] = (int)t.size();
       s.tcount[kd.type] = n; s.tslot[kd.type] = (int)t.size();
       for (int i = 0; i < n; ++i) {
          int b = kd.array_off + kd.stride * i;
@@ -222,10 +224,10 @@ static int commit_scene(mdh_renderer *r)
    // material ids (int32), 4 per float4
    for (int k = 0; k < r->npk; ++k) {
       const Kind &kd = r->pk[k];
-      s.kmat[k] = (int)t.size() * 4;
-      for (int i0 = 0; i0 < s.kcount[k]; i0 += 4) {
+      H[H_KMAT + k] = (int)t.size() * 4;
+      for (int i0 = 0; i0 < H[H_KCOUNT + k]; i0 += 4) {
          float m[4] = {0, 0, 0, 0};
-         for (int j = 0; j < 4 && i0 + j < s.kcount[k]; ++j) m[j] = i_as_f(rd_i(r, kd.array_off + kd.stride * (i0 + j) + kd.f_d));
+         for (int j = 0; j < 4 && i0 + j < H[H_KCOUNT + k]; ++j) m[j] = i_as_f(rd_i(r, kd.array_off + kd.stride * (i0 + j) + kd.f_d));
          t.push_back(mk4(m[0], m[1], m[2], m[3]));
       }
    }
@@ -234,7 +236,7 @@ static int commit_scene(mdh_renderer *r)
       int n = rd_i(r, kd.count_off);
       if (n < 0) n = 0;
       if (n > kd.max_count) n = kd.max_count;
-      s.ltype[k] = kd.type; s.lcount[k] = n; s.lslot[k] = (int)t.size();
+      H[H_LTYPE + k] = kd.type; H[H_LCOUNT + k] = n; H[H_LSLOT + k] = (int)t.size();
       for (int i = 0; i < n; ++i) {
          int b = kd.array_off + kd.stride * i;
          if (kd.type == LK_POINT) { t.push_back(rd_v3w(r, b + kd.f_a, 0.0f)); t.push_back(rd_v3w(r, b + kd.f_b, 0.0f)); }
@@ -252,6 +254,7 @@ static int commit_scene(mdh_renderer *r)
    // k / 255 for k = 0..255: the RGB8 texel decode, one correctly rounded division each
    s.u8_slot = (int)t.size();
    for (int k = 0; k < 256; k += 4) t.push_back(mk4((float)k / 255.0f, (float)(k + 1) / 255.0f, (float)(k + 2) / 255.0f, (float)(k + 3) / 255.0f));
+   memcpy(t.data(), H, sizeof H);
    s.table_f4 = (int)t.size();
    if ((size_t)s.table_f4 * 16 > 64 * 1024) return seterr(MDH_E_INVALID, "scene tables exceed the 64 KiB LDS budget of a workgroup");
    if (t.size() > r->table_cap) {
@@ -281,6 +284,8 @@ static KProbes make_probes(const mdh_renderer *r)
    p.sx = r->probes.grid_spacing[0]; p.sy = r->probes.grid_spacing[1]; p.sz = r->probes.grid_spacing[2];
    p.rres = r->probes.radiance_resolution; p.ires = r->probes.irradiance_resolution;
    p.fmt = r->opt_atlas;
+   auto log2_or_neg = [](int v) { int s = 0; while ((1 << s) < v) ++s; return (1 << s) == v ? s : -1; };
+   p.rshift = log2_or_neg(p.rres); p.ishift = log2_or_neg(p.ires); p.pcx_shift = log2_or_neg(p.pcx);
    p.rad = r->d_rad; p.irr = r->d_irr;
    own_probes(r, &p.probe_begin, &p.probe_end);
    return p;
@@ -543,6 +548,8 @@ static int ensure_committed(mdh_renderer *r)
    return MDH_OK;
 }
 static size_t lds_bytes(const mdh_renderer *r) { return (size_t)r->ks.table_f4 * sizeof(float4); }
+// the march kernels park MDH_PARK_DWORDS floats per thread behind the table (mdh_march.h)
+static size_t lds_bytes_march(const mdh_renderer *r) { return lds_bytes(r) + (size_t)MDH_PARK_DWORDS * MDH_BLOCK * sizeof(float); }
 
 // Update_Partitioning (renderers.adb:757-775): all three methods build the table on the device
 extern "C" int32_t mdh_update_partitioning(mdh_renderer *r, int32_t method)
@@ -578,8 +585,8 @@ extern "C" int32_t mdh_update_partitioning(mdh_renderer *r, int32_t method)
 
 template <bool PART, int MODE> static void launch_screen_g(mdh_renderer *r, const KProbes &pr, const KVolumetrics &vol, const KCamera &cam, const ScreenArgs &a, int blocks)
 {
-   if (r->opt_gbuffer) hipLaunchKernelGGL((k_screen<PART, MODE, true>), dim3(blocks), dim3(MDH_BLOCK), lds_bytes(r), r->stream, r->ks, pr, vol, cam, a);
-   else hipLaunchKernelGGL((k_screen<PART, MODE, false>), dim3(blocks), dim3(MDH_BLOCK), lds_bytes(r), r->stream, r->ks, pr, vol, cam, a);
+   if (r->opt_gbuffer) hipLaunchKernelGGL((k_screen<PART, MODE, true>), dim3(blocks), dim3(MDH_BLOCK), lds_bytes_march(r), r->stream, r->ks, pr, vol, cam, a);
+   else hipLaunchKernelGGL((k_screen<PART, MODE, false>), dim3(blocks), dim3(MDH_BLOCK), lds_bytes_march(r), r->stream, r->ks, pr, vol, cam, a);
 }
 template <bool PART> static void launch_screen_m(mdh_renderer *r, const KProbes &pr, const KVolumetrics &vol, const KCamera &cam, const ScreenArgs &a, int blocks)
 {
@@ -605,8 +612,8 @@ static int run_pass(mdh_renderer *r, int pass)
       long n = (long)(pr.probe_end - pr.probe_begin) * pr.rres * pr.rres;
       if (n > 0) {
          int blocks = (int)((n + MDH_BLOCK - 1) / MDH_BLOCK);
-         if (part) hipLaunchKernelGGL(k_radiance<true>, dim3(blocks), dim3(MDH_BLOCK), lds_bytes(r), r->stream, r->ks, pr);
-         else hipLaunchKernelGGL(k_radiance<false>, dim3(blocks), dim3(MDH_BLOCK), lds_bytes(r), r->stream, r->ks, pr);
+         if (part) hipLaunchKernelGGL(k_radiance<true>, dim3(blocks), dim3(MDH_BLOCK), lds_bytes_march(r), r->stream, r->ks, pr);
+         else hipLaunchKernelGGL(k_radiance<false>, dim3(blocks), dim3(MDH_BLOCK), lds_bytes_march(r), r->stream, r->ks, pr);
       }
       break;
    }

@@ -32,33 +32,41 @@ enum { PK_SPHERE = 0, PK_PLANE = 1, PK_BOX = 2, PK_TRIANGLE = 3 };
 enum { LK_POINT = 0, LK_SPOT = 1 };
 
 // ---------------------------------------------------------------- kernel argument blocks
-// Uniform scene header: lives in SGPRs.  `slot` values index the float4 table in LDS.
+// Uniform scene header.  The part the march loops need on every step lives in SGPRs (kernel
+// arguments); the per-kind bookkeeping that only the cold paths read (arg-min index, normals,
+// light dispatch) sits in an int block at the head of the LDS table -- SGPRs are the scarce
+// resource of these kernels (they ran at the 102-SGPR limit with everything passed by value).
 struct KScene {
-   int nk;
-   int ktype[MDH_MAX_KINDS];  // PK_*
-   int kcount[MDH_MAX_KINDS]; // runtime count  (prim_<K>_count, scenes.adb:560-565)
-   int kbase[MDH_MAX_KINDS];  // flat index base = sum of earlier DECLARED counts (scenes.adb:656-666)
-   int kmax[MDH_MAX_KINDS];   // declared count
-   int kslot[MDH_MAX_KINDS];  // first float4 of the kind's primitives in the table
-   int nl;
-   int ltype[MDH_MAX_LIGHT_KINDS];
-   int lcount[MDH_MAX_LIGHT_KINDS];
-   int lslot[MDH_MAX_LIGHT_KINDS];
+   // the primitives by TYPE, for the order-free min of closest_primitive
+   int tcount[4];    // runtime count of Sphere / Plane / Box / Triangle
+   int tslot[4];     // first float4 of that type's geometry in the table
+   float max_dist;
    int total_lights; // total_light_count (scenes.adb:594)
    int mat_slot;     // first float4 of the materials (2 per material)
-   int table_f4;     // float4 count of the whole table
-   // the same primitives by TYPE, for the order-free min of closest_primitive
-   int tcount[4];    // runtime count of Sphere / Plane / Box / Triangle
-   int tslot[4];     // = kslot of the kind of that type (0 when the type is absent)
-   int kmat[MDH_MAX_KINDS]; // first int of the kind's material ids (int index into the table)
    int u8_slot;      // float4 index of the 256-entry k / 255 table
-   float max_dist;
+   int table_f4;     // float4 count of the whole table
    // space partition (scenes.adb:799-1118)
    int part_enable, part_border, part_index_count, part_cells;
    int part_dims[3];
    float part_sp[3], part_off[3];
-   const float4 *table; // HBM image of the table (staged to LDS by every workgroup)
+   const float4 *table;   // HBM image of the table (staged to LDS by every workgroup)
    const int *part_table; // [cell][nk + index_count]
+};
+// int block at table[0..]: per-kind data in SCENE order (the order the flat primitive index
+// and the arg-min tie-break follow, scenes.adb:656-666) and the light kinds
+enum {
+   H_NK = 0,
+   H_KTYPE = 1,   // [4] PK_*
+   H_KCOUNT = 5,  // [4] runtime count (prim_<K>_count, scenes.adb:560-565)
+   H_KBASE = 9,   // [4] flat index base = sum of earlier DECLARED counts
+   H_KMAX = 13,   // [4] declared count
+   H_KSLOT = 17,  // [4] first float4 of the kind's geometry
+   H_KMAT = 21,   // [4] first int of the kind's material ids
+   H_NL = 25,
+   H_LTYPE = 26,  // [4]
+   H_LCOUNT = 30, // [4]
+   H_LSLOT = 34,  // [4]
+   H_INTS = 40    // 10 float4
 };
 
 struct KProbes {
@@ -67,6 +75,7 @@ struct KProbes {
    float sx, sy, sz;  // grid_spacing
    int rres, ires;    // radiance / irradiance resolution
    int fmt;           // 0 = RGBA8 unorm texels, 1 = float4 texels
+   int rshift, ishift, pcx_shift; // log2 of rres / ires / pcx when a power of two, else -1
    void *rad;         // probe-major [probe][y][x]
    void *irr;
    int probe_begin, probe_end; // slice this rank updates
@@ -191,6 +200,8 @@ MDH_DEV void stage_table(const KScene &sc)
 MDH_DEV int prim_slots(int type) { return type == PK_TRIANGLE ? 3 : (type == PK_BOX ? 2 : 1); }
 MDH_DEV int tab_int(int int_index) { return ((const int *)s_tab)[int_index]; }
 MDH_DEV float tab_float(int float_index) { return ((const float *)s_tab)[float_index]; }
+// header ints: wave-uniform LDS reads, moved to SGPRs
+MDH_DEV int hdr(int i) { return __builtin_amdgcn_readfirstlane(tab_int(i)); }
 
 // ---------------------------------------------------------------------------- the SDFs
 // madarch-primitives-spheres.ads:13-14
@@ -258,25 +269,54 @@ MDH_DEV float prim_dist(int type, int slot, f3 x)
 #ifndef MDH_SDF_UNROLL
 #define MDH_SDF_UNROLL 2
 #endif
-// closest_primitive (scenes.adb:602-629).  min is order-free, so the primitives are
-// visited by TYPE: four plain loops, wave-uniform trip counts, LDS broadcast reads.
+// closest_primitive (scenes.adb:602-629).  min is order-free, so the primitives are visited by
+// TYPE -- planes first, they are cheap and bring `closest` down -- in four plain loops with
+// wave-uniform trip counts and LDS broadcast reads.
+//
+// Spheres and boxes are CULLED conservatively before their square root: when a cheap lower
+// bound of the distance already exceeds `closest` in every lane of the wave (one ballot), the
+// rest of the evaluation is skipped; min(closest, d) would have returned `closest`, so the
+// result is bit-identical.  Margins (1e-6 relative, >> the few-2^-24 rounding of the bound):
+//   sphere: d = sqrt(d2) - r >= closest  <=  d2 > (closest + r)^2 (1 + 1e-6), or closest + r < 0
+//   box:    d >= m (1 - 2^-23) with m = max(q.x, q.y, q.z); skip when m > closest (1 + 1e-6)
+//           (for m <= 0 the distance IS m, for closest <= 0 the test m > closest is exact)
+#ifndef MDH_CULL
+#define MDH_CULL 1
+#endif
 MDH_DEV float closest_primitive(const KScene &sc, f3 x)
 {
    float closest = sc.max_dist;
-   {
-      const int n = sc.tcount[PK_SPHERE], s0 = sc.tslot[PK_SPHERE];
-#pragma unroll MDH_SDF_UNROLL
-      for (int i = 0; i < n; ++i) closest = min_(closest, sd_sphere(s_tab[s0 + i], x));
-   }
    {
       const int n = sc.tcount[PK_PLANE], s0 = sc.tslot[PK_PLANE];
 #pragma unroll MDH_SDF_UNROLL
       for (int i = 0; i < n; ++i) closest = min_(closest, sd_plane(s_tab[s0 + i], x));
    }
    {
+      const int n = sc.tcount[PK_SPHERE], s0 = sc.tslot[PK_SPHERE];
+#pragma unroll 1
+      for (int i = 0; i < n; ++i) {
+         const float4 a = s_tab[s0 + i];
+         const float d2 = dot2(xyz(a) - x); // sd_sphere = sqrt(d2) - a.w (spheres.ads:13-14)
+#if MDH_CULL
+         const float tsum = closest + a.w;
+         const bool need = !(tsum < 0.0f) && !(d2 > (tsum * tsum) * 1.000001f);
+         if (__ballot(need) == 0ull) continue;
+#endif
+         closest = min_(closest, sqrt_(d2) - a.w);
+      }
+   }
+   {
       const int n = sc.tcount[PK_BOX], s0 = sc.tslot[PK_BOX];
-#pragma unroll MDH_SDF_UNROLL
-      for (int i = 0; i < n; ++i) closest = min_(closest, sd_box(s_tab[s0 + 2 * i], s_tab[s0 + 2 * i + 1], x));
+#pragma unroll 1
+      for (int i = 0; i < n; ++i) {
+         const f3 q = abs3(xyz(s_tab[s0 + 2 * i]) - x) - xyz(s_tab[s0 + 2 * i + 1]); // boxes.adb:10
+         const float m = max_(q.x, max_(q.y, q.z));
+#if MDH_CULL
+         const float thr = closest > 0.0f ? closest * 1.000001f : closest;
+         if (__ballot(!(m > thr)) == 0ull) continue;
+#endif
+         closest = min_(closest, length(max3s(q, 0.0f)) + min_(m, 0.0f));
+      }
    }
    {
       const int n = sc.tcount[PK_TRIANGLE], s0 = sc.tslot[PK_TRIANGLE];
@@ -291,9 +331,10 @@ MDH_DEV float closest_primitive(const KScene &sc, f3 x)
 MDH_DEV float closest_primitive_info(const KScene &sc, f3 x, int &index)
 {
    float closest = sc.max_dist;
+   const int nk = hdr(H_NK);
 #pragma unroll 1
-   for (int k = 0; k < sc.nk; ++k) {
-      const int n = sc.kcount[k], s0 = sc.kslot[k], base = sc.kbase[k], type = sc.ktype[k];
+   for (int k = 0; k < nk; ++k) {
+      const int n = hdr(H_KCOUNT + k), s0 = hdr(H_KSLOT + k), base = hdr(H_KBASE + k), type = hdr(H_KTYPE + k);
 #pragma unroll 1
       for (int i = 0; i < n; ++i) {
          float d = prim_dist(type, s0 + prim_slots(type) * i, x);
@@ -309,12 +350,14 @@ MDH_DEV void primitive_info(const KScene &sc, int index, f3 pos, f3 &normal, int
 {
    normal = F3(0.0f, 0.0f, 0.0f);
    material_id = 0;
+   const int nk = hdr(H_NK);
 #pragma unroll 1
-   for (int k = 0; k < sc.nk; ++k) {
-      if (index < sc.kmax[k]) {
-         const int type = sc.ktype[k];
-         const int slot = sc.kslot[k] + prim_slots(type) * index; // per-lane LDS gather
-         material_id = tab_int(sc.kmat[k] + index);
+   for (int k = 0; k < nk; ++k) {
+      const int kmax = hdr(H_KMAX + k);
+      if (index < kmax) {
+         const int type = hdr(H_KTYPE + k);
+         const int slot = hdr(H_KSLOT + k) + prim_slots(type) * index; // per-lane LDS gather
+         material_id = tab_int(hdr(H_KMAT + k) + index);
          float4 a = s_tab[slot];
          switch (type) {
          case PK_SPHERE: normal = normalize(pos - xyz(a)); break; // spheres.ads:16-17
@@ -324,7 +367,7 @@ MDH_DEV void primitive_info(const KScene &sc, int index, f3 pos, f3 &normal, int
          }
          return;
       }
-      index -= sc.kmax[k];
+      index -= kmax;
    }
 }
 
@@ -350,14 +393,15 @@ template <bool INFO> MDH_DEV float partitioning_lookup(const KScene &sc, f3 x, i
    if (fb) return INFO ? closest_primitive_info(sc, x, index) : closest_primitive(sc, x);
    float closest = sc.max_dist;
    if (cell < 0 || cell >= sc.part_cells) return closest;
-   const int *rec = sc.part_table + (size_t)cell * (sc.nk + sc.part_index_count);
+   const int nk = hdr(H_NK);
+   const int *rec = sc.part_table + (size_t)cell * (nk + sc.part_index_count);
    int i = 0;
 #pragma unroll 1
-   for (int k = 0; k < sc.nk; ++k) {
-      const int size = i + rec[k], type = sc.ktype[k], s0 = sc.kslot[k], base = sc.kbase[k];
+   for (int k = 0; k < nk; ++k) {
+      const int size = i + rec[k], type = hdr(H_KTYPE + k), s0 = hdr(H_KSLOT + k), base = hdr(H_KBASE + k);
       const int stop = min(size, sc.part_index_count);
       for (; i < stop; ++i) {
-         int pi = rec[sc.nk + i];
+         int pi = rec[nk + i];
          float d = prim_dist(type, s0 + prim_slots(type) * pi, x);
          if (INFO) { if (d < closest) { closest = d; index = base + pi; } }
          else closest = min_(closest, d);
@@ -427,18 +471,19 @@ template <bool PART> MDH_DEV float raycast_visibility(const KScene &sc, f3 from,
 // sample_<Light> (scenes.adb:497-549) dispatched by cumulative RUNTIME counts (scenes.adb:731-764)
 MDH_DEV f3 sample_light(const KScene &sc, int index, f3 pos, f3 &dir, float &dist)
 {
+   const int nl = hdr(H_NL);
 #pragma unroll 1
-   for (int k = 0; k < sc.nl; ++k) {
-      const int n = sc.lcount[k];
+   for (int k = 0; k < nl; ++k) {
+      const int n = hdr(H_LCOUNT + k);
       if (index < n) {
-         if (sc.ltype[k] == LK_POINT) { // madarch-lights-point_lights.ads:20-22
-            const int s = sc.lslot[k] + 2 * index;
+         if (hdr(H_LTYPE + k) == LK_POINT) { // madarch-lights-point_lights.ads:20-22
+            const int s = hdr(H_LSLOT + k) + 2 * index;
             dir = xyz(s_tab[s]) - pos;
             dist = length(dir);
             dir = dir / dist;
             return xyz(s_tab[s + 1]) / ((dist * dist) * 0.03f);
          }
-         const int s = sc.lslot[k] + 3 * index; // madarch-lights-spot_lights.adb:5-24
+         const int s = hdr(H_LSLOT + k) + 3 * index; // madarch-lights-spot_lights.adb:5-24
          float4 a = s_tab[s];
          dir = xyz(a) - pos;
          dist = length(dir);
@@ -556,7 +601,7 @@ MDH_DEV i3 world_to_grid(const KProbes &pr, f3 p)
 MDH_DEV int grid_to_probe_id(const KProbes &pr, i3 g) { return g.z * pr.gx * pr.gy + g.y * pr.gx + g.x; }
 MDH_DEV f2 probe_id_to_coord(const KProbes &pr, int id)
 {
-   int y = id / pr.pcx, x = id - y * pr.pcx;
+   int y = pr.pcx_shift >= 0 ? (id >> pr.pcx_shift) : (id / pr.pcx), x = id - y * pr.pcx;
    return F2((float)x / (float)pr.pcx, (float)y / (float)pr.pcy);
 }
 // glsl/probe_utils.glsl:58-92
@@ -590,6 +635,7 @@ MDH_DEV f2 ray_dir_to_ray_id(f3 d)
 // GL_MIRRORED_REPEAT (support/render_passes.adb:111-112)
 MDH_DEV int mirror(int i, int n)
 {
+   if ((unsigned)i < (unsigned)n) return i; // inside the image: the usual case, no integer division
    int m = i % (2 * n);
    if (m < 0) m += 2 * n;
    return m >= n ? 2 * n - 1 - m : m;
@@ -599,13 +645,16 @@ MDH_DEV float unorm8(float x) { return (x != x) ? 0.0f : __builtin_rintf(clamp_(
 // Probe atlases are stored probe-major -- [probe][y][x], RGBA8 or float4 texels -- so a
 // rank's probe slice is one contiguous range (DESIGN.md "HBM layout").  (X, Y) are texel
 // coordinates of the reference's 2-D atlas image, X = tile_x * res + x.
-MDH_DEV size_t atlas_index(int pcx, int res, int X, int Y)
+// `shift` = log2(res) when res is a power of two (wave-uniform fast path), else -1
+MDH_DEV unsigned atlas_index(int pcx, int res, int shift, int X, int Y)
 {
-   int tx = X / res, ty = Y / res;
-   return ((size_t)(ty * pcx + tx) * res + (Y - ty * res)) * res + (X - tx * res);
+   int tx, ty;
+   if (shift >= 0) { tx = X >> shift; ty = Y >> shift; }
+   else { tx = X / res; ty = Y / res; }
+   return ((unsigned)(ty * pcx + tx) * res + (Y - ty * res)) * res + (X - tx * res);
 }
 // u8_tab = float index of the k / 255 table in LDS (KScene::u8_slot * 4), or < 0: divide
-MDH_DEV f3 atlas_texel(const void *base, int fmt, size_t idx, int u8_tab)
+MDH_DEV f3 atlas_texel(const void *base, int fmt, unsigned idx, int u8_tab)
 {
    if (fmt == 0) {
       uchar4 t = ((const uchar4 *)base)[idx];
@@ -615,7 +664,7 @@ MDH_DEV f3 atlas_texel(const void *base, int fmt, size_t idx, int u8_tab)
    float4 t = ((const float4 *)base)[idx];
    return F3(t.x, t.y, t.z);
 }
-MDH_DEV void atlas_store(void *base, int fmt, size_t idx, f3 v)
+MDH_DEV void atlas_store(void *base, int fmt, unsigned idx, f3 v)
 {
    if (fmt == 0) {
       uchar4 t;
@@ -628,7 +677,7 @@ MDH_DEV void atlas_store(void *base, int fmt, size_t idx, f3 v)
    }
 }
 // GL_LINEAR on the atlas image of pcx*res x pcy*res texels (render_passes.adb:113-114)
-MDH_DEV f3 atlas_sample(const void *base, int fmt, int pcx, int pcy, int res, float cx, float cy, int u8_tab)
+MDH_DEV f3 atlas_sample(const void *base, int fmt, int pcx, int pcy, int res, int shift, float cx, float cy, int u8_tab)
 {
    const int W = pcx * res, H = pcy * res;
    float px = cx * (float)W - 0.5f, py = cy * (float)H - 0.5f;
@@ -636,8 +685,8 @@ MDH_DEV f3 atlas_sample(const void *base, int fmt, int pcx, int pcy, int res, fl
    float fx = px - fx0, fy = py - fy0;
    int x0 = mirror((int)fx0, W), x1 = mirror((int)fx0 + 1, W), y0 = mirror((int)fy0, H), y1 = mirror((int)fy0 + 1, H);
    float w00 = (1.0f - fx) * (1.0f - fy), w10 = fx * (1.0f - fy), w01 = (1.0f - fx) * fy, w11 = fx * fy;
-   f3 a = atlas_texel(base, fmt, atlas_index(pcx, res, x0, y0), u8_tab), b = atlas_texel(base, fmt, atlas_index(pcx, res, x1, y0), u8_tab);
-   f3 c = atlas_texel(base, fmt, atlas_index(pcx, res, x0, y1), u8_tab), d = atlas_texel(base, fmt, atlas_index(pcx, res, x1, y1), u8_tab);
+   f3 a = atlas_texel(base, fmt, atlas_index(pcx, res, shift, x0, y0), u8_tab), b = atlas_texel(base, fmt, atlas_index(pcx, res, shift, x1, y0), u8_tab);
+   f3 c = atlas_texel(base, fmt, atlas_index(pcx, res, shift, x0, y1), u8_tab), d = atlas_texel(base, fmt, atlas_index(pcx, res, shift, x1, y1), u8_tab);
    return ((a * w00 + b * w10) + c * w01) + d * w11;
 }
 
@@ -669,7 +718,7 @@ template <bool PART> MDH_DEV f3 sample_irradiance(const KScene &sc, const KProbe
       f3 tri = F3(mix_(1.0f - alpha.x, alpha.x, (float)ox), mix_(1.0f - alpha.y, alpha.y, (float)oy), mix_(1.0f - alpha.z, alpha.z, (float)oz));
       weight *= tri.x * tri.y * tri.z;
       f2 base = probe_id_to_coord(pr, grid_to_probe_id(pr, q));
-      f3 tx = atlas_sample(pr.irr, pr.fmt, pr.pcx, pr.pcy, pr.ires, base.x + rid.x / (float)pr.pcx, base.y + rid.y / (float)pr.pcy, sc.u8_slot * 4);
+      f3 tx = atlas_sample(pr.irr, pr.fmt, pr.pcx, pr.pcy, pr.ires, pr.ishift, base.x + rid.x / (float)pr.pcx, base.y + rid.y / (float)pr.pcy, sc.u8_slot * 4);
       irradiance = irradiance + sqrt3(tx) * weight;
       total_weight += weight;
    }
@@ -708,7 +757,7 @@ template <bool PART> MDH_DEV f3 sample_radiance_no_specular(const KScene &sc, co
    f2 rid = ray_dir_to_ray_id(best_pts);
    rid = F2(clamp_(rid.x, rmin, rmax), clamp_(rid.y, rmin, rmax));
    // textureLod(.., 1.0) on a single-level texture samples level 0
-   f3 radiance = atlas_sample(pr.rad, pr.fmt, pr.pcx, pr.pcy, pr.rres, base.x + rid.x / (float)pr.pcx, base.y + rid.y / (float)pr.pcy, sc.u8_slot * 4);
+   f3 radiance = atlas_sample(pr.rad, pr.fmt, pr.pcx, pr.pcy, pr.rres, pr.rshift, base.x + rid.x / (float)pr.pcx, base.y + rid.y / (float)pr.pcy, sc.u8_slot * 4);
    Material m = get_material(sc, spec_mat);
    return radiance + compute_direct_lighting<PART>(sc, spec_pos, spec_normal, dir, F3(0.0f, 0.0f, 0.0f), m.metallic, m.roughness, true);
 }

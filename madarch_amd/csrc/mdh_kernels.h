@@ -5,9 +5,10 @@
 #pragma once
 
 #include "mdh_device.h"
-#include "mdh_march.h"
 
 #define MDH_BLOCK 256 // 4 wavefronts; every wavefront owns one 8x8 tile
+
+#include "mdh_march.h"
 // which formulation of the pixel program the screen / radiance kernels run (mdh_march.h)
 #ifndef MDH_SHADE
 #define MDH_SHADE shade_structured
@@ -100,7 +101,7 @@ template <bool PART> __global__ __launch_bounds__(MDH_BLOCK, MDH_WAVES_PER_SIMD)
    bool hit;
    f3 pos;
    f3 c = MDH_SHADE<PART, 0>(sc, pr, cfg, valid, world, ray_dir, ph, hit, pos);
-   if (valid) atlas_store(pr.rad, pr.fmt, atlas_index(pr.pcx, pr.rres, i, j), c);
+   if (valid) atlas_store(pr.rad, pr.fmt, atlas_index(pr.pcx, pr.rres, pr.rshift, i, j), c);
 }
 
 // -------------------------------------------------------------------- irradiance pass
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(MDH_IRR_BLOCK) void k_irradiance(KProbes pr)
    for (int tap = threadIdx.x; tap < ntaps; tap += MDH_IRR_BLOCK) {
       const int yy = tap / pr.rres, xx = tap - yy * pr.rres;
       f2 c = F2(clamp_(rad_coord.x + (float)xx * step.x, step.x, 1.0f - step.x), clamp_(rad_coord.y + (float)yy * step.y, step.y, 1.0f - step.y));
-      f3 rad = atlas_sample(pr.rad, pr.fmt, pr.pcx, pr.pcy, pr.rres, c.x, c.y, -1);
+      f3 rad = atlas_sample(pr.rad, pr.fmt, pr.pcx, pr.pcy, pr.rres, pr.rshift, c.x, c.y, -1);
       f3 rad_dir = ray_id_to_ray_dir(F2(fract_(c.x * pcx), fract_(c.y * pcy)));
       s_taps[2 * tap] = make_float4(rad.x, rad.y, rad.z, 0.0f);
       s_taps[2 * tap + 1] = make_float4(rad_dir.x, rad_dir.y, rad_dir.z, 0.0f);
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(MDH_IRR_BLOCK) void k_irradiance(KProbes pr)
          total_weight += w;
       }
       irradiance = irradiance / total_weight;
-      atlas_store(pr.irr, pr.fmt, atlas_index(pr.pcx, pr.ires, i, j), irradiance);
+      atlas_store(pr.irr, pr.fmt, atlas_index(pr.pcx, pr.ires, pr.ishift, i, j), irradiance);
    }
 }
 
@@ -239,7 +240,8 @@ struct PartBuildArgs {
 // go through Primitives.Eval_Dist (madarch-primitives.adb:90-108)
 template <bool ADA_DIV> MDH_DEV float part_dist(const KScene &sc, int k, int i, f3 x)
 {
-   const int type = sc.ktype[k], slot = sc.kslot[k] + prim_slots(type) * i;
+   // k may differ per lane here (candidate lists): plain per-lane header reads, not hdr()
+   const int type = tab_int(H_KTYPE + k), slot = tab_int(H_KSLOT + k) + prim_slots(type) * i;
    if (type == PK_TRIANGLE) return sd_triangle<ADA_DIV>(xyz(s_tab[slot]), xyz(s_tab[slot + 1]), xyz(s_tab[slot + 2]), x);
    return prim_dist(type, slot, x);
 }
@@ -255,24 +257,25 @@ __global__ __launch_bounds__(64) void k_partition_build(KScene sc, PartBuildArgs
    const int cell = X * a.gy * a.gz + Y * a.gz + Z;
    if (cell >= sc.part_cells) return;
    const f3 sp = F3(a.sp[0], a.sp[1], a.sp[2]), off = F3(a.off[0], a.off[1], a.off[2]);
+   const int nk = hdr(H_NK);
    unsigned short pre[MDH_PART_MAX_PRE]; // (kind << 12) | index
    int npre = 0;
    unsigned char accepted[MDH_PART_MAX_PRE];
    if (a.method == 2) {
       const f3 center = (F3((float)X, (float)Y, (float)Z) + F3s(0.5f)) * sp + off;
       const float thr = closest_primitive(sc, center) + a.gpu_diag;
-      for (int k = 0; k < sc.nk; ++k)
-         for (int i = 0; i < sc.kcount[k]; ++i)
+      for (int k = 0; k < nk; ++k)
+         for (int i = 0; i < hdr(H_KCOUNT + k); ++i)
             if (part_dist<false>(sc, k, i, center) < thr && npre < MDH_PART_MAX_PRE) { pre[npre] = (unsigned short)((k << 12) | i); accepted[npre++] = 1; }
    } else {
       const f3 grid_pos = F3((float)X, (float)Y, (float)Z) * sp + off;
       const float cell_diag = length(sp);
       const f3 center = grid_pos + sp * 0.5f;
       float closest = 1.0e10f;
-      for (int k = 0; k < sc.nk; ++k)
-         for (int i = 0; i < sc.kcount[k]; ++i) closest = min_(closest, part_dist<true>(sc, k, i, center));
-      for (int k = 0; k < sc.nk; ++k)
-         for (int i = 0; i < sc.kcount[k]; ++i)
+      for (int k = 0; k < nk; ++k)
+         for (int i = 0; i < hdr(H_KCOUNT + k); ++i) closest = min_(closest, part_dist<true>(sc, k, i, center));
+      for (int k = 0; k < nk; ++k)
+         for (int i = 0; i < hdr(H_KCOUNT + k); ++i)
             if (part_dist<true>(sc, k, i, center) < closest + cell_diag && npre < MDH_PART_MAX_PRE) { pre[npre] = (unsigned short)((k << 12) | i); accepted[npre++] = (a.method == 1); }
       if (a.method == 0) { // Find_Candidates, renderers.adb:669-723: 3x3x3 sample points
          // acceptance ORDER defines the order of a kind's indices: keep a sequence number
@@ -294,21 +297,21 @@ __global__ __launch_bounds__(64) void k_partition_build(KScene sc, PartBuildArgs
    }
    // write counts and indices kind by kind (Write_Partitioning_Info, renderers.adb:578-608);
    // the reference only warns when a cell overflows Index_Count, here the list is cut
-   int *rec = a.table + (size_t)cell * (sc.nk + sc.part_index_count);
+   int *rec = a.table + (size_t)cell * (nk + sc.part_index_count);
    int written = 0;
-   for (int k = 0; k < sc.nk; ++k) {
+   for (int k = 0; k < nk; ++k) {
       int n = 0;
       if (a.method == 0) {
          for (int s = 1; s <= 27; ++s)
             for (int q = 0; q < npre; ++q)
                if (accepted[q] == s && (pre[q] >> 12) == k) {
-                  if (written + n < sc.part_index_count) rec[sc.nk + written + n] = pre[q] & 0xfff;
+                  if (written + n < sc.part_index_count) rec[nk + written + n] = pre[q] & 0xfff;
                   ++n;
                }
       } else {
          for (int q = 0; q < npre; ++q)
             if (accepted[q] && (pre[q] >> 12) == k) {
-               if (written + n < sc.part_index_count) rec[sc.nk + written + n] = pre[q] & 0xfff;
+               if (written + n < sc.part_index_count) rec[nk + written + n] = pre[q] & 0xfff;
                ++n;
             }
       }
@@ -340,12 +343,12 @@ template <bool ADA_DIV> __global__ __launch_bounds__(64) void k_eval_distance(KS
    float closest = 1.0e10f;
    f3 normal = F3(0.0f, 0.0f, 0.0f);
    for (int kk = 0; kk < a.n_kinds; ++kk) {
-      const int k = a.kinds[kk], type = sc.ktype[k];
+      const int k = a.kinds[kk], type = hdr(H_KTYPE + k);
       for (int i = 0; i < a.host_count[k]; ++i) {
          float d = part_dist<ADA_DIV>(sc, k, i, p);
          if (d < closest) {
             closest = d;
-            const int slot = sc.kslot[k] + prim_slots(type) * i;
+            const int slot = hdr(H_KSLOT + k) + prim_slots(type) * i;
             float4 A = s_tab[slot];
             switch (type) {
             case PK_SPHERE: normal = normalize(p - xyz(A)); break;

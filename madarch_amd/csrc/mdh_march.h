@@ -200,7 +200,7 @@ MDH_DEV f3 shade_machine(const KScene &sc, const KProbes &pr, const MachineCfg c
                f2 rid = ray_dir_to_ray_id(N);
                rid = F2(clamp_(rid.x, irr_min, irr_max), clamp_(rid.y, irr_min, irr_max));
                f2 base = probe_id_to_coord(pr, grid_to_probe_id(pr, q));
-               f3 tx = atlas_sample(pr.irr, pr.fmt, pr.pcx, pr.pcy, pr.ires, base.x + rid.x / (float)pr.pcx, base.y + rid.y / (float)pr.pcy, sc.u8_slot * 4);
+               f3 tx = atlas_sample(pr.irr, pr.fmt, pr.pcx, pr.pcy, pr.ires, pr.ishift, base.x + rid.x / (float)pr.pcx, base.y + rid.y / (float)pr.pcy, sc.u8_slot * 4);
                acc = acc + sqrt3(tx) * weight;
                accw += weight;
             } else { // render_probes.glsl:170-183
@@ -223,7 +223,7 @@ MDH_DEV f3 shade_machine(const KScene &sc, const KProbes &pr, const MachineCfg c
                const float rmin = 0.5f / (float)pr.rres, rmax = 1.0f - rmin;
                f2 rid = ray_dir_to_ray_id(best_pts);
                rid = F2(clamp_(rid.x, rmin, rmax), clamp_(rid.y, rmin, rmax));
-               spec_rad = atlas_sample(pr.rad, pr.fmt, pr.pcx, pr.pcy, pr.rres, base.x + rid.x / (float)pr.pcx, base.y + rid.y / (float)pr.pcy, sc.u8_slot * 4);
+               spec_rad = atlas_sample(pr.rad, pr.fmt, pr.pcx, pr.pcy, pr.rres, pr.rshift, base.x + rid.x / (float)pr.pcx, base.y + rid.y / (float)pr.pcy, sc.u8_slot * 4);
                it = 0; Lo = F3(0.0f, 0.0f, 0.0f);
                todo = T_LIGHT_BEGIN;
             }
@@ -325,21 +325,40 @@ template <bool PART> MDH_DEV bool march_plain(const KScene &sc, f3 o, f3 d, floa
    return h;
 }
 
+// Per-lane parking space in LDS behind the scene table (MDH_PARK_DWORDS floats per thread,
+// [slot][thread] so that a wave's access is one conflict-free row).  What the first shaded
+// point leaves behind for the final combine -- position, normal, view direction, direct light,
+// irradiance -- is cold while the reflection's point is shaded: parking it takes 15 VGPRs
+// out of the live set of the inner loops, where hipcc would otherwise spill them to scratch
+// (HBM round trips inside the probe loop; measured 47 % of the wave's cycles waiting).
+#define MDH_PARK_DWORDS 16
+MDH_DEV float *park_base(const KScene &sc) { return (float *)(s_tab + sc.table_f4); }
+MDH_DEV void park_store3(float *pk, int slot, f3 v)
+{
+   pk[(slot + 0) * MDH_BLOCK + threadIdx.x] = v.x;
+   pk[(slot + 1) * MDH_BLOCK + threadIdx.x] = v.y;
+   pk[(slot + 2) * MDH_BLOCK + threadIdx.x] = v.z;
+}
+MDH_DEV f3 park_load3(const float *pk, int slot)
+{
+   return F3(pk[(slot + 0) * MDH_BLOCK + threadIdx.x], pk[(slot + 1) * MDH_BLOCK + threadIdx.x], pk[(slot + 2) * MDH_BLOCK + threadIdx.x]);
+}
+
 template <bool PART, int MODE>
-MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCfg cfg, bool lane_valid, f3 from, f3 dir,
-                            PrimaryHit &ph, bool &hit, f3 &pos)
+MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCfg cfg, bool lane_valid, f3 from, f3 dir_in,
+                            PrimaryHit &ph, bool &hit, f3 &pos_out)
 {
    const int u8_tab = sc.u8_slot * 4;
+   float *pk = park_base(sc);
    hit = false;
-   pos = F3(0.0f, 0.0f, 0.0f);
    ph.index = -1; ph.t = 0.0f; ph.steps = 0;
-   f3 normal = F3(0.0f, 0.0f, 0.0f), direct = F3(0.0f, 0.0f, 0.0f), irr = F3(0.0f, 0.0f, 0.0f), specular_col = F3(0.0f, 0.0f, 0.0f);
-   f3 result = F3(0.0f, 0.0f, 0.0f);
+   f3 specular_col = F3(0.0f, 0.0f, 0.0f);
    int mat_id = 0;
    bool shaded = false; // the primary ray hit and the full shading ran
    // the ray that finds the next point to shade
-   f3 ro = from, rd = dir;
+   f3 ro = from, rd = dir_in;
    bool active = lane_valid;
+   park_store3(pk, 6, dir_in);
 #pragma unroll 1
    for (int ctx = 0; ctx < 2; ++ctx) {
       if (active) {
@@ -347,150 +366,180 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
          int steps;
          const bool h = march_plain<PART>(sc, ro, rd, sc.max_dist, t, steps);
          if (ctx == 0) { hit = h; ph.steps = steps; }
-         if (!h) {
-            if (ctx == 0) { // render_probes.glsl:287
-               float s = dir.y * 0.7f;
-               result = F3(0.30f - s, 0.36f - s, 0.60f - s);
-            }
-            active = false; // ctx 1: specular_col stays 0 (render_probes.glsl:142-144)
-         } else {
+         active = false; // a miss ends the chain (ctx 1: specular_col stays 0, render_probes.glsl:142-144)
+         if (h) {
             const f3 P = ro + rd * t;
             int index = -1;
             (void)sdf_info<PART>(sc, P, index);
             f3 N;
             int pm;
             primitive_info(sc, index, P, N, pm);
-            Material m = get_material(sc, pm);
             if (ctx == 0) {
-               pos = P; normal = N; mat_id = pm;
+               mat_id = pm;
                ph.index = index; ph.t = t;
-               if (MODE == 1) { result = N * 0.5f + F3s(0.5f); active = false; }
-            } else {
-               m.albedo = F3(0.0f, 0.0f, 0.0f); // render_probes.glsl:202-205
+               park_store3(pk, 0, P);
+               park_store3(pk, 3, N);
             }
             if (MODE != 1) {
                const f3 from_off = P + (N * MDH_MIN_STEP) * 5.0f;
                // ---- compute_direct_lighting (lighting.glsl:1-40) at P, seen along rd
                f3 Lo = F3(0.0f, 0.0f, 0.0f);
+               {
+                  Material m = get_material(sc, pm);
+                  if (ctx) m.albedo = F3(0.0f, 0.0f, 0.0f); // render_probes.glsl:202-205
 #pragma unroll 1
-               for (int li = 0; li < sc.total_lights; ++li) {
-                  f3 L;
-                  float L_dist;
-                  f3 radiance = sample_light(sc, li, P, L, L_dist);
-                  float NdotL = max_(dot(N, L), 0.0f);
-                  f3 kD, kS;
-                  cook_torrance(N, -rd, L, NdotL, m.albedo, m.metallic, m.roughness, kD, kS);
-                  float shadows = 0.0f;
-                  if (NdotL > MDH_EPS) { // softshadows, raymarching.glsl:4-23
-                     float res = 1.0f, prev = 1e20f, total = 0.0f;
-                     bool blocked = false;
-                     while (total < L_dist) {
-                        float dist = sdf<PART>(sc, from_off + L * total);
-                        if (dist < MDH_EPS) { blocked = true; break; }
-                        float y = dist * dist / (2.0f * prev);
-                        float d = sqrt_(dist * dist - y * y);
-                        res = min_(res, 64.0f * d / max_(0.0f, total - y));
-                        prev = dist;
-                        total += dist;
+                  for (int li = 0; li < sc.total_lights; ++li) {
+                     f3 L;
+                     float L_dist;
+                     f3 radiance = sample_light(sc, li, P, L, L_dist);
+                     float NdotL = max_(dot(N, L), 0.0f);
+                     f3 kD, kS;
+                     cook_torrance(N, -rd, L, NdotL, m.albedo, m.metallic, m.roughness, kD, kS);
+                     if (ctx == 0 && !cfg.direct_specular) kS = F3(0.0f, 0.0f, 0.0f);
+                     const f3 contrib = (((kD * m.albedo) / MDH_PI + kS) * radiance) * NdotL;
+                     float shadows = 0.0f;
+#ifdef MDH_ABL_NO_SHADOW
+                     if (false) {
+#else
+                     if (NdotL > MDH_EPS) { // softshadows, raymarching.glsl:4-23
+#endif
+                        float res = 1.0f, prev = 1e20f, total = 0.0f;
+                        bool blocked = false;
+                        while (total < L_dist) {
+                           float dist = sdf<PART>(sc, from_off + L * total);
+                           if (dist < MDH_EPS) { blocked = true; break; }
+                           float y = dist * dist / (2.0f * prev);
+                           float d = sqrt_(dist * dist - y * y);
+                           res = min_(res, 64.0f * d / max_(0.0f, total - y));
+                           prev = dist;
+                           total += dist;
+                        }
+                        shadows = blocked ? 0.0f : res;
                      }
-                     shadows = blocked ? 0.0f : res;
+                     Lo = Lo + contrib * shadows;
                   }
-                  if (ctx == 0 && !cfg.direct_specular) kS = F3(0.0f, 0.0f, 0.0f);
-                  Lo = Lo + ((((kD * m.albedo) / MDH_PI + kS) * radiance) * NdotL) * shadows;
                }
-               if (ctx == 0) direct = Lo;
+               if (ctx == 0) park_store3(pk, 9, Lo); // = direct
+               else specular_col = Lo;                // + the radiance tap below (render_probes.glsl:197-206)
                if (MODE == 2) {
-                  active = false;
                   shaded = true;
                } else {
                   // ---- the 8 cage probes of P (render_probes.glsl:13-63 and :156-184)
                   const i3 gp = world_to_grid(pr, P);
-                  const f3 alpha = P / F3(pr.sx, pr.sy, pr.sz) - F3((float)gp.x, (float)gp.y, (float)gp.z);
-                  f3 acc = F3(0.0f, 0.0f, 0.0f), best_pts = F3(0.0f, 0.0f, 1.0f);
+                  // ctx 0: acc = sum sqrt(irradiance) * w, accw = sum w; ctx 1: acc = best probe_to_spec, accw = best weight
+                  f3 acc = (ctx == 0) ? F3(0.0f, 0.0f, 0.0f) : F3(0.0f, 0.0f, 1.0f);
                   float accw = (ctx == 0) ? 0.0f : -2.0f;
-                  i3 best_q;
-                  best_q.x = 0; best_q.y = 0; best_q.z = 0;
-                  f2 rid = F2(0.0f, 0.0f);
-                  if (ctx == 0) {
-                     const float irr_min = 0.5f / (float)pr.ires, irr_max = 1.0f - irr_min;
-                     rid = ray_dir_to_ray_id(N);
-                     rid = F2(clamp_(rid.x, irr_min, irr_max), clamp_(rid.y, irr_min, irr_max));
-                  }
+                  int best_q = 0; // x | y << 10 | z << 20
 #pragma unroll 1
                   for (int i = 0; i < 8; ++i) {
                      const i3 q = cage_probe(pr, gp, i);
                      const f3 pw = grid_to_world(pr, q);
                      const f3 hvec = (ctx == 0) ? (pw - P) : (P - pw);
                      const float dist = length(hvec);
-                     const f3 u = hvec / dist; // ctx 0: dir_to_probe, ctx 1: probe_to_spec
-                     const f3 vd = (ctx == 0) ? u : -u;
+                     f3 vd = hvec / dist; // ctx 0: dir_to_probe, ctx 1: probe_to_spec
+                     if (ctx) vd = -vd;   // the visibility ray always runs from the point to the probe
                      // raycast_visibility, raymarching.glsl:39-56
                      float vis = 1.0f, total = 0.0f;
                      const float vmax = dist - MDH_MIN_STEP * 5.0f;
+#ifdef MDH_ABL_NO_VIS
+                     if (false)
+#endif
                      while (total < vmax) {
                         float sd = sdf<PART>(sc, from_off + vd * total);
                         if (sd < MDH_EPS) { vis = 0.0f; break; }
                         total += sd;
                      }
                      if (ctx == 0) { // render_probes.glsl:26-62
-                        float angle = (dot(u, N) + 1.0f) * 0.5f;
+                        float angle = (dot(vd, N) + 1.0f) * 0.5f;
                         float weight = angle * angle + 0.2f;
                         weight *= vis;
                         const float crush = 0.2f;
                         if (weight < crush) weight *= weight * weight * (1.0f / (crush * crush));
+                        const f3 alpha = P / F3(pr.sx, pr.sy, pr.sz) - F3((float)gp.x, (float)gp.y, (float)gp.z);
                         f3 tri = F3(mix_(1.0f - alpha.x, alpha.x, (float)(i & 1)), mix_(1.0f - alpha.y, alpha.y, (float)((i >> 1) & 1)),
                                     mix_(1.0f - alpha.z, alpha.z, (float)((i >> 2) & 1)));
                         weight *= tri.x * tri.y * tri.z;
+                        const float irr_min = 0.5f / (float)pr.ires, irr_max = 1.0f - irr_min;
+                        f2 rid = ray_dir_to_ray_id(N);
+                        rid = F2(clamp_(rid.x, irr_min, irr_max), clamp_(rid.y, irr_min, irr_max));
                         f2 base = probe_id_to_coord(pr, grid_to_probe_id(pr, q));
-                        f3 tx = atlas_sample(pr.irr, pr.fmt, pr.pcx, pr.pcy, pr.ires, base.x + rid.x / (float)pr.pcx, base.y + rid.y / (float)pr.pcy, u8_tab);
+#ifdef MDH_ABL_NO_TAPS
+                        f3 tx = F3(base.x, base.y, rid.x);
+#else
+                        f3 tx = atlas_sample(pr.irr, pr.fmt, pr.pcx, pr.pcy, pr.ires, pr.ishift, base.x + rid.x / (float)pr.pcx, base.y + rid.y / (float)pr.pcy, u8_tab);
+#endif
                         acc = acc + sqrt3(tx) * weight;
                         accw += weight;
-                     } else { // render_probes.glsl:170-183
-                        float weight = dot(u, -N);
+                     } else { // render_probes.glsl:170-183; probe_to_spec = -vd
+                        float weight = dot(-vd, -N);
                         weight *= vis;
-                        if (weight > accw) { accw = weight; best_q = q; best_pts = u; }
+                        if (weight > accw) { accw = weight; best_q = q.x | (q.y << 10) | (q.z << 20); acc = -vd; }
                      }
                   }
                   if (ctx == 0) {
                      // render_probes.glsl:65-66 (0/0 fixed as 0)
+                     f3 irr = F3(0.0f, 0.0f, 0.0f);
                      if (accw != 0.0f) { irr = acc / accw; irr = irr * irr; }
+                     park_store3(pk, 12, irr);
                      shaded = true;
                      // the reflection ray of render_probes.glsl:262-275 finds the next point
-                     active = cfg.indirect_specular && m.roughness < 0.75f;
+                     active = cfg.indirect_specular && tab_float((sc.mat_slot + 2 * pm + 1) * 4) < 0.75f;
+#ifdef MDH_ABL_NO_REFLECT
+                     active = false;
+#endif
                      ro = from_off;
-                     rd = reflect(dir, N);
+                     rd = reflect(rd, N);
                   } else { // render_probes.glsl:186-208
-                     f2 base = probe_id_to_coord(pr, grid_to_probe_id(pr, best_q));
+                     i3 bq;
+                     bq.x = best_q & 1023; bq.y = (best_q >> 10) & 1023; bq.z = (best_q >> 20) & 1023;
+                     f2 base = probe_id_to_coord(pr, grid_to_probe_id(pr, bq));
                      const float rmin = 0.5f / (float)pr.rres, rmax = 1.0f - rmin;
-                     f2 brid = ray_dir_to_ray_id(best_pts);
+                     f2 brid = ray_dir_to_ray_id(acc);
                      brid = F2(clamp_(brid.x, rmin, rmax), clamp_(brid.y, rmin, rmax));
-                     f3 radiance = atlas_sample(pr.rad, pr.fmt, pr.pcx, pr.pcy, pr.rres, base.x + brid.x / (float)pr.pcx, base.y + brid.y / (float)pr.pcy, u8_tab);
-                     specular_col = radiance + Lo;
+                     f3 radiance = atlas_sample(pr.rad, pr.fmt, pr.pcx, pr.pcy, pr.rres, pr.rshift, base.x + brid.x / (float)pr.pcx, base.y + brid.y / (float)pr.pcy, u8_tab);
+                     specular_col = radiance + specular_col;
                   }
                }
             }
          }
       }
    }
-   if (shaded) { // render_probes.glsl:277-285 and lighting.glsl:51-69
-      if (MODE == 0) {
-         Material m = get_material(sc, mat_id);
-         const f3 specular_dir = reflect(dir, normal);
-         direct = direct + compute_indirect_lighting(irr, specular_col, -dir, normal, specular_dir, m.albedo, m.metallic, m.roughness);
-      }
-      float ao = 1.0f;
-      if (cfg.ao_steps > 0) {
-         float ao_sum = 0.0f, max_ao_sum = 0.0f, factor = 1.0f;
-#pragma unroll 1
-         for (int i = 0; i < cfg.ao_steps; ++i) {
-            f3 p = pos + (normal * (float)(i + 1)) * 0.1f;
-            ao_sum += factor * sdf<PART>(sc, p);
-            max_ao_sum += factor * (float)(i + 1) * 0.1f;
-            factor = factor * 0.5f;
+   // ---- everything parked comes back for the combine
+   const f3 dir = park_load3(pk, 6);
+   f3 result;
+   pos_out = F3(0.0f, 0.0f, 0.0f);
+   if (!hit) { // render_probes.glsl:287
+      float s = dir.y * 0.7f;
+      result = F3(0.30f - s, 0.36f - s, 0.60f - s);
+      if (!lane_valid) result = F3(0.0f, 0.0f, 0.0f);
+   } else {
+      const f3 pos = park_load3(pk, 0), normal = park_load3(pk, 3);
+      pos_out = pos;
+      if (MODE == 1) {
+         result = normal * 0.5f + F3s(0.5f);
+      } else { // render_probes.glsl:277-285 and lighting.glsl:51-69
+         (void)shaded;
+         f3 direct = park_load3(pk, 9);
+         if (MODE == 0) {
+            const f3 irr = park_load3(pk, 12);
+            Material m = get_material(sc, mat_id);
+            const f3 specular_dir = reflect(dir, normal);
+            direct = direct + compute_indirect_lighting(irr, specular_col, -dir, normal, specular_dir, m.albedo, m.metallic, m.roughness);
          }
-         ao = 0.6f + 0.4f * ao_sum / max_ao_sum;
+         float ao = 1.0f;
+         if (cfg.ao_steps > 0) {
+            float ao_sum = 0.0f, max_ao_sum = 0.0f, factor = 1.0f;
+#pragma unroll 1
+            for (int i = 0; i < cfg.ao_steps; ++i) {
+               f3 p = pos + (normal * (float)(i + 1)) * 0.1f;
+               ao_sum += factor * sdf<PART>(sc, p);
+               max_ao_sum += factor * (float)(i + 1) * 0.1f;
+               factor = factor * 0.5f;
+            }
+            ao = 0.6f + 0.4f * ao_sum / max_ao_sum;
+         }
+         result = direct * ao;
       }
-      result = direct * ao;
    }
    return result;
 }
