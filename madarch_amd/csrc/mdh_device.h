@@ -171,10 +171,65 @@ MDH_DEV f3 normalize(f3 a) { return a / length(a); } // support/math_utils.ads:8
 MDH_DEV f3 cross(f3 a, f3 b) { return F3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
 MDH_DEV f3 reflect(f3 i, f3 n) { return i - n * (2.0f * dot(n, i)); }
 
-// transcendentals: correctly rounded fp32 through one fp64 evaluation
-MDH_DEV float exp_(float x) { return (float)exp((double)x); }
-MDH_DEV float acos_(float x) { return (float)acos((double)x); }
-MDH_DEV float pow_(float x, float y) { return (float)pow((double)x, (double)y); }
+// Transcendentals: explicit fp32 algorithms, operation for operation what the oracle fixes in
+// oracle/orc_math.h (no fp64, no v_exp/v_log: those have no bit-identical CPU counterpart).
+// acos: Abramowitz & Stegun 4.4.46
+MDH_DEV float acos_(float x)
+{
+   float ax = __builtin_fabsf(x);
+   float p = -0.0012624911f;
+   p = p * ax + 0.0066700901f;
+   p = p * ax + -0.0170881256f;
+   p = p * ax + 0.0308918810f;
+   p = p * ax + -0.0501743046f;
+   p = p * ax + 0.0889789874f;
+   p = p * ax + -0.2145988016f;
+   p = p * ax + 1.5707963050f;
+   float r = sqrt_(1.0f - ax) * p;
+   return x < 0.0f ? 3.14159265358979f - r : r;
+}
+MDH_DEV float exp2_(float z)
+{
+   if (z != z) return z;
+   if (z > 128.0f) return __builtin_inff();
+   if (z < -126.0f) return 0.0f;
+   float n = __builtin_rintf(z);
+   float u = (z - n) * 0.693147182464599609375f;
+   float p = 1.0f / 5040.0f;
+   p = p * u + 1.0f / 720.0f;
+   p = p * u + 1.0f / 120.0f;
+   p = p * u + 1.0f / 24.0f;
+   p = p * u + 1.0f / 6.0f;
+   p = p * u + 0.5f;
+   p = p * u + 1.0f;
+   p = p * u + 1.0f;
+   return p * __int_as_float(((int)n + 127) << 23);
+}
+MDH_DEV float log2_(float x)
+{
+   int e = 0;
+   if (x < 1.17549435e-38f) { x = x * 16777216.0f; e = -24; }
+   unsigned b = (unsigned)__float_as_int(x);
+   e += (int)((b >> 23) & 255u) - 127;
+   float m = __int_as_float((int)((b & 0x007fffffu) | 0x3f800000u));
+   if (m > 1.41421356f) { m = m * 0.5f; e += 1; }
+   float s = (m - 1.0f) / (m + 1.0f);
+   float s2 = s * s;
+   float p = 1.0f / 9.0f;
+   p = p * s2 + 1.0f / 7.0f;
+   p = p * s2 + 1.0f / 5.0f;
+   p = p * s2 + 1.0f / 3.0f;
+   p = p * s2 + 1.0f;
+   return (float)e + ((2.0f * s) * p) * 1.44269502162933349609375f;
+}
+MDH_DEV float exp_(float x) { return exp2_(x * 1.44269502162933349609375f); }
+MDH_DEV float pow_(float x, float y)
+{
+   if (x != x || x < 0.0f) return __builtin_nanf("");
+   if (x == 0.0f) return 0.0f;
+   if (x > 3.40282347e+38f) return x;
+   return exp2_(y * log2_(x));
+}
 MDH_DEV float pow5_(float x) { float x2 = x * x; return (x2 * x2) * x; }                 // cook_torrance_brdf.glsl:2
 MDH_DEV float pow8_(float x) { float x2 = x * x; float x4 = x2 * x2; return x4 * x4; } // spot_lights.adb:18
 MDH_DEV float pow1_5_(float x) { return x * sqrt_(x); }                        // volumetrics.glsl:25-28

@@ -1582,3 +1582,7 @@ float orc_exprs_sdf(int32_t type, const float *a, const float *b, const float *c
    orc_exprs_set_ada_div(1);
    return d;
 }
+/* the fp32 transcendental algorithms of orc_math.h, for the accuracy tests */
+float orc_acos(float x) { return acos_(x); }
+float orc_exp(float x) { return exp_(x); }
+float orc_pow(float x, float y) { return pow_(x, y); }

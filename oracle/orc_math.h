@@ -76,22 +76,86 @@ ORC_INLINE v3 cross(v3 a, v3 b)
 /* reflect(I,N) = I - 2 dot(N,I) N (GLSL 4.30 8.5) */
 ORC_INLINE v3 reflect(v3 i, v3 n) { return sub(i, scale(n, 2.0f * dot(n, i))); }
 
-/* Transcendentals.  GLSL gives them implementation-defined precision; the
- * oracle fixes them as the correctly rounded fp32 value, obtained by
- * evaluating in fp64 and rounding once (the kernels do the same through the
- * fp64 ocml functions).  Small literal integer powers are fixed as repeated
- * multiplication (below). */
-ORC_INLINE float exp_(float x) { return (float)exp((double)x); }
-ORC_INLINE float acos_(float x) { return (float)acos((double)x); }
-ORC_INLINE float pow_(float x, float y) { return (float)pow((double)x, (double)y); }
+ORC_INLINE float f_of_bits(uint32_t u) { union { uint32_t u; float f; } c; c.u = u; return c.f; }
+ORC_INLINE uint32_t bits_of_f(float f) { union { uint32_t u; float f; } c; c.f = f; return c.u; }
+
+/* Transcendentals.  GLSL gives acos / exp / pow implementation-defined precision and the
+ * hardware approximations of the GPU (v_exp_f32, v_log_f32) have no bit-identical CPU
+ * counterpart, so the oracle FIXES them as the explicit fp32 algorithms below (plain mul/add
+ * in the order written, no fma); the HIP kernels run the same operation sequences.  Accuracy
+ * against libm (tests/test_oracle_pins.py): acos abs error < 5e-7, exp and x^0.4545 within 1.2e-6
+ * relative -- two orders below the 1e-4 parity tolerance.  Small literal integer
+ * powers are repeated multiplication. */
+
+/* acos(x) = sqrt(1 - |x|) * P7(|x|), Abramowitz & Stegun 4.4.46 (|error| <= 2e-8), mirrored
+ * for x < 0 */
+ORC_INLINE float acos_(float x)
+{
+   float ax = fabsf(x);
+   float p = -0.0012624911f;
+   p = p * ax + 0.0066700901f;
+   p = p * ax + -0.0170881256f;
+   p = p * ax + 0.0308918810f;
+   p = p * ax + -0.0501743046f;
+   p = p * ax + 0.0889789874f;
+   p = p * ax + -0.2145988016f;
+   p = p * ax + 1.5707963050f;
+   float r = sqrtf(1.0f - ax) * p;
+   return x < 0.0f ? 3.14159265358979f - r : r;
+}
+/* 2^z: n = rint(z), 2^(z - n) = exp(u) with u = (z - n) ln2 in [-0.347, 0.347] by its Taylor
+ * polynomial of degree 7 (truncation < 6e-9), scaled by 2^n through the exponent field */
+ORC_INLINE float exp2_(float z)
+{
+   if (z != z) return z;
+   if (z > 128.0f) return INFINITY;
+   if (z < -126.0f) return 0.0f; /* results below the normal range are flushed */
+   float n = rintf(z);
+   float u = (z - n) * 0.693147182464599609375f;
+   float p = 1.0f / 5040.0f;
+   p = p * u + 1.0f / 720.0f;
+   p = p * u + 1.0f / 120.0f;
+   p = p * u + 1.0f / 24.0f;
+   p = p * u + 1.0f / 6.0f;
+   p = p * u + 0.5f;
+   p = p * u + 1.0f;
+   p = p * u + 1.0f;
+   return p * f_of_bits((uint32_t)((int32_t)n + 127) << 23);
+}
+/* log2(x), x > 0: x = m 2^e with m in [sqrt(1/2), sqrt(2)); ln m = 2 atanh(s), s = (m-1)/(m+1),
+ * by the odd series up to s^9 (|s| <= 0.172, truncation < 2e-9 relative) */
+ORC_INLINE float log2_(float x)
+{
+   int32_t e = 0;
+   if (x < 1.17549435e-38f) { x = x * 16777216.0f; e = -24; }
+   uint32_t b = bits_of_f(x);
+   e += (int32_t)((b >> 23) & 255u) - 127;
+   float m = f_of_bits((b & 0x007fffffu) | 0x3f800000u);
+   if (m > 1.41421356f) { m = m * 0.5f; e += 1; }
+   float s = (m - 1.0f) / (m + 1.0f);
+   float s2 = s * s;
+   float p = 1.0f / 9.0f;
+   p = p * s2 + 1.0f / 7.0f;
+   p = p * s2 + 1.0f / 5.0f;
+   p = p * s2 + 1.0f / 3.0f;
+   p = p * s2 + 1.0f;
+   return (float)e + ((2.0f * s) * p) * 1.44269502162933349609375f;
+}
+ORC_INLINE float exp_(float x) { return exp2_(x * 1.44269502162933349609375f); }
+/* pow(x, y) for the tonemap (y = 0.4545, draw_screen.glsl:29): 2^(y log2 x); x < 0 is NaN as in
+ * GLSL, 0 gives 0 */
+ORC_INLINE float pow_(float x, float y)
+{
+   if (x != x || x < 0.0f) return NAN;
+   if (x == 0.0f) return 0.0f;
+   if (x > 3.40282347e+38f) return x;
+   return exp2_(y * log2_(x));
+}
 /* pow(x, 5.0) of fresnel_schlick (cook_torrance_brdf.glsl:2) */
 ORC_INLINE float pow5_(float x) { float x2 = x * x; return (x2 * x2) * x; }
 /* pow(x, 8.0) of the spot light (madarch-lights-spot_lights.adb:18) */
 ORC_INLINE float pow8_(float x) { float x2 = x * x; float x4 = x2 * x2; return x4 * x4; }
 /* pow(x, 1.5) of henvey_greenstein_phase (volumetrics.glsl:25-28) */
 ORC_INLINE float pow1_5_(float x) { return x * sqrtf(x); }
-
-ORC_INLINE float f_of_bits(uint32_t u) { union { uint32_t u; float f; } c; c.u = u; return c.f; }
-ORC_INLINE uint32_t bits_of_f(float f) { union { uint32_t u; float f; } c; c.f = f; return c.u; }
 
 #endif

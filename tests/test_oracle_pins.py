@@ -228,3 +228,27 @@ def test_partitioning_lookup_agrees_with_full_scan(orc):
         assert near.sum() > 50
         assert np.array_equal(d_full[near], d_part[near])
         assert np.array_equal(i_full[near], i_part[near])
+
+
+def test_transcendental_algorithms_against_libm(orc):
+    """acos / exp / pow are fixed as explicit fp32 algorithms (oracle/orc_math.h) that the HIP
+    kernels repeat operation for operation; here they are held against libm in float64."""
+    lib = orc.lib
+    for f in (lib.orc_acos, lib.orc_exp, lib.orc_pow):
+        f.restype = C.c_float
+    lib.orc_acos.argtypes = [C.c_float]
+    lib.orc_exp.argtypes = [C.c_float]
+    lib.orc_pow.argtypes = [C.c_float, C.c_float]
+    rng = np.random.RandomState(9)
+    for x in np.concatenate([rng.uniform(-1, 1, 2000), [0.0, 1.0, -1.0, 0.5, 1e-7]]).astype(np.float32):
+        assert abs(lib.orc_acos(x) - np.arccos(np.float64(x))) < 5e-7
+    for x in np.concatenate([rng.uniform(-12, 2, 2000), [0.0, -0.1, -2.0]]).astype(np.float32):
+        want = np.exp(np.float64(x))
+        assert abs(lib.orc_exp(x) - want) <= 1.2e-6 * want
+    # the tonemap: (c / (c + 1)) ^ 0.4545 on (0, 1)  (draw_screen.glsl:29)
+    for x in np.concatenate([rng.uniform(0, 1, 2000), 10.0 ** rng.uniform(-8, 0, 500), [1.0]]).astype(np.float32):
+        want = np.float64(x) ** np.float64(np.float32(0.4545))
+        assert abs(lib.orc_pow(x, np.float32(0.4545)) - want) <= 2e-6 * want
+    assert lib.orc_pow(0.0, 0.4545) == 0.0
+    assert np.isnan(lib.orc_pow(-0.5, 0.4545)) and np.isnan(lib.orc_pow(float("nan"), 0.4545))
+    assert lib.orc_exp(0.0) == 1.0 and lib.orc_acos(1.0) == 0.0
