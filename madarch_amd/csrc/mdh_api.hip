@@ -610,6 +610,10 @@ static int run_pass(mdh_renderer *r, int pass)
    switch (pass) {
    case MDH_PASS_RADIANCE: {
       long n = (long)(pr.probe_end - pr.probe_begin) * pr.rres * pr.rres;
+      {
+         const int G = MDH_RAD_PROBES_PER_WAVE, T = (G == 1) ? 8 : (G == 4) ? 4 : (G == 16) ? 2 : 1;
+         if (pr.rres % T == 0) n = (long)((pr.probe_end - pr.probe_begin + G - 1) / G) * G * pr.rres * pr.rres;
+      }
       if (n > 0) {
          int blocks = (int)((n + MDH_BLOCK - 1) / MDH_BLOCK);
          if (part) hipLaunchKernelGGL(k_radiance<true>, dim3(blocks), dim3(MDH_BLOCK), lds_bytes_march(r), r->stream, r->ks, pr);

@@ -478,21 +478,6 @@ template <bool PART> MDH_DEV float sdf_info(const KScene &sc, f3 x, int &index)
 }
 
 // ------------------------------------------------------------------------- raymarching
-// glsl/raymarching.glsl:4-23
-template <bool PART> MDH_DEV float softshadows(const KScene &sc, f3 from, f3 dir, float min_dist, float max_dist, float k)
-{
-   float res = 1.0f, prev_dist = 1e20f;
-   for (float total = min_dist; total < max_dist;) {
-      float dist = sdf<PART>(sc, from + dir * total);
-      if (dist < MDH_EPS) return 0.0f;
-      float y = dist * dist / (2.0f * prev_dist);
-      float d = sqrt_(dist * dist - y * y);
-      res = min_(res, k * d / max_(0.0f, total - y));
-      prev_dist = dist;
-      total += dist;
-   }
-   return res;
-}
 // glsl/raymarching.glsl:25-37
 template <bool PART> MDH_DEV bool raycast(const KScene &sc, f3 from, f3 dir, int &index, f3 &coll, float &t_out, int &steps)
 {
@@ -591,26 +576,6 @@ MDH_DEV void cook_torrance(f3 N, f3 V, f3 L, float NdotL, f3 albedo, float metal
    kD = F3(1.0f - F.x, 1.0f - F.y, 1.0f - F.z) * (1.0f - metallic);
    kS = min3s(numerator / dm, 1.0f);
 }
-// glsl/lighting.glsl:1-40
-template <bool PART>
-MDH_DEV f3 compute_direct_lighting(const KScene &sc, f3 pos, f3 normal, f3 dir, f3 albedo, float metallic, float roughness, bool direct_specular)
-{
-   f3 N = normal, V = -dir, Lo = F3(0.0f, 0.0f, 0.0f);
-   for (int i = 0; i < sc.total_lights; ++i) {
-      f3 L;
-      float L_dist;
-      f3 radiance = sample_light(sc, i, pos, L, L_dist);
-      float NdotL = max_(dot(N, L), 0.0f);
-      f3 kD, kS;
-      cook_torrance(N, V, L, NdotL, albedo, metallic, roughness, kD, kS);
-      float shadows = 0.0f;
-      if (NdotL > MDH_EPS) shadows = softshadows<PART>(sc, pos + (normal * MDH_MIN_STEP) * 5.0f, L, 0.0f, L_dist, 64.0f);
-      if (!direct_specular) kS = F3(0.0f, 0.0f, 0.0f);
-      f3 brdf = (kD * albedo) / MDH_PI + kS;
-      Lo = Lo + ((brdf * radiance) * NdotL) * shadows;
-   }
-   return Lo;
-}
 // glsl/lighting.glsl:42-49
 MDH_DEV f3 compute_indirect_lighting(f3 irradiance, f3 radiance, f3 V, f3 N, f3 L, f3 albedo, float metallic, float roughness)
 {
@@ -619,21 +584,6 @@ MDH_DEV f3 compute_indirect_lighting(f3 irradiance, f3 radiance, f3 V, f3 N, f3 
    cook_torrance(N, V, L, NdotL, albedo, metallic, roughness, kD, kS);
    return (kD * irradiance) / MDH_PI + (kS * radiance) * NdotL;
 }
-// glsl/lighting.glsl:51-69
-template <bool PART> MDH_DEV float compute_ambient_occlusion(const KScene &sc, f3 pos, f3 normal, int steps)
-{
-   if (steps <= 0) return 1.0f;
-   const float ao_step_size = 0.1f;
-   float ao_sum = 0.0f, max_ao_sum = 0.0f, factor = 1.0f;
-   for (int i = 0; i < steps; ++i) {
-      f3 p = pos + (normal * (float)(i + 1)) * ao_step_size;
-      ao_sum += factor * sdf<PART>(sc, p);
-      max_ao_sum += factor * (float)(i + 1) * ao_step_size;
-      factor = factor * 0.5f;
-   }
-   return 0.6f + 0.4f * ao_sum / max_ao_sum;
-}
-
 // ------------------------------------------------------------------------- probe utils
 // glsl/probe_utils.glsl:19-56
 MDH_DEV i3 probe_id_to_grid(const KProbes &pr, int id)
@@ -745,78 +695,6 @@ MDH_DEV f3 atlas_sample(const void *base, int fmt, int pcx, int pcy, int res, in
    return ((a * w00 + b * w10) + c * w01) + d * w11;
 }
 
-// ------------------------------------------------------------------ probes: sampling
-// glsl/render_probes.glsl:6-69
-template <bool PART> MDH_DEV f3 sample_irradiance(const KScene &sc, const KProbes &pr, f3 pos, f3 normal)
-{
-   i3 gp = world_to_grid(pr, pos);
-   f3 irradiance = F3(0.0f, 0.0f, 0.0f);
-   float total_weight = 0.0f;
-   f3 alpha = pos / F3(pr.sx, pr.sy, pr.sz) - F3((float)gp.x, (float)gp.y, (float)gp.z);
-   const float irr_min = 0.5f / (float)pr.ires, irr_max = 1.0f - irr_min;
-   f2 rid = ray_dir_to_ray_id(normal);
-   rid = F2(clamp_(rid.x, irr_min, irr_max), clamp_(rid.y, irr_min, irr_max));
-   const f3 from = pos + (normal * MDH_MIN_STEP) * 5.0f;
-   for (int i = 0; i < 8; ++i) {
-      const int ox = i & 1, oy = (i >> 1) & 1, oz = (i >> 2) & 1;
-      i3 q;
-      q.x = iclamp_(gp.x + ox, 0, pr.gx - 1); q.y = iclamp_(gp.y + oy, 0, pr.gy - 1); q.z = iclamp_(gp.z + oz, 0, pr.gz - 1);
-      f3 hit_to_probe = grid_to_world(pr, q) - pos;
-      float probe_distance = length(hit_to_probe);
-      f3 dir_to_probe = hit_to_probe / probe_distance;
-      float weight = 1.0f;
-      float angle = (dot(dir_to_probe, normal) + 1.0f) * 0.5f;
-      weight *= angle * angle + 0.2f;
-      weight *= raycast_visibility<PART>(sc, from, dir_to_probe, probe_distance - MDH_MIN_STEP * 5.0f);
-      const float crush = 0.2f;
-      if (weight < crush) weight *= weight * weight * (1.0f / (crush * crush));
-      f3 tri = F3(mix_(1.0f - alpha.x, alpha.x, (float)ox), mix_(1.0f - alpha.y, alpha.y, (float)oy), mix_(1.0f - alpha.z, alpha.z, (float)oz));
-      weight *= tri.x * tri.y * tri.z;
-      f2 base = probe_id_to_coord(pr, grid_to_probe_id(pr, q));
-      f3 tx = atlas_sample(pr.irr, pr.fmt, pr.pcx, pr.pcy, pr.ires, pr.ishift, base.x + rid.x / (float)pr.pcx, base.y + rid.y / (float)pr.pcy, sc.u8_slot * 4);
-      irradiance = irradiance + sqrt3(tx) * weight;
-      total_weight += weight;
-   }
-   if (total_weight == 0.0f) return F3(0.0f, 0.0f, 0.0f); // render_probes.glsl:65 is 0/0 here
-   irradiance = irradiance / total_weight;
-   return irradiance * irradiance;
-}
-// glsl/render_probes.glsl:138-209, M_COMPUTE_INDIRECT_SPECULAR == 2 with M_ADD_INDIRECT_SPECULAR == 1
-template <bool PART> MDH_DEV f3 sample_radiance_no_specular(const KScene &sc, const KProbes &pr, f3 pos, f3 normal, f3 dir)
-{
-   int prim_index = -1, steps;
-   float t;
-   f3 spec_pos;
-   if (!raycast<PART>(sc, pos + (normal * MDH_MIN_STEP) * 5.0f, dir, prim_index, spec_pos, t, steps)) return F3(0.0f, 0.0f, 0.0f);
-   f3 spec_normal;
-   int spec_mat;
-   primitive_info(sc, prim_index, spec_pos, spec_normal, spec_mat);
-   i3 gp = world_to_grid(pr, spec_pos);
-   float max_weight = -2.0f;
-   i3 best_q;
-   best_q.x = 0; best_q.y = 0; best_q.z = 0;
-   f3 best_pts = F3(0.0f, 0.0f, 1.0f);
-   const f3 from = spec_pos + (spec_normal * MDH_MIN_STEP) * 5.0f;
-   for (int i = 0; i < 8; ++i) {
-      i3 q;
-      q.x = iclamp_(gp.x + (i & 1), 0, pr.gx - 1); q.y = iclamp_(gp.y + ((i >> 1) & 1), 0, pr.gy - 1); q.z = iclamp_(gp.z + ((i >> 2) & 1), 0, pr.gz - 1);
-      f3 probe_to_spec = spec_pos - grid_to_world(pr, q);
-      float distance = length(probe_to_spec);
-      probe_to_spec = probe_to_spec / distance;
-      float weight = dot(probe_to_spec, -spec_normal);
-      weight *= raycast_visibility<PART>(sc, from, -probe_to_spec, distance - MDH_MIN_STEP * 5.0f);
-      if (weight > max_weight) { max_weight = weight; best_q = q; best_pts = probe_to_spec; }
-   }
-   f2 base = probe_id_to_coord(pr, grid_to_probe_id(pr, best_q));
-   const float rmin = 0.5f / (float)pr.rres, rmax = 1.0f - rmin;
-   f2 rid = ray_dir_to_ray_id(best_pts);
-   rid = F2(clamp_(rid.x, rmin, rmax), clamp_(rid.y, rmin, rmax));
-   // textureLod(.., 1.0) on a single-level texture samples level 0
-   f3 radiance = atlas_sample(pr.rad, pr.fmt, pr.pcx, pr.pcy, pr.rres, pr.rshift, base.x + rid.x / (float)pr.pcx, base.y + rid.y / (float)pr.pcy, sc.u8_slot * 4);
-   Material m = get_material(sc, spec_mat);
-   return radiance + compute_direct_lighting<PART>(sc, spec_pos, spec_normal, dir, F3(0.0f, 0.0f, 0.0f), m.metallic, m.roughness, true);
-}
-
 // ------------------------------------------------------------------------ volumetrics
 #define MDH_TAU 0.1f // glsl/volumetrics.glsl:12
 // glsl/volumetrics.glsl:21-30
@@ -859,51 +737,7 @@ MDH_DEV f3 render_volumetrics(const KScene &sc, const KVolumetrics &vol, f3 L, f
    return L * exp_(-len * MDH_TAU) + fog;
 }
 
-// ----------------------------------------------------------------- pixel_color_probes
-struct PassCfg {
-   bool direct_specular;   // M_COMPUTE_DIRECT_SPECULAR
-   bool indirect_specular; // M_COMPUTE_INDIRECT_SPECULAR == 2
-   int ao_steps;           // M_AMBIENT_OCCLUSION_STEPS
-   bool volumetrics;       // M_RENDER_VOLUMETRICS
-};
 struct PrimaryHit { int index; float t; int steps; };
-
-// glsl/render_probes.glsl:246-291.  MODE: 0 reference, 1 primary ray only, 2 direct + AO
-template <bool PART, int MODE>
-MDH_DEV f3 pixel_color_probes(const KScene &sc, const KProbes &pr, const KVolumetrics &vol, const PassCfg cfg, f3 from, f3 dir, f2 frag_pos, PrimaryHit &ph)
-{
-   int prim_index = -1, steps = 0;
-   float t = 0.0f;
-   f3 pos = F3(0.0f, 0.0f, 0.0f), result;
-   const bool hit = raycast<PART>(sc, from, dir, prim_index, pos, t, steps);
-   ph.index = hit ? prim_index : -1;
-   ph.t = hit ? t : 0.0f;
-   ph.steps = steps;
-   if (hit) {
-      int material_id;
-      f3 normal;
-      primitive_info(sc, prim_index, pos, normal, material_id);
-      if (MODE == 1) return normal * 0.5f + F3s(0.5f);
-      Material m = get_material(sc, material_id);
-      f3 direct = compute_direct_lighting<PART>(sc, pos, normal, dir, m.albedo, m.metallic, m.roughness, cfg.direct_specular);
-      if (MODE == 2) {
-         result = direct * compute_ambient_occlusion<PART>(sc, pos, normal, cfg.ao_steps);
-      } else {
-         f3 irradiance = sample_irradiance<PART>(sc, pr, pos, normal);
-         f3 specular_col = F3(0.0f, 0.0f, 0.0f);
-         f3 specular_dir = reflect(dir, normal);
-         if (cfg.indirect_specular && m.roughness < 0.75f) specular_col = sample_radiance_no_specular<PART>(sc, pr, pos, normal, specular_dir);
-         f3 indirect = compute_indirect_lighting(irradiance, specular_col, -dir, normal, specular_dir, m.albedo, m.metallic, m.roughness);
-         float ao = compute_ambient_occlusion<PART>(sc, pos, normal, cfg.ao_steps);
-         result = (direct + indirect) * ao;
-      }
-   } else {
-      float s = dir.y * 0.7f;
-      result = F3(0.30f - s, 0.36f - s, 0.60f - s);
-   }
-   if (MODE == 0 && cfg.volumetrics) result = render_volumetrics(sc, vol, result, from, pos, hit, frag_pos);
-   return result;
-}
 
 // camera ray (glsl/draw_screen.glsl:21-24)
 MDH_DEV f3 mat_mul(const float *m, f3 v)

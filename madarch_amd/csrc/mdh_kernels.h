@@ -9,9 +9,9 @@
 #define MDH_BLOCK 256 // 4 wavefronts; every wavefront owns one 8x8 tile
 
 #include "mdh_march.h"
-// which formulation of the pixel program the screen / radiance kernels run (mdh_march.h)
-#ifndef MDH_SHADE
 #define MDH_SHADE shade_structured
+#ifndef MDH_RAD_PROBES_PER_WAVE
+#define MDH_RAD_PROBES_PER_WAVE 64 // 1, 4, 16 or 64 (measured on MI355X: see DESIGN.md)
 #endif
 #ifndef MDH_WAVES_PER_SIMD
 #define MDH_WAVES_PER_SIMD 6 // register budget of the march kernels (measured: 6 > 5 > 8 > 4 > 3 > 2 waves/SIMD)
@@ -73,19 +73,27 @@ template <bool PART> __global__ __launch_bounds__(MDH_BLOCK, MDH_WAVES_PER_SIMD)
    stage_table(sc);
    const int per_probe = pr.rres * pr.rres;
    const long lin = (long)blockIdx.x * MDH_BLOCK + threadIdx.x;
-   const int probe_raw = pr.probe_begin + (int)(lin / per_probe);
-   const bool valid = probe_raw < pr.probe_end;
-   const int probe = valid ? probe_raw : pr.probe_begin;
-   const int rem = (int)(lin % per_probe);
-   int x, y;
-   if ((pr.rres & 7) == 0) {
-      const int tile = rem >> 6, l = rem & 63, tpr = pr.rres >> 3;
-      x = (tile % tpr) * 8 + (l & 7);
-      y = (tile / tpr) * 8 + (l >> 3);
-   } else {
+   // a wavefront = a TxT texel tile (T*T = 64 / G) of the octahedral maps of G consecutive probes:
+   // G = 1 is one 8x8 tile of one probe, G = 64 the same ray direction from 64 probes
+   constexpr int G = MDH_RAD_PROBES_PER_WAVE, T = (G == 1) ? 8 : (G == 4) ? 4 : (G == 16) ? 2 : 1;
+   const int lane = (int)(lin & 63);
+   const long wave_global = lin >> 6;
+   int x, y, probe_raw;
+   if ((pr.rres % T) == 0) {
+      const int tpr = pr.rres / T, tiles = tpr * tpr;      // texel tiles per probe
+      const int group = (int)(wave_global / tiles), tile = (int)(wave_global % tiles);
+      probe_raw = pr.probe_begin + group * G + lane / (T * T);
+      const int l = lane % (T * T);
+      x = (tile % tpr) * T + (l % T);
+      y = (tile / tpr) * T + (l / T);
+   } else { // resolutions that are no multiple of the tile edge: row-major, one probe per run
+      probe_raw = pr.probe_begin + (int)(lin / per_probe);
+      const int rem = (int)(lin % per_probe);
       y = rem / pr.rres;
       x = rem - y * pr.rres;
    }
+   const bool valid = probe_raw < pr.probe_end;
+   const int probe = valid ? probe_raw : pr.probe_begin;
    const int ty = probe / pr.pcx, tx = probe - ty * pr.pcx;
    const int i = tx * pr.rres + x, j = ty * pr.rres + y; // texel of the reference's 2-D atlas image
    const f2 nc = F2((centre(i, pr.pcx * pr.rres) + 1.0f) * 0.5f, (centre(j, pr.pcy * pr.rres) + 1.0f) * 0.5f);

@@ -1,35 +1,16 @@
-// mdh_march.h -- pixel_color_probes (reference glsl/render_probes.glsl:246-291) as a
-// per-lane ray STATE MACHINE with one shared sphere-tracing loop.
+// mdh_march.h -- pixel_color_probes (reference glsl/render_probes.glsl:246-291) for gfx950.
 //
-// The GLSL runs ~20 rays per pixel one after the other, each in its own loop, so a
-// wavefront waits for the slowest lane of every single ray.  Here a lane carries the
-// state of "its" current ray plus a small shading program counter; the wavefront executes
-// ONE march loop (one SDF evaluation site), and a lane whose ray has ended does not leave
-// the loop: it waits until the ballot of ended lanes is large enough (or nobody marches
-// any more), then all ended lanes run their transition -- finish the ray's bookkeeping,
-// set up the next ray -- together and rejoin the march.  The wave only waits for the
-// slowest PIXEL (sum of its rays), not for the slowest lane of every ray, the hot loop is
-// ~1 KB of code instead of nine inlined copies, and the live state is ~60 VGPRs.
-//
-// Every ray performs exactly the arithmetic of the reference's loop for that ray, in the
-// same order, so results are bit-identical with the straight-line restatement (and the
-// CPU oracle).  Rays that need the index of the primitive they hit (primary, reflection)
-// march with the plain distance and take the index from one closest_primitive_info
-// evaluation at the hit point: same point, same arithmetic, same arg-min.
+// Two formulations were built and measured on MI355X (BASELINE config 3, 1080p):
+//  * a per-lane ray STATE MACHINE -- one shared march loop, lanes whose ray ended wait for a
+//    ballot threshold and then run their transition together (the classic persistent-ray
+//    design).  Bit-exact, but 3-4x SLOWER than the structured form at every threshold
+//    (1.4-2.4 ms radiance, 3.4-4.4 ms screen vs 0.58 / 0.97 ms): the transitions (BRDF,
+//    light sampling, atlas taps: ~40 % of the work) then run under sparse exec masks, and the
+//    machine keeps every variable of every stage live across the loop.  Removed.
+//  * the lock-step STRUCTURED form below, which is what the kernels run.
 #pragma once
 
 #include "mdh_device.h"
-
-// ended lanes start their transitions when at least this many wait (or nobody marches)
-#ifndef MDH_TRANSITION_THRESHOLD
-#define MDH_TRANSITION_THRESHOLD 16
-#endif
-
-enum { RAY_PLAIN = 0, RAY_SOFT = 1, RAY_POINT = 2 };
-enum {
-   T_PRIMARY_END = 0, T_LIGHT_BEGIN, T_LIGHT_END, T_DIRECT_END, T_PROBE_BEGIN, T_PROBE_END,
-   T_REFLECT_BEGIN, T_REFLECT_END, T_COMBINE, T_AO_BEGIN, T_AO_END, T_FINISH
-};
 
 struct MachineCfg {
    bool direct_specular;   // M_COMPUTE_DIRECT_SPECULAR
@@ -45,256 +26,6 @@ MDH_DEV i3 cage_probe(const KProbes &pr, i3 gp, int i)
    q.y = iclamp_(gp.y + ((i >> 1) & 1), 0, pr.gy - 1);
    q.z = iclamp_(gp.z + ((i >> 2) & 1), 0, pr.gz - 1);
    return q;
-}
-
-// MODE: 0 reference, 1 primary ray only, 2 direct + AO (MDH_OPT_SCREEN_MODE)
-// Returns the colour before volumetrics / tonemap; `hit`, `pos` describe the primary ray.
-template <bool PART, int MODE>
-MDH_DEV f3 shade_machine(const KScene &sc, const KProbes &pr, const MachineCfg cfg, bool lane_valid, f3 from, f3 dir,
-                         PrimaryHit &ph, bool &hit, f3 &pos)
-{
-   // ---- ray state
-   f3 ro = from, rd = dir;
-   float t = 0.0f, tmax = sc.max_dist, res = 1.0f, prev = 1e20f;
-   int kind = RAY_PLAIN;
-   bool marching = lane_valid, pending = false, ray_hit = false;
-   // ---- program state
-   int todo = T_PRIMARY_END, ctx = 0, it = 0, steps = 0;
-   f3 normal = F3(0.0f, 0.0f, 0.0f), spec_pos = F3(0.0f, 0.0f, 0.0f), spec_normal = F3(0.0f, 0.0f, 0.0f);
-   int mat_id = 0, spec_mat = 0;
-   f3 Lo = F3(0.0f, 0.0f, 0.0f), contrib = F3(0.0f, 0.0f, 0.0f), direct = F3(0.0f, 0.0f, 0.0f);
-   f3 acc = F3(0.0f, 0.0f, 0.0f), best_pts = F3(0.0f, 0.0f, 1.0f), specular_col = F3(0.0f, 0.0f, 0.0f);
-   f3 irr = F3(0.0f, 0.0f, 0.0f), spec_rad = F3(0.0f, 0.0f, 0.0f);
-   float accw = 0.0f, ao_sum = 0.0f;
-   int best_q = 0;
-   f3 result = F3(0.0f, 0.0f, 0.0f);
-   hit = false;
-   pos = F3(0.0f, 0.0f, 0.0f);
-   ph.index = -1; ph.t = 0.0f; ph.steps = 0;
-
-   for (;;) {
-      // ------------------------------------------------------------------ march: one step
-      if (marching) {
-         if (t < tmax) { // the loop condition of raymarching.glsl:8,26,40
-            const float dist = sdf<PART>(sc, ro + rd * t);
-            if (todo == T_PRIMARY_END) ++steps;
-            if (kind == RAY_POINT) {
-               res = dist;
-               marching = false; pending = true;
-            } else if (dist < MDH_EPS) {
-               ray_hit = true;
-               marching = false; pending = true;
-            } else {
-               if (kind == RAY_SOFT) { // raymarching.glsl:15-19
-                  float y = dist * dist / (2.0f * prev);
-                  float d = sqrt_(dist * dist - y * y);
-                  res = min_(res, 64.0f * d / max_(0.0f, t - y));
-                  prev = dist;
-               }
-               t += dist;
-            }
-         } else {
-            ray_hit = false;
-            marching = false; pending = true;
-         }
-      }
-      // ------------------------------------------------ ballot: who marches, who waits
-      const unsigned long long mb = __ballot(marching), pb = __ballot(pending);
-      if ((mb | pb) == 0ull) break;
-      if (mb != 0ull && __popcll(pb) < MDH_TRANSITION_THRESHOLD) continue;
-
-      // ------------------------------------------------------------------- transitions
-      while (pending) {
-         // the point being shaded: the primary hit (ctx 0) or the reflection's hit (ctx 1)
-         const f3 P = ctx ? spec_pos : pos, N = ctx ? spec_normal : normal;
-         switch (todo) {
-         case T_PRIMARY_END: {
-            hit = ray_hit;
-            ph.steps = steps;
-            if (!ray_hit) { // render_probes.glsl:287
-               float s = dir.y * 0.7f;
-               result = F3(0.30f - s, 0.36f - s, 0.60f - s);
-               todo = T_FINISH;
-               break;
-            }
-            pos = ro + rd * t;
-            int index = -1;
-            (void)sdf_info<PART>(sc, pos, index);
-            ph.index = index;
-            ph.t = t;
-            primitive_info(sc, index, pos, normal, mat_id);
-            if (MODE == 1) { result = normal * 0.5f + F3s(0.5f); todo = T_FINISH; break; }
-            ctx = 0; it = 0; Lo = F3(0.0f, 0.0f, 0.0f);
-            todo = T_LIGHT_BEGIN;
-            break;
-         }
-         case T_LIGHT_BEGIN: { // lighting.glsl:8-29 for light `it`
-            if (it >= sc.total_lights) { todo = T_DIRECT_END; break; }
-            f3 L;
-            float L_dist;
-            f3 radiance = sample_light(sc, it, P, L, L_dist);
-            float NdotL = max_(dot(N, L), 0.0f);
-            const f3 vdir = ctx ? reflect(dir, normal) : dir;
-            Material m = get_material(sc, ctx ? spec_mat : mat_id);
-            if (ctx) m.albedo = F3(0.0f, 0.0f, 0.0f); // render_probes.glsl:202-205
-            f3 kD, kS;
-            cook_torrance(N, -vdir, L, NdotL, m.albedo, m.metallic, m.roughness, kD, kS);
-            if (!ctx && !cfg.direct_specular) kS = F3(0.0f, 0.0f, 0.0f);
-            contrib = (((kD * m.albedo) / MDH_PI + kS) * radiance) * NdotL;
-            if (NdotL > MDH_EPS) { // soft shadow ray, raymarching.glsl:4-23
-               ro = P + (N * MDH_MIN_STEP) * 5.0f; rd = L; t = 0.0f; tmax = L_dist; res = 1.0f; prev = 1e20f;
-               kind = RAY_SOFT; ray_hit = false;
-               todo = T_LIGHT_END;
-               pending = false; marching = true;
-            } else {
-               Lo = Lo + contrib * 0.0f;
-               ++it;
-            }
-            break;
-         }
-         case T_LIGHT_END: { // lighting.glsl:36
-            const float shadows = ray_hit ? 0.0f : res;
-            Lo = Lo + contrib * shadows;
-            ++it;
-            todo = T_LIGHT_BEGIN;
-            break;
-         }
-         case T_DIRECT_END: {
-            if (ctx == 0) {
-               direct = Lo;
-               if (MODE == 2) { it = 0; ao_sum = 0.0f; todo = T_AO_BEGIN; break; }
-               it = 0; acc = F3(0.0f, 0.0f, 0.0f); accw = 0.0f;
-               todo = T_PROBE_BEGIN;
-            } else { // render_probes.glsl:199-206
-               specular_col = spec_rad + Lo;
-               todo = T_COMBINE;
-            }
-            break;
-         }
-         case T_PROBE_BEGIN: { // one visibility ray towards cage probe `it`
-            const i3 q = cage_probe(pr, world_to_grid(pr, P), it);
-            const f3 h = ctx ? (P - grid_to_world(pr, q)) : (grid_to_world(pr, q) - P);
-            const float dist = length(h);
-            const f3 u = h / dist; // ctx 0: dir_to_probe; ctx 1: probe_to_spec
-            ro = P + (N * MDH_MIN_STEP) * 5.0f; rd = ctx ? -u : u; t = 0.0f; tmax = dist - MDH_MIN_STEP * 5.0f;
-            kind = RAY_PLAIN; ray_hit = false;
-            todo = T_PROBE_END;
-            pending = false; marching = true;
-            break;
-         }
-         case T_PROBE_END: {
-            const float vis = ray_hit ? 0.0f : 1.0f; // raymarching.glsl:53-56
-            const i3 gp = world_to_grid(pr, P);
-            const i3 q = cage_probe(pr, gp, it);
-            if (ctx == 0) { // render_probes.glsl:26-62
-               float angle = (dot(rd, N) + 1.0f) * 0.5f;
-               float weight = angle * angle + 0.2f;
-               weight *= vis;
-               const float crush = 0.2f;
-               if (weight < crush) weight *= weight * weight * (1.0f / (crush * crush));
-               f3 alpha = P / F3(pr.sx, pr.sy, pr.sz) - F3((float)gp.x, (float)gp.y, (float)gp.z);
-               f3 tri = F3(mix_(1.0f - alpha.x, alpha.x, (float)(it & 1)), mix_(1.0f - alpha.y, alpha.y, (float)((it >> 1) & 1)),
-                           mix_(1.0f - alpha.z, alpha.z, (float)((it >> 2) & 1)));
-               weight *= tri.x * tri.y * tri.z;
-               const float irr_min = 0.5f / (float)pr.ires, irr_max = 1.0f - irr_min;
-               f2 rid = ray_dir_to_ray_id(N);
-               rid = F2(clamp_(rid.x, irr_min, irr_max), clamp_(rid.y, irr_min, irr_max));
-               f2 base = probe_id_to_coord(pr, grid_to_probe_id(pr, q));
-               f3 tx = atlas_sample(pr.irr, pr.fmt, pr.pcx, pr.pcy, pr.ires, pr.ishift, base.x + rid.x / (float)pr.pcx, base.y + rid.y / (float)pr.pcy, sc.u8_slot * 4);
-               acc = acc + sqrt3(tx) * weight;
-               accw += weight;
-            } else { // render_probes.glsl:170-183
-               const f3 pts = -rd;
-               float weight = dot(pts, -N);
-               weight *= vis;
-               if (it == 0) { accw = -2.0f; best_q = 0; best_pts = F3(0.0f, 0.0f, 1.0f); }
-               if (weight > accw) { accw = weight; best_q = q.x | (q.y << 10) | (q.z << 20); best_pts = pts; }
-            }
-            ++it;
-            if (it < 8) { todo = T_PROBE_BEGIN; break; }
-            if (ctx == 0) { // render_probes.glsl:65-66 (0/0 fixed as 0)
-               if (accw == 0.0f) irr = F3(0.0f, 0.0f, 0.0f);
-               else { irr = acc / accw; irr = irr * irr; }
-               todo = T_REFLECT_BEGIN;
-            } else { // render_probes.glsl:186-197
-               i3 bq;
-               bq.x = best_q & 1023; bq.y = (best_q >> 10) & 1023; bq.z = (best_q >> 20) & 1023;
-               f2 base = probe_id_to_coord(pr, grid_to_probe_id(pr, bq));
-               const float rmin = 0.5f / (float)pr.rres, rmax = 1.0f - rmin;
-               f2 rid = ray_dir_to_ray_id(best_pts);
-               rid = F2(clamp_(rid.x, rmin, rmax), clamp_(rid.y, rmin, rmax));
-               spec_rad = atlas_sample(pr.rad, pr.fmt, pr.pcx, pr.pcy, pr.rres, pr.rshift, base.x + rid.x / (float)pr.pcx, base.y + rid.y / (float)pr.pcy, sc.u8_slot * 4);
-               it = 0; Lo = F3(0.0f, 0.0f, 0.0f);
-               todo = T_LIGHT_BEGIN;
-            }
-            break;
-         }
-         case T_REFLECT_BEGIN: { // render_probes.glsl:262-275
-            Material m = get_material(sc, mat_id);
-            if (cfg.indirect_specular && m.roughness < 0.75f) {
-               ro = pos + (normal * MDH_MIN_STEP) * 5.0f; rd = reflect(dir, normal); t = 0.0f; tmax = sc.max_dist;
-               kind = RAY_PLAIN; ray_hit = false;
-               todo = T_REFLECT_END;
-               pending = false; marching = true;
-            } else {
-               specular_col = F3(0.0f, 0.0f, 0.0f);
-               todo = T_COMBINE;
-            }
-            break;
-         }
-         case T_REFLECT_END: { // render_probes.glsl:138-150
-            if (!ray_hit) { specular_col = F3(0.0f, 0.0f, 0.0f); todo = T_COMBINE; break; }
-            spec_pos = ro + rd * t;
-            int index = -1;
-            (void)sdf_info<PART>(sc, spec_pos, index);
-            primitive_info(sc, index, spec_pos, spec_normal, spec_mat);
-            ctx = 1; it = 0;
-            todo = T_PROBE_BEGIN;
-            break;
-         }
-         case T_COMBINE: { // render_probes.glsl:277-285
-            ctx = 0;
-            Material m = get_material(sc, mat_id);
-            const f3 specular_dir = reflect(dir, normal);
-            f3 indirect = compute_indirect_lighting(irr, specular_col, -dir, normal, specular_dir, m.albedo, m.metallic, m.roughness);
-            direct = direct + indirect;
-            it = 0; ao_sum = 0.0f;
-            todo = T_AO_BEGIN;
-            break;
-         }
-         case T_AO_BEGIN: { // lighting.glsl:51-69, tap `it`
-            if (it < cfg.ao_steps) {
-               ro = pos + (normal * (float)(it + 1)) * 0.1f; rd = F3(0.0f, 0.0f, 0.0f); t = 0.0f; tmax = 1.0f;
-               kind = RAY_POINT; ray_hit = false;
-               todo = T_AO_END;
-               pending = false; marching = true;
-               break;
-            }
-            float ao = 1.0f;
-            if (cfg.ao_steps > 0) {
-               float max_ao_sum = 0.0f, factor = 1.0f;
-               for (int i = 0; i < cfg.ao_steps; ++i) { max_ao_sum += factor * (float)(i + 1) * 0.1f; factor = factor * 0.5f; }
-               ao = 0.6f + 0.4f * ao_sum / max_ao_sum;
-            }
-            result = direct * ao;
-            todo = T_FINISH;
-            break;
-         }
-         case T_AO_END: {
-            float factor = 1.0f;
-            for (int i = 0; i < it; ++i) factor = factor * 0.5f; // 1 / pow(2, it), exact
-            ao_sum += factor * res;
-            ++it;
-            todo = T_AO_BEGIN;
-            break;
-         }
-         default: // T_FINISH
-            pending = false;
-            break;
-         }
-      }
-   }
-   return result;
 }
 
 // =============================================================================================
