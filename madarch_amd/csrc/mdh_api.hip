@@ -221,6 +221,35 @@ static int commit_scene(mdh_renderer *r)
          }
       }
    }
+   // axis-aligned planes fold into six offsets; the others are repeated as "general planes"
+   // for closest_primitive (the per-kind copy above stays complete for the arg-min / normals)
+   {
+      const float inf = INFINITY;
+      for (int g = 0; g < 6; ++g) s.axis_off[g] = inf;
+      s.n_axis = 0;
+      s.gplane_slot = (int)t.size();
+      s.gplane_count = 0;
+      for (int k = 0; k < r->npk; ++k) {
+         const Kind &kd = r->pk[k];
+         if (kd.type != PK_PLANE) continue;
+         for (int i = 0; i < H[H_KCOUNT + k]; ++i) {
+            int b = kd.array_off + kd.stride * i;
+            float n[3] = {rd_f(r, b + kd.f_a), rd_f(r, b + kd.f_a + 4), rd_f(r, b + kd.f_a + 8)};
+            float o = rd_f(r, b + kd.f_b);
+            int axis = -1, nz = 0;
+            for (int c = 0; c < 3; ++c)
+               if (n[c] != 0.0f) { ++nz; axis = c; }
+            if (nz == 1 && (n[axis] == 1.0f || n[axis] == -1.0f) && o == o) {
+               int g = 2 * axis + (n[axis] < 0.0f ? 1 : 0);
+               if (o < s.axis_off[g]) s.axis_off[g] = o;
+               ++s.n_axis;
+            } else {
+               t.push_back(mk4(n[0], n[1], n[2], o));
+               ++s.gplane_count;
+            }
+         }
+      }
+   }
    // material ids (int32), 4 per float4
    for (int k = 0; k < r->npk; ++k) {
       const Kind &kd = r->pk[k];

@@ -40,6 +40,13 @@ struct KScene {
    // the primitives by TYPE, for the order-free min of closest_primitive
    int tcount[4];    // runtime count of Sphere / Plane / Box / Triangle
    int tslot[4];     // first float4 of that type's geometry in the table
+   // Planes whose normal is exactly +-e_x, +-e_y or +-e_z (the walls of a room): for finite p,
+   // dot(n, p) + o is bit-identical to (+-p_axis) + o, and since rounding is monotonic the min over
+   // all planes of one direction is (+-p_axis) + min(o).  axis_off = that min offset for
+   // +x, -x, +y, -y, +z, -z (+inf where there is none); gplane_* = the remaining general planes.
+   float axis_off[6];
+   int n_axis;       // number of planes folded into axis_off (0: skip the block)
+   int gplane_count, gplane_slot;
    float max_dist;
    int total_lights; // total_light_count (scenes.adb:594)
    int mat_slot;     // first float4 of the materials (2 per material)
@@ -341,8 +348,13 @@ MDH_DEV float prim_dist(int type, int slot, f3 x)
 MDH_DEV float closest_primitive(const KScene &sc, f3 x)
 {
    float closest = sc.max_dist;
+   if (sc.n_axis > 0) { // six adds for all axis-aligned planes together
+      closest = min_(closest, min_(x.x + sc.axis_off[0], -x.x + sc.axis_off[1]));
+      closest = min_(closest, min_(x.y + sc.axis_off[2], -x.y + sc.axis_off[3]));
+      closest = min_(closest, min_(x.z + sc.axis_off[4], -x.z + sc.axis_off[5]));
+   }
    {
-      const int n = sc.tcount[PK_PLANE], s0 = sc.tslot[PK_PLANE];
+      const int n = sc.gplane_count, s0 = sc.gplane_slot;
 #pragma unroll MDH_SDF_UNROLL
       for (int i = 0; i < n; ++i) closest = min_(closest, sd_plane(s_tab[s0 + i], x));
    }
