@@ -1,0 +1,57 @@
+// examples/simple_scene.cpp -- the reference program examples/simple_scene/main.adb:28-122
+// restated with the C++ mirror (20 spheres, 6 planes, 14 boxes, one point light, the 10x10x20
+// space partition built with CPU_Best).  Usage: simple_scene W H FRAMES out.f32
+#include "madarch.hpp"
+
+#include <cstdio>
+#include <cstdlib>
+
+using namespace Madarch;
+
+int main(int argc, char **argv)
+{
+   const int W = argc > 1 ? atoi(argv[1]) : 1000, H = argc > 2 ? atoi(argv[2]) : 1000, frames = argc > 3 ? atoi(argv[3]) : 1;
+   try {
+      Scenes::Scene Scene = Scenes::Compile({{Primitives::Spheres::Sphere, 20}, {Primitives::Planes::Plane, 10}, {Primitives::Boxes::Box, 20}},
+                                            {{Lights::Point_Lights::Point_Light, 4}});
+      Renderers::Renderer Renderer = Renderers::Create(Windows::Open(W, H, "Simple_Scene"), Scene, {}, Renderers::No_Volumetrics);
+      Entities::Entity Point_Light_Instance = Lights::Point_Lights::Create({0.0f, 3.0f, 0.0f}, {0.9f, 0.9f, 0.9f});
+
+      const Entities::Entity Planes[] = {
+         Primitives::Planes::Create({0.0f, 1.0f, 0.0f}, 1.0f, 0), Primitives::Planes::Create({0.0f, -1.0f, 0.0f}, 7.0f, 0),
+         Primitives::Planes::Create({1.0f, 0.0f, 0.0f}, 1.0f, 1), Primitives::Planes::Create({-1.0f, 0.0f, 0.0f}, 7.0f, 2),
+         Primitives::Planes::Create({0.0f, 0.0f, 1.0f}, 6.0f, 0), Primitives::Planes::Create({0.0f, 0.0f, -1.0f}, 7.0f, 0)};
+      for (auto &Plane : Planes) Renderer.Add_Primitive(Primitives::Planes::Plane, Plane);
+      const float rows[4][2] = {{3.5f, 2.0f}, {0.5f, 2.0f}, {3.5f, 5.0f}, {0.5f, 5.0f}};
+      for (int r = 0; r < 4; ++r)
+         for (int i = 0; i < (r == 3 ? 2 : 6); ++i)
+            Renderer.Add_Primitive(Primitives::Spheres::Sphere, Primitives::Spheres::Create({0.5f + (float)i, rows[r][0], rows[r][1]}, 0.5f, 3));
+      const float boxes[14][6] = {{3, 1, 2, .5f, .5f, .5f},  {0, 1, 2, .3f, .3f, .5f},  {3, 1, 4, .5f, .5f, .5f},  {4, 2, 2, .5f, .5f, .5f},  {2, 2, 2, .5f, .5f, .5f},
+                                  {1, 1, 6, .5f, .5f, .5f},  {3, 1, 6, .5f, .5f, .5f},  {3, 1, -2, .5f, .5f, .5f}, {1, 1, -2, .3f, .3f, .5f}, {3, 1, -4, .5f, .5f, .5f},
+                                  {4, 2, -2, .5f, .5f, .5f}, {2, 2, -2, .5f, .5f, .5f}, {1, 1, -6, .5f, .5f, .5f}, {3, 1, -6, .5f, .5f, .5f}};
+      for (auto &b : boxes) Renderer.Add_Primitive(Primitives::Boxes::Box, Primitives::Boxes::Create({b[0], b[1], b[2]}, {b[3], b[4], b[5]}, 2));
+      Renderer.Set_Material(0, Materials::Create({0.0f, 0.0f, 0.0f}, 0.0f, 0.6f));
+      Renderer.Set_Material(1, Materials::Create({1.0f, 0.0f, 0.0f}, 0.0f, 0.6f));
+      Renderer.Set_Material(2, Materials::Create({0.0f, 0.0f, 1.0f}, 0.0f, 0.6f));
+      Renderer.Set_Material(3, Materials::Create({0.1f, 0.1f, 0.1f}, 0.9f, 0.1f));
+      Renderer.Set_Light(1, Lights::Point_Lights::Point_Light, Point_Light_Instance);
+      Renderer.Set_Camera_Position({2.0f, 2.0f, 0.0f});
+      Renderer.Update_Partitioning(Renderers::CPU_Best);
+
+      for (int f = 0; f < frames; ++f) Renderer.Render();
+      std::vector<float> image = Renderer.Read_Framebuffer();
+      if (argc > 4) {
+         FILE *out = fopen(argv[4], "wb");
+         if (!out) return 2;
+         fwrite(image.data(), sizeof(float), image.size(), out);
+         fclose(out);
+      }
+      double sum = 0;
+      for (float v : image) sum += (v == v) ? v : 0;
+      printf("simple_scene %dx%d frames %d mean %.6f\n", W, H, frames, sum / image.size());
+   } catch (const std::exception &e) {
+      fprintf(stderr, "error: %s\n", e.what());
+      return 1;
+   }
+   return 0;
+}
