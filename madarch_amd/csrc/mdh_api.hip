@@ -1003,3 +1003,14 @@ extern "C" int32_t mdh_read_partitioning(mdh_renderer *r, int32_t *out, int32_t 
    return MDH_OK;
 }
 extern "C" int32_t mdh_partition_warnings(mdh_renderer *r) { return r ? r->part_warnings : 0; }
+
+#ifdef MDH_DIAG
+// debug: read and reset the lane-utilisation counters of mdh_march.h
+extern "C" int32_t mdh_diag_read(unsigned long long *out16)
+{
+   if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_diag), sizeof(unsigned long long) * 16) != hipSuccess) return MDH_E_DEVICE;
+   unsigned long long z[16] = {0};
+   if (hipMemcpyToSymbol(HIP_SYMBOL(g_diag), z, sizeof z) != hipSuccess) return MDH_E_DEVICE;
+   return MDH_OK;
+}
+#endif

@@ -39,6 +39,21 @@ MDH_DEV i3 cage_probe(const KProbes &pr, i3 gp, int i)
 // and well under 128 VGPRs.
 // =============================================================================================
 
+// -DMDH_DIAG: per loop type, count SDF evaluations (wave level) and the lanes alive in them
+#ifdef MDH_DIAG
+__device__ unsigned long long g_diag[16];
+#define MDH_DIAG_STEP(type)                                                                 \
+   do {                                                                                     \
+      unsigned long long m_ = __ballot(1);                                                  \
+      if ((threadIdx.x & 63) == __ffsll((long long)m_) - 1) {                               \
+         atomicAdd(&g_diag[2 * (type)], 1ull);                                              \
+         atomicAdd(&g_diag[2 * (type) + 1], (unsigned long long)__popcll(m_));              \
+      }                                                                                     \
+   } while (0)
+#else
+#define MDH_DIAG_STEP(type) do { } while (0)
+#endif
+
 // raymarching.glsl:25-51: plain sphere trace until a hit or tmax; `steps` counts SDF evaluations
 template <bool PART> MDH_DEV bool march_plain(const KScene &sc, f3 o, f3 d, float tmax, float &t_out, int &steps)
 {
@@ -46,6 +61,7 @@ template <bool PART> MDH_DEV bool march_plain(const KScene &sc, f3 o, f3 d, floa
    bool h = false;
    float total = 0.0f;
    while (total < tmax) {
+      MDH_DIAG_STEP(0);
       float dist = sdf<PART>(sc, o + d * total);
       ++n;
       if (dist < MDH_EPS) { h = true; break; }
@@ -137,6 +153,7 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
                         float res = 1.0f, prev = 1e20f, total = 0.0f;
                         bool blocked = false;
                         while (total < L_dist) {
+                           MDH_DIAG_STEP(1 + ctx);
                            float dist = sdf<PART>(sc, from_off + L * total);
                            if (dist < MDH_EPS) { blocked = true; break; }
                            float y = dist * dist / (2.0f * prev);
@@ -176,6 +193,7 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
                      if (false)
 #endif
                      while (total < vmax) {
+                        MDH_DIAG_STEP(3 + ctx);
                         float sd = sdf<PART>(sc, from_off + vd * total);
                         if (sd < MDH_EPS) { vis = 0.0f; break; }
                         total += sd;
