@@ -68,6 +68,20 @@ def host_cpu_share():
     return max(1, n)
 
 
+def measured_traffic(workload, world):
+    """HBM bytes per k_screen launch from the PMC passes of the committed profile set (collected with
+    scripts/collect_profiles.sh on the same command), or None when no profile matches this run."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
+        try:
+            t = json.load(open(path))
+            if t.get("workload") == workload and t.get("n_gpus") == world:
+                return int(t["kernels"]["k_screen"]["hbm_bytes_per_launch"]), os.path.basename(path)
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None
+
+
 def cpu_baseline(workload):
     """The CPU oracle (a C restatement of the reference's path -- the Ada/GLSL reference
     cannot be built here) on the host cores: one warm-up frame, one timed frame."""
@@ -160,6 +174,7 @@ def main():
         alg_bytes, per_px, tables = algorithmic_bytes_screen(R)
         screen_ms = passes.get("screen", {}).get("ms_avg", float("nan"))
         achieved = alg_bytes / (screen_ms * 1e-3) / 1e9
+        traffic, traffic_src = measured_traffic(args.workload, world) if args.atlas == "rgb8" and args.mode is None else (None, None)
         out = {
             "metric": "Mpixels/sec at 1920x1080 global_illumination scene (one Renderers.Render frame: DDGI radiance + irradiance passes + screen pass)",
             "value": round(value, 3), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -169,7 +184,7 @@ def main():
                        "probe_grid": "8x8x8" if probes == "gi8" else "4x3x3", "atlas": args.atlas,
                        "screen_mode": mode, "parallelism": "tiles+probes/%d" % world},
             "roofline": {"bound": "hbm", "kernel": "k_screen", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": int(alg_bytes), "bytes_per_pixel": per_px,
                          "kernel_ms_avg": screen_ms,
                          "note": "the path is fp32-VALU bound (sphere tracing), not HBM bound; see DESIGN.md 'Roofline'"},
