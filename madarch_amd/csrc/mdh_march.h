@@ -12,6 +12,13 @@
 
 #include "mdh_device.h"
 
+#ifndef MDH_REUSE_FOLDED
+#define MDH_REUSE_FOLDED 1
+#endif
+#ifndef MDH_SKIP_NULL_RAYS
+#define MDH_SKIP_NULL_RAYS 1
+#endif
+
 struct MachineCfg {
    bool direct_specular;   // M_COMPUTE_DIRECT_SPECULAR
    bool indirect_specular; // M_COMPUTE_INDIRECT_SPECULAR == 2
@@ -145,10 +152,13 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
                      if (ctx == 0 && !cfg.direct_specular) kS = F3(0.0f, 0.0f, 0.0f);
                      const f3 contrib = (((kD * m.albedo) / MDH_PI + kS) * radiance) * NdotL;
                      float shadows = 0.0f;
+                     // a light that contributes exactly nothing here (outside a spot's cone, black BRDF)
+                     // needs no shadow ray: Lo + (+-0) * shadows = Lo for every shadows in [0, 1]
+                     const bool lit = MDH_SKIP_NULL_RAYS ? (contrib.x != 0.0f || contrib.y != 0.0f || contrib.z != 0.0f) : true;
 #ifdef MDH_ABL_NO_SHADOW
                      if (false) {
 #else
-                     if (NdotL > MDH_EPS) { // softshadows, raymarching.glsl:4-23
+                     if (NdotL > MDH_EPS && lit) { // softshadows, raymarching.glsl:4-23
 #endif
                         float res = 1.0f, prev = 1e20f, total = 0.0f;
                         bool blocked = false;
@@ -178,6 +188,13 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
                   f3 acc = (ctx == 0) ? F3(0.0f, 0.0f, 0.0f) : F3(0.0f, 0.0f, 1.0f);
                   float accw = (ctx == 0) ? 0.0f : -2.0f;
                   int best_q = 0; // x | y << 10 | z << 20
+                  // Cage corners that the clamp to the grid folds onto an earlier corner (P outside the
+                  // probe grid along an axis: all six walls of the example rooms are) name the SAME probe,
+                  // hence the same visibility ray: its result is reused instead of marched again.
+                  // bit a of `folded`: corners differing only in axis a coincide.
+                  const int folded = ((gp.x < 0 || gp.x >= pr.gx - 1) ? 1 : 0) | ((gp.y < 0 || gp.y >= pr.gy - 1) ? 2 : 0) |
+                                     ((gp.z < 0 || gp.z >= pr.gz - 1) ? 4 : 0);
+                  int vis_bits = 0; // bit i: visibility of corner i
 #pragma unroll 1
                   for (int i = 0; i < 8; ++i) {
                      const i3 q = cage_probe(pr, gp, i);
@@ -188,7 +205,19 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
                      if (ctx) vd = -vd;   // the visibility ray always runs from the point to the probe
                      // raycast_visibility, raymarching.glsl:39-56
                      float vis = 1.0f, total = 0.0f;
-                     const float vmax = dist - MDH_MIN_STEP * 5.0f;
+                     float vmax = dist - MDH_MIN_STEP * 5.0f;
+#if MDH_REUSE_FOLDED
+                     if (i & folded) { // same probe as corner i & ~folded, already traced
+                        vis = ((vis_bits >> (i & ~folded)) & 1) ? 1.0f : 0.0f;
+                        vmax = 0.0f;
+                     }
+#endif
+#if MDH_SKIP_NULL_RAYS
+                     // ctx 1 keeps the probe with the largest dot(probe_to_spec, -N) * vis (strictly larger
+                     // than the best so far).  With vis in {0, 1} the candidate is d or d * 0: once the best
+                     // is >= 0, a probe with d <= best cannot win whatever its visibility.
+                     if (ctx == 1 && accw >= 0.0f && dot(-vd, -N) <= accw) vmax = 0.0f;
+#endif
 #ifdef MDH_ABL_NO_VIS
                      if (false)
 #endif
@@ -198,6 +227,7 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
                         if (sd < MDH_EPS) { vis = 0.0f; break; }
                         total += sd;
                      }
+                     vis_bits |= (vis != 0.0f ? 1 : 0) << i;
                      if (ctx == 0) { // render_probes.glsl:26-62
                         float angle = (dot(vd, N) + 1.0f) * 0.5f;
                         float weight = angle * angle + 0.2f;
