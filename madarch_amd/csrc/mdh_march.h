@@ -15,6 +15,9 @@
 #ifndef MDH_REUSE_FOLDED
 #define MDH_REUSE_FOLDED 1
 #endif
+#ifndef MDH_SHARE_FIRST_STEP
+#define MDH_SHARE_FIRST_STEP 1
+#endif
 #ifndef MDH_SKIP_NULL_RAYS
 #define MDH_SKIP_NULL_RAYS 1
 #endif
@@ -136,6 +139,10 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
             }
             if (MODE != 1) {
                const f3 from_off = P + (N * MDH_MIN_STEP) * 5.0f;
+               // Every shadow and probe-visibility ray of this point starts AT from_off with t = 0, so
+               // their first SDF evaluation is at the same position (from_off + dir * 0): it is done
+               // once here and each ray replays its first iteration with this value.
+               const float sd0 = MDH_SHARE_FIRST_STEP ? sdf<PART>(sc, from_off) : 0.0f;
                // ---- compute_direct_lighting (lighting.glsl:1-40) at P, seen along rd
                f3 Lo = F3(0.0f, 0.0f, 0.0f);
                {
@@ -162,9 +169,11 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
 #endif
                         float res = 1.0f, prev = 1e20f, total = 0.0f;
                         bool blocked = false;
+                        bool first = MDH_SHARE_FIRST_STEP != 0;
                         while (total < L_dist) {
                            MDH_DIAG_STEP(1 + ctx);
-                           float dist = sdf<PART>(sc, from_off + L * total);
+                           float dist = first ? sd0 : sdf<PART>(sc, from_off + L * total);
+                           first = false;
                            if (dist < MDH_EPS) { blocked = true; break; }
                            float y = dist * dist / (2.0f * prev);
                            float d = sqrt_(dist * dist - y * y);
@@ -221,9 +230,11 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
 #ifdef MDH_ABL_NO_VIS
                      if (false)
 #endif
+                     bool first = MDH_SHARE_FIRST_STEP != 0;
                      while (total < vmax) {
                         MDH_DIAG_STEP(3 + ctx);
-                        float sd = sdf<PART>(sc, from_off + vd * total);
+                        float sd = first ? sd0 : sdf<PART>(sc, from_off + vd * total);
+                        first = false;
                         if (sd < MDH_EPS) { vis = 0.0f; break; }
                         total += sd;
                      }
