@@ -128,7 +128,13 @@ enum {
    MDH_OPT_TIMING = 6,
    /* Eval_Distance_To arithmetic: 1 = reproduce Madarch.Values."/" on floats
     * (L + R, madarch-values.adb:112) as the Ada evaluator does; 0 = GLSL "/" */
-   MDH_OPT_ADA_EVAL_DIV = 7
+   MDH_OPT_ADA_EVAL_DIV = 7,
+   /* 1 (default) = mdh_render may overlap the probe passes of a frame with the
+    * screen pass of the frame before it (second HIP stream, two atlas sets; same
+    * results as the serial order, madarch-renderers.adb:302-321); 0 = strictly
+    * one pass after the other.  Ignored (serial) for sharded renderers and on a
+    * caller-supplied stream. */
+   MDH_OPT_FRAME_OVERLAP = 8
 };
 
 /* passes of Renderers.Render (madarch-renderers.adb:302-321) */

@@ -131,7 +131,16 @@ struct mdh_renderer {
    size_t table_cap = 0;
    bool table_dirty = true;
    int *d_part = nullptr, *d_warn = nullptr;
-   void *d_rad = nullptr, *d_irr = nullptr;
+   // Two sets of probe atlases.  `last` is the set the most recent frame wrote: every read, write and
+   // single pass works on it in place.  A pipelined mdh_render (frame overlap, see mdh_render) writes the
+   // other set while the previous frame's screen pass still reads this one, then flips.
+   void *d_rad2[2] = {nullptr, nullptr}, *d_irr2[2] = {nullptr, nullptr};
+   int last = 0;
+   int opt_overlap = 1;
+   hipStream_t probe_stream = nullptr;   // radiance + irradiance passes of pipelined frames
+   hipEvent_t ev_screen[2] = {nullptr, nullptr}, ev_probe = nullptr, ev_join = nullptr;
+   bool ev_screen_valid[2] = {false, false};
+   bool main_dirty = true; // work went to `stream` outside a pipelined frame since the probe stream last joined it
    float *d_vis = nullptr;
    float4 *d_scat = nullptr, *d_fb = nullptr;
    int *d_gb_index = nullptr, *d_gb_steps = nullptr;
@@ -315,7 +324,7 @@ static KProbes make_probes(const mdh_renderer *r)
    p.fmt = r->opt_atlas;
    auto log2_or_neg = [](int v) { int s = 0; while ((1 << s) < v) ++s; return (1 << s) == v ? s : -1; };
    p.rshift = log2_or_neg(p.rres); p.ishift = log2_or_neg(p.ires); p.pcx_shift = log2_or_neg(p.pcx);
-   p.rad = r->d_rad; p.irr = r->d_irr;
+   p.rad = r->d_rad2[r->last]; p.irr = r->d_irr2[r->last];
    own_probes(r, &p.probe_begin, &p.probe_end);
    return p;
 }
@@ -339,14 +348,17 @@ static KVolumetrics make_vol(const mdh_renderer *r, bool enabled)
 
 static int alloc_atlases(mdh_renderer *r)
 {
-   if (r->d_rad) HIP_TRY(hipFree(r->d_rad));
-   if (r->d_irr) HIP_TRY(hipFree(r->d_irr));
-   r->d_rad = r->d_irr = nullptr;
-   HIP_TRY(hipMalloc(&r->d_rad, atlas_bytes(r, MDH_TEX_RADIANCE)));
-   HIP_TRY(hipMalloc(&r->d_irr, atlas_bytes(r, MDH_TEX_IRRADIANCE)));
-   // Load_Empty_Texture (render_passes.adb:115-116): contents start as zeros here
-   HIP_TRY(hipMemsetAsync(r->d_rad, 0, atlas_bytes(r, MDH_TEX_RADIANCE), r->stream));
-   HIP_TRY(hipMemsetAsync(r->d_irr, 0, atlas_bytes(r, MDH_TEX_IRRADIANCE), r->stream));
+   for (int s = 0; s < 2; ++s) {
+      if (r->d_rad2[s]) HIP_TRY(hipFree(r->d_rad2[s]));
+      if (r->d_irr2[s]) HIP_TRY(hipFree(r->d_irr2[s]));
+      r->d_rad2[s] = r->d_irr2[s] = nullptr;
+      HIP_TRY(hipMalloc(&r->d_rad2[s], atlas_bytes(r, MDH_TEX_RADIANCE)));
+      HIP_TRY(hipMalloc(&r->d_irr2[s], atlas_bytes(r, MDH_TEX_IRRADIANCE)));
+      // Load_Empty_Texture (render_passes.adb:115-116): contents start as zeros here
+      HIP_TRY(hipMemsetAsync(r->d_rad2[s], 0, atlas_bytes(r, MDH_TEX_RADIANCE), r->stream));
+      HIP_TRY(hipMemsetAsync(r->d_irr2[s], 0, atlas_bytes(r, MDH_TEX_IRRADIANCE), r->stream));
+   }
+   r->main_dirty = true;
    return MDH_OK;
 }
 
@@ -354,12 +366,16 @@ extern "C" int32_t mdh_destroy(mdh_renderer *r)
 {
    if (!r) return MDH_OK;
    (void)hipSetDevice(r->device);
+   if (r->probe_stream) (void)hipStreamSynchronize(r->probe_stream);
    if (r->stream) (void)hipStreamSynchronize(r->stream);
-   void *ptrs[] = {r->d_table, r->d_part, r->d_warn, r->d_rad, r->d_irr, r->d_vis, r->d_scat, r->d_fb, r->d_gb_index, r->d_gb_steps, r->d_gb_t};
+   void *ptrs[] = {r->d_table, r->d_part, r->d_warn, r->d_rad2[0], r->d_irr2[0], r->d_rad2[1], r->d_irr2[1], r->d_vis, r->d_scat, r->d_fb, r->d_gb_index, r->d_gb_steps, r->d_gb_t};
    for (void *p : ptrs)
       if (p) (void)hipFree(p);
    for (auto &p : r->pending) { (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1); }
    for (auto e : r->free_events) (void)hipEventDestroy(e);
+   for (hipEvent_t e : {r->ev_screen[0], r->ev_screen[1], r->ev_probe, r->ev_join})
+      if (e) (void)hipEventDestroy(e);
+   if (r->probe_stream) (void)hipStreamDestroy(r->probe_stream);
    if (r->own_stream) (void)hipStreamDestroy(r->own_stream);
    delete r;
    return MDH_OK;
@@ -428,6 +444,15 @@ extern "C" int32_t mdh_create(int32_t width, int32_t height, const mdh_scene_des
    TRY_OR_FAIL(hipSetDevice(device));
    TRY_OR_FAIL(hipStreamCreateWithFlags(&r->own_stream, hipStreamNonBlocking));
    r->stream = r->own_stream;
+   {
+      int lo = 0, hi = 0; // numerically lower = higher priority
+      TRY_OR_FAIL(hipDeviceGetStreamPriorityRange(&lo, &hi));
+      const char *pe = getenv("MADARCH_HIP_PROBE_PRIORITY"); // experiments: -1 high, 0 default, 1 low
+      int prio = pe ? atoi(pe) : 0;
+      prio = prio < 0 ? hi : (prio > 0 ? lo : 0);
+      TRY_OR_FAIL(hipStreamCreateWithPriority(&r->probe_stream, hipStreamNonBlocking, prio));
+      for (hipEvent_t *e : {&r->ev_screen[0], &r->ev_screen[1], &r->ev_probe, &r->ev_join}) TRY_OR_FAIL(hipEventCreateWithFlags(e, hipEventDisableTiming));
+   }
    if ((rc = alloc_atlases(r)) != MDH_OK) return fail(rc);
    size_t px = (size_t)width * height;
    TRY_OR_FAIL(hipMalloc(&r->d_fb, px * sizeof(float4)));
@@ -474,6 +499,7 @@ extern "C" int32_t mdh_set_option(mdh_renderer *r, int32_t option, int32_t value
    case MDH_OPT_WORLD: if (value < 1) return seterr(MDH_E_INVALID, "world < 1"); r->opt_world = value; break;
    case MDH_OPT_TIMING: r->opt_timing = value ? 1 : 0; break;
    case MDH_OPT_ADA_EVAL_DIV: r->opt_ada_div = value ? 1 : 0; break;
+   case MDH_OPT_FRAME_OVERLAP: r->opt_overlap = value ? 1 : 0; break;
    default: return seterr(MDH_E_INVALID, "unknown option");
    }
    return MDH_OK;
@@ -490,6 +516,7 @@ extern "C" int32_t mdh_get_option(mdh_renderer *r, int32_t option, int32_t *valu
    case MDH_OPT_WORLD: *value = r->opt_world; break;
    case MDH_OPT_TIMING: *value = r->opt_timing; break;
    case MDH_OPT_ADA_EVAL_DIV: *value = r->opt_ada_div; break;
+   case MDH_OPT_FRAME_OVERLAP: *value = r->opt_overlap; break;
    default: return seterr(MDH_E_INVALID, "unknown option");
    }
    return MDH_OK;
@@ -612,29 +639,33 @@ extern "C" int32_t mdh_update_partitioning(mdh_renderer *r, int32_t method)
    return MDH_OK;
 }
 
-template <bool PART, int MODE> static void launch_screen_g(mdh_renderer *r, const KProbes &pr, const KVolumetrics &vol, const KCamera &cam, const ScreenArgs &a, int blocks)
+template <bool PART, int MODE> static void launch_screen_g(mdh_renderer *r, hipStream_t st, const KProbes &pr, const KVolumetrics &vol, const KCamera &cam, const ScreenArgs &a, int blocks)
 {
-   if (r->opt_gbuffer) hipLaunchKernelGGL((k_screen<PART, MODE, true>), dim3(blocks), dim3(MDH_BLOCK), lds_bytes_march(r), r->stream, r->ks, pr, vol, cam, a);
-   else hipLaunchKernelGGL((k_screen<PART, MODE, false>), dim3(blocks), dim3(MDH_BLOCK), lds_bytes_march(r), r->stream, r->ks, pr, vol, cam, a);
+   if (r->opt_gbuffer) hipLaunchKernelGGL((k_screen<PART, MODE, true>), dim3(blocks), dim3(MDH_BLOCK), lds_bytes_march(r), st, r->ks, pr, vol, cam, a);
+   else hipLaunchKernelGGL((k_screen<PART, MODE, false>), dim3(blocks), dim3(MDH_BLOCK), lds_bytes_march(r), st, r->ks, pr, vol, cam, a);
 }
-template <bool PART> static void launch_screen_m(mdh_renderer *r, const KProbes &pr, const KVolumetrics &vol, const KCamera &cam, const ScreenArgs &a, int blocks)
+template <bool PART> static void launch_screen_m(mdh_renderer *r, hipStream_t st, const KProbes &pr, const KVolumetrics &vol, const KCamera &cam, const ScreenArgs &a, int blocks)
 {
-   if (r->opt_mode == 0) launch_screen_g<PART, 0>(r, pr, vol, cam, a, blocks);
-   else if (r->opt_mode == 1) launch_screen_g<PART, 1>(r, pr, vol, cam, a, blocks);
-   else launch_screen_g<PART, 2>(r, pr, vol, cam, a, blocks);
+   if (r->opt_mode == 0) launch_screen_g<PART, 0>(r, st, pr, vol, cam, a, blocks);
+   else if (r->opt_mode == 1) launch_screen_g<PART, 1>(r, st, pr, vol, cam, a, blocks);
+   else launch_screen_g<PART, 2>(r, st, pr, vol, cam, a, blocks);
 }
 
-static int run_pass(mdh_renderer *r, int pass)
+// One pass on stream `st`.  The radiance pass reads the irradiance atlas of set `src` and writes the
+// radiance atlas of set `dst`; every other pass works on set `dst` (in place: src == dst == r->last).
+static int run_pass(mdh_renderer *r, int pass, hipStream_t st, int src, int dst)
 {
    const bool part = r->part.enable != 0;
    KProbes pr = make_probes(r);
+   pr.rad = r->d_rad2[dst];
+   pr.irr = r->d_irr2[pass == MDH_PASS_RADIANCE ? src : dst];
    KCamera cam = make_camera(r);
    hipEvent_t e0 = nullptr, e1 = nullptr;
    if (r->opt_timing) {
       e0 = get_event(r);
       e1 = get_event(r);
       if (!e0 || !e1) return seterr(MDH_E_DEVICE, "hipEventCreate failed");
-      HIP_TRY(hipEventRecord(e0, r->stream));
+      HIP_TRY(hipEventRecord(e0, st));
    }
    switch (pass) {
    case MDH_PASS_RADIANCE: {
@@ -645,8 +676,8 @@ static int run_pass(mdh_renderer *r, int pass)
       }
       if (n > 0) {
          int blocks = (int)((n + MDH_BLOCK - 1) / MDH_BLOCK);
-         if (part) hipLaunchKernelGGL(k_radiance<true>, dim3(blocks), dim3(MDH_BLOCK), lds_bytes_march(r), r->stream, r->ks, pr);
-         else hipLaunchKernelGGL(k_radiance<false>, dim3(blocks), dim3(MDH_BLOCK), lds_bytes_march(r), r->stream, r->ks, pr);
+         if (part) hipLaunchKernelGGL(k_radiance<true>, dim3(blocks), dim3(MDH_BLOCK), lds_bytes_march(r), st, r->ks, pr);
+         else hipLaunchKernelGGL(k_radiance<false>, dim3(blocks), dim3(MDH_BLOCK), lds_bytes_march(r), st, r->ks, pr);
       }
       break;
    }
@@ -654,7 +685,7 @@ static int run_pass(mdh_renderer *r, int pass)
       int n = pr.probe_end - pr.probe_begin; // one workgroup per probe, its taps staged in LDS
       size_t lds = (size_t)2 * pr.rres * pr.rres * sizeof(float4);
       if (lds > 64 * 1024) return seterr(MDH_E_INVALID, "radiance resolution too large for the irradiance pass (LDS)");
-      if (n > 0) hipLaunchKernelGGL(k_irradiance, dim3(n), dim3(MDH_IRR_BLOCK), lds, r->stream, pr);
+      if (n > 0) hipLaunchKernelGGL(k_irradiance, dim3(n), dim3(MDH_IRR_BLOCK), lds, st, pr);
       break;
    }
    case MDH_PASS_VISIBILITY: {
@@ -662,8 +693,8 @@ static int run_pass(mdh_renderer *r, int pass)
       long n = (long)vol.vw * vol.vh * vol.vz;
       if (n > 0) {
          int blocks = (int)((n + MDH_BLOCK - 1) / MDH_BLOCK);
-         if (part) hipLaunchKernelGGL(k_visibility<true>, dim3(blocks), dim3(MDH_BLOCK), lds_bytes(r), r->stream, r->ks, vol, cam);
-         else hipLaunchKernelGGL(k_visibility<false>, dim3(blocks), dim3(MDH_BLOCK), lds_bytes(r), r->stream, r->ks, vol, cam);
+         if (part) hipLaunchKernelGGL(k_visibility<true>, dim3(blocks), dim3(MDH_BLOCK), lds_bytes(r), st, r->ks, vol, cam);
+         else hipLaunchKernelGGL(k_visibility<false>, dim3(blocks), dim3(MDH_BLOCK), lds_bytes(r), st, r->ks, vol, cam);
       }
       break;
    }
@@ -672,8 +703,8 @@ static int run_pass(mdh_renderer *r, int pass)
       long n = (long)vol.sw * vol.sh;
       if (n > 0) {
          int blocks = (int)((n + MDH_BLOCK - 1) / MDH_BLOCK);
-         if (part) hipLaunchKernelGGL(k_scattering<true>, dim3(blocks), dim3(MDH_BLOCK), lds_bytes(r), r->stream, r->ks, vol, cam);
-         else hipLaunchKernelGGL(k_scattering<false>, dim3(blocks), dim3(MDH_BLOCK), lds_bytes(r), r->stream, r->ks, vol, cam);
+         if (part) hipLaunchKernelGGL(k_scattering<true>, dim3(blocks), dim3(MDH_BLOCK), lds_bytes(r), st, r->ks, vol, cam);
+         else hipLaunchKernelGGL(k_scattering<false>, dim3(blocks), dim3(MDH_BLOCK), lds_bytes(r), st, r->ks, vol, cam);
       }
       break;
    }
@@ -686,12 +717,12 @@ static int run_pass(mdh_renderer *r, int pass)
       a.rank = r->opt_rank; a.world = r->opt_world;
       a.ao_steps = r->opt_ao;
       a.fb = r->d_fb; a.gb_index = r->d_gb_index; a.gb_t = r->d_gb_t; a.gb_steps = r->d_gb_steps;
-      if (a.world > 1) HIP_TRY(hipMemsetAsync(r->d_fb, 0, (size_t)r->W * r->H * sizeof(float4), r->stream)); // other ranks' tiles read 0
+      if (a.world > 1) HIP_TRY(hipMemsetAsync(r->d_fb, 0, (size_t)r->W * r->H * sizeof(float4), st)); // other ranks' tiles read 0
       int own_tiles = (a.n_tiles - a.rank + a.world - 1) / a.world;
       if (own_tiles > 0) {
          int blocks = (own_tiles + (MDH_BLOCK / 64) - 1) / (MDH_BLOCK / 64);
-         if (part) launch_screen_m<true>(r, pr, vol, cam, a, blocks);
-         else launch_screen_m<false>(r, pr, vol, cam, a, blocks);
+         if (part) launch_screen_m<true>(r, st, pr, vol, cam, a, blocks);
+         else launch_screen_m<false>(r, st, pr, vol, cam, a, blocks);
       }
       break;
    }
@@ -699,7 +730,7 @@ static int run_pass(mdh_renderer *r, int pass)
    }
    HIP_TRY(hipGetLastError());
    if (r->opt_timing) {
-      HIP_TRY(hipEventRecord(e1, r->stream));
+      HIP_TRY(hipEventRecord(e1, st));
       r->pending.push_back({pass, e0, e1});
       if (r->pending.size() >= 4096) return resolve_timing(r);
    }
@@ -711,23 +742,62 @@ extern "C" int32_t mdh_render_pass(mdh_renderer *r, int32_t pass)
    if (!r) return seterr(MDH_E_INVALID, "null renderer");
    int rc = ensure_committed(r);
    if (rc != MDH_OK) return rc;
-   return run_pass(r, pass);
+   r->main_dirty = true;
+   return run_pass(r, pass, r->stream, r->last, r->last);
 }
-// Render (renderers.adb:302-321)
+// Render (renderers.adb:302-321).
+//
+// Frame overlap (MDH_OPT_FRAME_OVERLAP, on by default, single-GPU renderers on their own stream):
+// the probe passes of frame N+1 do not depend on the screen pass of frame N -- they need the
+// irradiance atlas frame N produced and nothing else -- so they run on a second HIP stream into
+// the other atlas set while screen(N) is still drawing.  The radiance pass ends in a long tail
+// of a few slow wavefronts and the irradiance pass fills a fraction of the chip; the screen pass of
+// the previous frame fills those holes.  Per frame and atlas set `cur`:
+//    probe stream: wait screen(N-2) (last reader of set cur) -> radiance(irr[last] -> rad[cur])
+//                  -> irradiance(rad[cur] -> irr[cur]) -> ev_probe
+//    main stream:  wait ev_probe -> [volumetric passes] -> screen(set cur) -> ev_screen[cur]
+// Every later operation on the main stream is therefore ordered after all probe-stream work, and
+// the results are those of the serial order bit for bit.
 extern "C" int32_t mdh_render(mdh_renderer *r)
 {
    if (!r) return seterr(MDH_E_INVALID, "null renderer");
    int rc = ensure_committed(r);
    if (rc != MDH_OK) return rc;
-   if (r->opt_mode == 0) {
-      if ((rc = run_pass(r, MDH_PASS_RADIANCE)) != MDH_OK) return rc;
-      if ((rc = run_pass(r, MDH_PASS_IRRADIANCE)) != MDH_OK) return rc;
-      if (r->vol.enabled) {
-         if ((rc = run_pass(r, MDH_PASS_VISIBILITY)) != MDH_OK) return rc;
-         if ((rc = run_pass(r, MDH_PASS_SCATTERING)) != MDH_OK) return rc;
+   const bool pipelined = r->opt_overlap && r->opt_mode == 0 && r->opt_world == 1 && r->stream == r->own_stream;
+   if (!pipelined) {
+      r->main_dirty = true;
+      const int s = r->last;
+      if (r->opt_mode == 0) {
+         if ((rc = run_pass(r, MDH_PASS_RADIANCE, r->stream, s, s)) != MDH_OK) return rc;
+         if ((rc = run_pass(r, MDH_PASS_IRRADIANCE, r->stream, s, s)) != MDH_OK) return rc;
+         if (r->vol.enabled) {
+            if ((rc = run_pass(r, MDH_PASS_VISIBILITY, r->stream, s, s)) != MDH_OK) return rc;
+            if ((rc = run_pass(r, MDH_PASS_SCATTERING, r->stream, s, s)) != MDH_OK) return rc;
+         }
       }
+      return run_pass(r, MDH_PASS_SCREEN, r->stream, s, s);
    }
-   return run_pass(r, MDH_PASS_SCREEN);
+   const int prev = r->last, cur = prev ^ 1;
+   if (r->main_dirty) { // the probe stream has to see everything that went to the main stream meanwhile
+      HIP_TRY(hipEventRecord(r->ev_join, r->stream));
+      HIP_TRY(hipStreamWaitEvent(r->probe_stream, r->ev_join, 0));
+      r->main_dirty = false;
+   } else if (r->ev_screen_valid[cur]) {
+      HIP_TRY(hipStreamWaitEvent(r->probe_stream, r->ev_screen[cur], 0));
+   }
+   if ((rc = run_pass(r, MDH_PASS_RADIANCE, r->probe_stream, prev, cur)) != MDH_OK) return rc;
+   if ((rc = run_pass(r, MDH_PASS_IRRADIANCE, r->probe_stream, cur, cur)) != MDH_OK) return rc;
+   HIP_TRY(hipEventRecord(r->ev_probe, r->probe_stream));
+   HIP_TRY(hipStreamWaitEvent(r->stream, r->ev_probe, 0));
+   if (r->vol.enabled) {
+      if ((rc = run_pass(r, MDH_PASS_VISIBILITY, r->stream, cur, cur)) != MDH_OK) return rc;
+      if ((rc = run_pass(r, MDH_PASS_SCATTERING, r->stream, cur, cur)) != MDH_OK) return rc;
+   }
+   if ((rc = run_pass(r, MDH_PASS_SCREEN, r->stream, cur, cur)) != MDH_OK) return rc;
+   HIP_TRY(hipEventRecord(r->ev_screen[cur], r->stream));
+   r->ev_screen_valid[cur] = true;
+   r->last = cur;
+   return MDH_OK;
 }
 extern "C" int32_t mdh_finish(mdh_renderer *r)
 {
@@ -765,7 +835,7 @@ static int atlas_to_host(mdh_renderer *r, int tex, std::vector<float> &rgb)
 {
    int res = tex == MDH_TEX_RADIANCE ? r->probes.radiance_resolution : r->probes.irradiance_resolution;
    size_t n = (size_t)probe_total(r) * res * res;
-   void *src = tex == MDH_TEX_RADIANCE ? r->d_rad : r->d_irr;
+   void *src = tex == MDH_TEX_RADIANCE ? r->d_rad2[r->last] : r->d_irr2[r->last];
    rgb.resize(n * 3);
    if (r->opt_atlas == 0) {
       std::vector<uchar4> tmp(n);
@@ -789,7 +859,8 @@ static float unorm8_host(float x)
 // upload texels [first, first + n) of a probe-major atlas from float RGB
 static int atlas_from_host(mdh_renderer *r, int tex, size_t first, size_t n, const float *rgb)
 {
-   void *dst = tex == MDH_TEX_RADIANCE ? r->d_rad : r->d_irr;
+   void *dst = tex == MDH_TEX_RADIANCE ? r->d_rad2[r->last] : r->d_irr2[r->last];
+   r->main_dirty = true;
    if (r->opt_atlas == 0) {
       std::vector<uchar4> tmp(n);
       for (size_t i = 0; i < n; ++i) {
@@ -895,7 +966,8 @@ extern "C" int32_t mdh_atlas_device_ptr(mdh_renderer *r, int32_t tex, void **dpt
    int b, e;
    own_probes(r, &b, &e);
    int64_t per = (int64_t)res * res * (int64_t)texel_bytes(r);
-   if (dptr) *dptr = tex == MDH_TEX_RADIANCE ? r->d_rad : r->d_irr;
+   if (dptr) *dptr = tex == MDH_TEX_RADIANCE ? r->d_rad2[r->last] : r->d_irr2[r->last];
+   r->main_dirty = true; // the caller may write through the pointer
    if (total_bytes) *total_bytes = (int64_t)atlas_bytes(r, tex);
    if (own_offset) *own_offset = per * b;
    if (own_bytes) *own_bytes = per * (e - b);
@@ -1011,6 +1083,24 @@ extern "C" int32_t mdh_diag_read(unsigned long long *out16)
    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_diag), sizeof(unsigned long long) * 16) != hipSuccess) return MDH_E_DEVICE;
    unsigned long long z[16] = {0};
    if (hipMemcpyToSymbol(HIP_SYMBOL(g_diag), z, sizeof z) != hipSuccess) return MDH_E_DEVICE;
+   return MDH_OK;
+}
+#endif
+#ifdef MDH_PHASES
+extern "C" int32_t mdh_diag_phases(unsigned long long *out16)
+{
+   if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_phase), sizeof(unsigned long long) * 16) != hipSuccess) return MDH_E_DEVICE;
+   unsigned long long z[16] = {0};
+   if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof z) != hipSuccess) return MDH_E_DEVICE;
+   return MDH_OK;
+}
+#endif
+#ifdef MDH_TIMELINE
+// debug: the wave timeline of the last k_radiance launch (3 words per wave)
+extern "C" int32_t mdh_diag_waves(unsigned long long *out, int32_t n_waves)
+{
+   if (n_waves > MDH_DIAG_WAVES) n_waves = MDH_DIAG_WAVES;
+   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_t), sizeof(unsigned long long) * 3 * n_waves) != hipSuccess) return MDH_E_DEVICE;
    return MDH_OK;
 }
 #endif

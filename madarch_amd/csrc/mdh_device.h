@@ -707,6 +707,41 @@ MDH_DEV f3 atlas_sample(const void *base, int fmt, int pcx, int pcy, int res, in
    return ((a * w00 + b * w10) + c * w01) + d * w11;
 }
 
+// The same tap in two halves, so that the four texel loads of an RGBA8 atlas can be issued long
+// before their values are needed (L2 latency hidden behind a march loop): atlas_tap_issue does
+// the addressing and the loads, atlas_tap_resolve the u8 -> float conversion and the blend.
+// float4 atlases load at resolve time.
+struct AtlasTap {
+   unsigned t00, t10, t01, t11; // RGBA8 texels; float4 atlases: the four texel indices
+   float fx, fy;
+};
+MDH_DEV AtlasTap atlas_tap_issue(const void *base, int fmt, int pcx, int pcy, int res, int shift, float cx, float cy)
+{
+   const int W = pcx * res, H = pcy * res;
+   float px = cx * (float)W - 0.5f, py = cy * (float)H - 0.5f;
+   float fx0 = __builtin_floorf(px), fy0 = __builtin_floorf(py);
+   AtlasTap t;
+   t.fx = px - fx0; t.fy = py - fy0;
+   int x0 = mirror((int)fx0, W), x1 = mirror((int)fx0 + 1, W), y0 = mirror((int)fy0, H), y1 = mirror((int)fy0 + 1, H);
+   t.t00 = atlas_index(pcx, res, shift, x0, y0); t.t10 = atlas_index(pcx, res, shift, x1, y0);
+   t.t01 = atlas_index(pcx, res, shift, x0, y1); t.t11 = atlas_index(pcx, res, shift, x1, y1);
+   if (fmt == 0) {
+      const unsigned *b = (const unsigned *)base;
+      t.t00 = b[t.t00]; t.t10 = b[t.t10]; t.t01 = b[t.t01]; t.t11 = b[t.t11];
+   }
+   return t;
+}
+MDH_DEV f3 u8_texel(unsigned t, int u8_tab) { return F3(tab_float(u8_tab + (t & 255u)), tab_float(u8_tab + ((t >> 8) & 255u)), tab_float(u8_tab + ((t >> 16) & 255u))); }
+MDH_DEV f3 atlas_tap_resolve(const void *base, int fmt, const AtlasTap &t, int u8_tab)
+{
+   const float fx = t.fx, fy = t.fy;
+   float w00 = (1.0f - fx) * (1.0f - fy), w10 = fx * (1.0f - fy), w01 = (1.0f - fx) * fy, w11 = fx * fy;
+   f3 a, b, c, d;
+   if (fmt == 0) { a = u8_texel(t.t00, u8_tab); b = u8_texel(t.t10, u8_tab); c = u8_texel(t.t01, u8_tab); d = u8_texel(t.t11, u8_tab); }
+   else { a = atlas_texel(base, fmt, t.t00, u8_tab); b = atlas_texel(base, fmt, t.t10, u8_tab); c = atlas_texel(base, fmt, t.t01, u8_tab); d = atlas_texel(base, fmt, t.t11, u8_tab); }
+   return ((a * w00 + b * w10) + c * w01) + d * w11;
+}
+
 // ------------------------------------------------------------------------ volumetrics
 #define MDH_TAU 0.1f // glsl/volumetrics.glsl:12
 // glsl/volumetrics.glsl:21-30

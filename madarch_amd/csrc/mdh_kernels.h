@@ -10,8 +10,21 @@
 
 #include "mdh_march.h"
 #define MDH_SHADE shade_structured
+#ifdef MDH_PHASES
+#define PH_KERNEL_BEGIN() float *pk = park_base(sc); if ((threadIdx.x & 63) < 32) ph_acc_(pk)[threadIdx.x & 63] = 0ull; PH_T0(pk_t)
+#define PH_KERNEL_END() do { PH_ADD(pk_t, 11); if ((threadIdx.x & 63) < 16) atomicAdd(&g_phase[threadIdx.x & 63], ph_acc_(pk)[threadIdx.x & 63]); } while (0)
+#else
+#define PH_KERNEL_BEGIN() do { } while (0)
+#define PH_KERNEL_END() do { } while (0)
+#endif
 #ifndef MDH_RAD_PROBES_PER_WAVE
 #define MDH_RAD_PROBES_PER_WAVE 64 // 1, 4, 16 or 64 (measured on MI355X: see DESIGN.md)
+#endif
+#ifndef MDH_RAD_QVIS
+#define MDH_RAD_QVIS 1 // probe-visibility rays through the wave's ray queue (mdh_march.h: queued_visibility)
+#endif
+#ifndef MDH_SCR_QVIS
+#define MDH_SCR_QVIS 0
 #endif
 #ifndef MDH_WAVES_PER_SIMD
 #define MDH_WAVES_PER_SIMD 6 // register budget of the march kernels (measured: 6 > 5 > 8 > 4 > 3 > 2 waves/SIMD)
@@ -39,6 +52,7 @@ __global__ __launch_bounds__(MDH_BLOCK, MDH_WAVES_PER_SIMD) void k_screen(KScene
    const int own = blockIdx.x * (MDH_BLOCK / 64) + wave;
    const int tile = a.rank + own * a.world;
    if (tile >= a.n_tiles) return; // wave-uniform
+   PH_KERNEL_BEGIN();
    const int i = (tile % a.tiles_x) * 8 + (lane & 7), j = (tile / a.tiles_x) * 8 + (lane >> 3);
    const bool valid = i < a.W && j < a.H;
    const float u = centre(i, a.W), v = -centre(j, a.H); // row 0 = top
@@ -51,7 +65,10 @@ __global__ __launch_bounds__(MDH_BLOCK, MDH_WAVES_PER_SIMD) void k_screen(KScene
    PrimaryHit ph;
    bool hit;
    f3 pos;
-   f3 c = MDH_SHADE<PART, MODE>(sc, pr, cfg, valid, origin, dir, ph, hit, pos);
+   f3 c = MDH_SHADE<PART, MODE, true, MDH_SCR_QVIS != 0>(sc, pr, cfg, valid, origin, dir, ph, hit, pos);
+#ifdef MDH_PHASES
+   if (!valid) { PH_KERNEL_END(); return; }
+#endif
    if (!valid) return;
    if (MODE == 0 && vol.enabled) c = render_volumetrics(sc, vol, c, origin, pos, hit, F2(u, v));
    if (MODE != 1) // draw_screen.glsl:29
@@ -63,6 +80,7 @@ __global__ __launch_bounds__(MDH_BLOCK, MDH_WAVES_PER_SIMD) void k_screen(KScene
       a.gb_t[px] = ph.t;
       a.gb_steps[px] = ph.steps;
    }
+   PH_KERNEL_END();
 }
 
 // ---------------------------------------------------------------------- radiance pass
@@ -93,6 +111,8 @@ template <bool PART> __global__ __launch_bounds__(MDH_BLOCK, MDH_WAVES_PER_SIMD)
       x = rem - y * pr.rres;
    }
    const bool valid = probe_raw < pr.probe_end;
+   MDH_DIAG_WAVE(wave_global);
+   PH_KERNEL_BEGIN();
    const int probe = valid ? probe_raw : pr.probe_begin;
    const int ty = probe / pr.pcx, tx = probe - ty * pr.pcx;
    const int i = tx * pr.rres + x, j = ty * pr.rres + y; // texel of the reference's 2-D atlas image
@@ -108,8 +128,9 @@ template <bool PART> __global__ __launch_bounds__(MDH_BLOCK, MDH_WAVES_PER_SIMD)
    PrimaryHit ph;
    bool hit;
    f3 pos;
-   f3 c = MDH_SHADE<PART, 0>(sc, pr, cfg, valid, world, ray_dir, ph, hit, pos);
+   f3 c = MDH_SHADE<PART, 0, false, MDH_RAD_QVIS != 0>(sc, pr, cfg, valid, world, ray_dir, ph, hit, pos);
    if (valid) atlas_store(pr.rad, pr.fmt, atlas_index(pr.pcx, pr.rres, pr.rshift, i, j), c);
+   PH_KERNEL_END();
 }
 
 // -------------------------------------------------------------------- irradiance pass

@@ -18,6 +18,9 @@
 #ifndef MDH_SHARE_FIRST_STEP
 #define MDH_SHARE_FIRST_STEP 1
 #endif
+#ifndef MDH_TAP_EARLY
+#define MDH_TAP_EARLY 1
+#endif
 #ifndef MDH_SKIP_NULL_RAYS
 #define MDH_SKIP_NULL_RAYS 1
 #endif
@@ -52,6 +55,7 @@ MDH_DEV i3 cage_probe(const KProbes &pr, i3 gp, int i)
 // -DMDH_DIAG: per loop type, count SDF evaluations (wave level) and the lanes alive in them
 #ifdef MDH_DIAG
 __device__ unsigned long long g_diag[16];
+
 #define MDH_DIAG_STEP(type)                                                                 \
    do {                                                                                     \
       unsigned long long m_ = __ballot(1);                                                  \
@@ -62,6 +66,44 @@ __device__ unsigned long long g_diag[16];
    } while (0)
 #else
 #define MDH_DIAG_STEP(type) do { } while (0)
+#endif
+// -DMDH_PHASES: wall cycles (s_memtime) per wave spent in each region of the pixel program, summed over waves
+#ifdef MDH_PHASES
+__device__ unsigned long long g_phase[16];
+#define MDH_PH_SLOT 18 // one extra park slot: 32 u64 accumulators per wave
+MDH_DEV unsigned long long *ph_acc_(float *pk) { return (unsigned long long *)(pk + MDH_PH_SLOT * MDH_BLOCK + (threadIdx.x & ~63)); }
+MDH_DEV void ph_add_(float *pk, int id, unsigned long long dt)
+{
+   if ((int)(threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) ph_acc_(pk)[id] += dt;
+}
+#define PH_T0(v) unsigned long long v = __builtin_amdgcn_s_memtime()
+#define PH_ADD(v, id) do { unsigned long long n_ = __builtin_amdgcn_s_memtime(); ph_add_(pk, id, n_ - v); v = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define PH_T0(v) do { } while (0)
+#define PH_ADD(v, id) do { } while (0)
+#endif
+#ifdef MDH_TIMELINE
+// wave timeline: [wave] = {start, end} in s_memrealtime ticks (100 MHz), {evals, hw id}
+#define MDH_DIAG_WAVES 65536
+__device__ unsigned long long g_wave_t[MDH_DIAG_WAVES * 3];
+struct DiagWaveTimer {
+   long wave;
+   unsigned long long t0;
+   __device__ DiagWaveTimer(long w) : wave(w), t0(__builtin_amdgcn_s_memrealtime()) {}
+   __device__ ~DiagWaveTimer()
+   {
+      if ((threadIdx.x & 63) == 0 && wave < MDH_DIAG_WAVES) {
+         g_wave_t[3 * wave] = t0;
+         g_wave_t[3 * wave + 1] = __builtin_amdgcn_s_memrealtime();
+         unsigned hw;
+         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+         g_wave_t[3 * wave + 2] = hw;
+      }
+   }
+};
+#define MDH_DIAG_WAVE(w) DiagWaveTimer diag_wave_timer_(w)
+#else
+#define MDH_DIAG_WAVE(w) do { } while (0)
 #endif
 
 // raymarching.glsl:25-51: plain sphere trace until a hit or tmax; `steps` counts SDF evaluations
@@ -88,7 +130,11 @@ template <bool PART> MDH_DEV bool march_plain(const KScene &sc, f3 o, f3 d, floa
 // irradiance -- is cold while the reflection's point is shaded: parking it takes 15 VGPRs
 // out of the live set of the inner loops, where hipcc would otherwise spill them to scratch
 // (HBM round trips inside the probe loop; measured 47 % of the wave's cycles waiting).
-#define MDH_PARK_DWORDS 16
+#ifdef MDH_PHASES
+#define MDH_PARK_DWORDS 19
+#else
+#define MDH_PARK_DWORDS 18
+#endif
 MDH_DEV float *park_base(const KScene &sc) { return (float *)(s_tab + sc.table_f4); }
 MDH_DEV void park_store3(float *pk, int slot, f3 v)
 {
@@ -101,7 +147,102 @@ MDH_DEV f3 park_load3(const float *pk, int slot)
    return F3(pk[(slot + 0) * MDH_BLOCK + threadIdx.x], pk[(slot + 1) * MDH_BLOCK + threadIdx.x], pk[(slot + 2) * MDH_BLOCK + threadIdx.x]);
 }
 
-template <bool PART, int MODE>
+
+// ---------------------------------------------------------------------------------------------
+// queued_visibility -- the probe-visibility rays of the wave's 64 shaded points as ONE queue.
+//
+// In lock step a wave pays, for each of the 8 cage corners, the longest visibility ray among
+// its lanes, while folded corners and rays that end at once leave lanes empty: the radiance
+// pass ran its visibility marches at 15 of 64 lanes.  Here every lane first lists the rays its
+// point really needs (corner i of lane l = entry l | i << 6, appended with a ballot prefix sum),
+// then the wave marches the list with ray REPLACEMENT: a lane whose ray has ended takes the
+// next entry, re-deriving origin, direction and length from the owner lane's parked P, N and
+// first-step distance (bit for bit the arithmetic of the lock-step loop), and ORs the
+// result into the owner's visibility word.  Results per ray are unchanged; only the schedule is.
+//
+// LDS: entries are u16 in park slots 12..15 of the wave (free until the irradiance is parked),
+// slot 16 = first-step distance, slot 17 = visibility word.
+// ---------------------------------------------------------------------------------------------
+#ifndef MDH_QVIS_REFILL
+#define MDH_QVIS_REFILL 16 // idle lanes that trigger a refill
+#endif
+MDH_DEV unsigned short *qvis_entry(float *pk, int wbase, int j)
+{
+   return (unsigned short *)(pk + (12 + (j >> 7)) * MDH_BLOCK + wbase) + (j & 127);
+}
+template <bool PART>
+MDH_DEV int queued_visibility(const KScene &sc, const KProbes &pr, float *pk, f3 P, f3 N, i3 gp, int folded, float sd0)
+{
+   const int lane = threadIdx.x & 63, wbase = threadIdx.x & ~63;
+   int *words = (int *)(pk + 17 * MDH_BLOCK);
+   pk[16 * MDH_BLOCK + threadIdx.x] = sd0;
+   words[threadIdx.x] = 0;
+   int bits = 0, njobs = 0;
+#pragma unroll 1
+   for (int i = 0; i < 8; ++i) {
+      bool need = false;
+      if (!(i & folded)) {
+         const f3 hvec = grid_to_world(pr, cage_probe(pr, gp, i)) - P;
+         const float vmax = length(hvec) - MDH_MIN_STEP * 5.0f;
+         // raycast_visibility (raymarching.glsl:39-56) whose first step is known: sd0 at t = 0
+         if (!(0.0f < vmax)) bits |= 1 << i;     // the loop is never entered
+         else if (sd0 < MDH_EPS) { }             // blocked at once
+         else if (!(sd0 < vmax)) bits |= 1 << i; // the first step already passes the probe
+         else need = true;
+      }
+      const unsigned long long m = __ballot(need);
+      if (need) *qvis_entry(pk, wbase, njobs + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))) = (unsigned short)(lane | (i << 6));
+      njobs += __popcll(m);
+   }
+   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+   __builtin_amdgcn_wave_barrier();
+   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+   int head = 0, job = -1;
+   float total = 0.0f, vmax = 0.0f;
+   f3 o = F3(0.0f, 0.0f, 0.0f), d = F3(0.0f, 0.0f, 0.0f);
+   for (;;) {
+      const unsigned long long idle = __ballot(job < 0);
+      const int n_idle = __popcll(idle);
+      if (head < njobs && n_idle >= MDH_QVIS_REFILL) {
+         if (job < 0) {
+            const int my = head + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(idle >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)idle, 0u));
+            if (my < njobs) {
+               const int e = *qvis_entry(pk, wbase, my);
+               const int owner = wbase + (e & 63), corner = e >> 6;
+               const f3 oP = F3(pk[0 * MDH_BLOCK + owner], pk[1 * MDH_BLOCK + owner], pk[2 * MDH_BLOCK + owner]);
+               const f3 oN = F3(pk[3 * MDH_BLOCK + owner], pk[4 * MDH_BLOCK + owner], pk[5 * MDH_BLOCK + owner]);
+               const f3 hvec = grid_to_world(pr, cage_probe(pr, world_to_grid(pr, oP), corner)) - oP;
+               const float dist = length(hvec);
+               d = hvec / dist;
+               vmax = dist - MDH_MIN_STEP * 5.0f;
+               o = oP + (oN * MDH_MIN_STEP) * 5.0f;
+               total = pk[16 * MDH_BLOCK + owner];
+               job = e;
+            }
+         }
+         head += n_idle;
+      }
+      if (__ballot(job >= 0) == 0ull) break;
+      if (job >= 0) {
+         MDH_DIAG_STEP(3);
+         const float sd = sdf<PART>(sc, o + d * total);
+         if (sd < MDH_EPS) job = -1; // blocked: the bit stays 0
+         else {
+            total += sd;
+            if (!(total < vmax)) {
+               atomicOr(&words[wbase + (job & 63)], 1 << (job >> 6));
+               job = -1;
+            }
+         }
+      }
+   }
+   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+   __builtin_amdgcn_wave_barrier();
+   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+   return bits | words[threadIdx.x];
+}
+
+template <bool PART, int MODE, bool REFLECT, bool QVIS>
 MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCfg cfg, bool lane_valid, f3 from, f3 dir_in,
                             PrimaryHit &ph, bool &hit, f3 &pos_out)
 {
@@ -117,11 +258,13 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
    bool active = lane_valid;
    park_store3(pk, 6, dir_in);
 #pragma unroll 1
-   for (int ctx = 0; ctx < 2; ++ctx) {
+   for (int ctx = 0; ctx < (REFLECT ? 2 : 1); ++ctx) {
       if (active) {
          float t;
          int steps;
+         PH_T0(pt);
          const bool h = march_plain<PART>(sc, ro, rd, sc.max_dist, t, steps);
+         PH_ADD(pt, 0);
          if (ctx == 0) { hit = h; ph.steps = steps; }
          active = false; // a miss ends the chain (ctx 1: specular_col stays 0, render_probes.glsl:142-144)
          if (h) {
@@ -137,6 +280,7 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
                park_store3(pk, 0, P);
                park_store3(pk, 3, N);
             }
+            PH_ADD(pt, 1);
             if (MODE != 1) {
                const f3 from_off = P + (N * MDH_MIN_STEP) * 5.0f;
                // Every shadow and probe-visibility ray of this point starts AT from_off with t = 0, so
@@ -159,6 +303,7 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
                      if (ctx == 0 && !cfg.direct_specular) kS = F3(0.0f, 0.0f, 0.0f);
                      const f3 contrib = (((kD * m.albedo) / MDH_PI + kS) * radiance) * NdotL;
                      float shadows = 0.0f;
+                     PH_ADD(pt, 2);
                      // a light that contributes exactly nothing here (outside a spot's cone, black BRDF)
                      // needs no shadow ray: Lo + (+-0) * shadows = Lo for every shadows in [0, 1]
                      const bool lit = MDH_SKIP_NULL_RAYS ? (contrib.x != 0.0f || contrib.y != 0.0f || contrib.z != 0.0f) : true;
@@ -184,6 +329,7 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
                         shadows = blocked ? 0.0f : res;
                      }
                      Lo = Lo + contrib * shadows;
+                     PH_ADD(pt, 3);
                   }
                }
                if (ctx == 0) park_store3(pk, 9, Lo); // = direct
@@ -204,6 +350,9 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
                   const int folded = ((gp.x < 0 || gp.x >= pr.gx - 1) ? 1 : 0) | ((gp.y < 0 || gp.y >= pr.gy - 1) ? 2 : 0) |
                                      ((gp.z < 0 || gp.z >= pr.gz - 1) ? 4 : 0);
                   int vis_bits = 0; // bit i: visibility of corner i
+                  PH_ADD(pt, 2);
+                  if (QVIS && ctx == 0) vis_bits = queued_visibility<PART>(sc, pr, pk, P, N, gp, folded, sd0);
+                  PH_ADD(pt, 5);
 #pragma unroll 1
                   for (int i = 0; i < 8; ++i) {
                      const i3 q = cage_probe(pr, gp, i);
@@ -212,9 +361,25 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
                      const float dist = length(hvec);
                      f3 vd = hvec / dist; // ctx 0: dir_to_probe, ctx 1: probe_to_spec
                      if (ctx) vd = -vd;   // the visibility ray always runs from the point to the probe
+#if MDH_TAP_EARLY
+                     // the irradiance tap of this corner (render_probes.glsl:44-58) depends on the probe and
+                     // N only: its texel loads go out now and land while the visibility ray is marched
+                     AtlasTap tap;
+                     if (ctx == 0) {
+                        const float irr_min = 0.5f / (float)pr.ires, irr_max = 1.0f - irr_min;
+                        f2 rid = ray_dir_to_ray_id(N);
+                        rid = F2(clamp_(rid.x, irr_min, irr_max), clamp_(rid.y, irr_min, irr_max));
+                        const f2 base = probe_id_to_coord(pr, grid_to_probe_id(pr, q));
+                        tap = atlas_tap_issue(pr.irr, pr.fmt, pr.pcx, pr.pcy, pr.ires, pr.ishift, base.x + rid.x / (float)pr.pcx, base.y + rid.y / (float)pr.pcy);
+                     }
+#endif
                      // raycast_visibility, raymarching.glsl:39-56
                      float vis = 1.0f, total = 0.0f;
                      float vmax = dist - MDH_MIN_STEP * 5.0f;
+                     if (QVIS && ctx == 0) { // every distinct corner was traced by queued_visibility
+                        vis = ((vis_bits >> (i & ~folded)) & 1) ? 1.0f : 0.0f;
+                        vmax = 0.0f;
+                     }
 #if MDH_REUSE_FOLDED
                      if (i & folded) { // same probe as corner i & ~folded, already traced
                         vis = ((vis_bits >> (i & ~folded)) & 1) ? 1.0f : 0.0f;
@@ -231,6 +396,8 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
                      if (false)
 #endif
                      bool first = MDH_SHARE_FIRST_STEP != 0;
+                     PH_ADD(pt, 4);
+                     if (!(QVIS && !REFLECT)) // (with the queue and no second point this loop is dead code)
                      while (total < vmax) {
                         MDH_DIAG_STEP(3 + ctx);
                         float sd = first ? sd0 : sdf<PART>(sc, from_off + vd * total);
@@ -239,6 +406,7 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
                         total += sd;
                      }
                      vis_bits |= (vis != 0.0f ? 1 : 0) << i;
+                     PH_ADD(pt, 5);
                      if (ctx == 0) { // render_probes.glsl:26-62
                         float angle = (dot(vd, N) + 1.0f) * 0.5f;
                         float weight = angle * angle + 0.2f;
@@ -255,6 +423,8 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
                         f2 base = probe_id_to_coord(pr, grid_to_probe_id(pr, q));
 #ifdef MDH_ABL_NO_TAPS
                         f3 tx = F3(base.x, base.y, rid.x);
+#elif MDH_TAP_EARLY
+                        f3 tx = atlas_tap_resolve(pr.irr, pr.fmt, tap, u8_tab);
 #else
                         f3 tx = atlas_sample(pr.irr, pr.fmt, pr.pcx, pr.pcy, pr.ires, pr.ishift, base.x + rid.x / (float)pr.pcx, base.y + rid.y / (float)pr.pcy, u8_tab);
 #endif
@@ -265,6 +435,7 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
                         weight *= vis;
                         if (weight > accw) { accw = weight; best_q = q.x | (q.y << 10) | (q.z << 20); acc = -vd; }
                      }
+                     PH_ADD(pt, 6);
                   }
                   if (ctx == 0) {
                      // render_probes.glsl:65-66 (0/0 fixed as 0)
@@ -289,12 +460,14 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
                      f3 radiance = atlas_sample(pr.rad, pr.fmt, pr.pcx, pr.pcy, pr.rres, pr.rshift, base.x + brid.x / (float)pr.pcx, base.y + brid.y / (float)pr.pcy, u8_tab);
                      specular_col = radiance + specular_col;
                   }
+                  PH_ADD(pt, 7);
                }
             }
          }
       }
    }
    // ---- everything parked comes back for the combine
+   PH_T0(pc);
    const f3 dir = park_load3(pk, 6);
    f3 result;
    pos_out = F3(0.0f, 0.0f, 0.0f);
@@ -331,5 +504,6 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
          result = direct * ao;
       }
    }
+   PH_ADD(pc, 8);
    return result;
 }

@@ -95,6 +95,9 @@ class ShardedFrame:
 
     def Render(self):
         R = self.R
+        if self.world == 1:  # nothing to exchange: the library's own frame (which may pipeline frames)
+            R.Render()
+            return
         if R.Get_Option(B.OPT_SCREEN_MODE) == 0:
             R.Render_Pass(B.PASS_RADIANCE)
             if self.world > 1:
