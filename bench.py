@@ -110,6 +110,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mode", type=int, default=None, help="override the screen mode (ablation runs only)")
     ap.add_argument("--serial", action="store_true", help="MDH_OPT_FRAME_OVERLAP = 0: one pass after the other (per-kernel timing runs)")
+    ap.add_argument("--overlap", type=int, default=None, help="MDH_OPT_FRAME_OVERLAP value (default: the library's)")
     args = ap.parse_args()
 
     import torch
@@ -136,6 +137,8 @@ def main():
         R.Set_Option(B.OPT_SCREEN_MODE, args.mode)
     if args.serial:
         R.Set_Option(B.OPT_FRAME_OVERLAP, 0)
+    elif args.overlap is not None:
+        R.Set_Option(B.OPT_FRAME_OVERLAP, args.overlap)
     exchange = sharding.DeviceExchange(dist, R, torch.device("cuda", local_rank)) if world > 1 else None
     frame = sharding.ShardedFrame(R, rank, world, exchange)
 
@@ -186,7 +189,7 @@ def main():
             "config": {"workload": args.workload, "scene": scene, "width": W, "height": H,
                        "probe_grid": "8x8x8" if probes == "gi8" else "4x3x3", "atlas": args.atlas,
                        "screen_mode": mode, "parallelism": "tiles+probes/%d" % world,
-                       "frame_overlap": bool(world == 1 and not args.serial and R.Get_Option(B.OPT_FRAME_OVERLAP))},
+                       "frame_overlap": R.Get_Option(B.OPT_FRAME_OVERLAP) if world == 1 else 0},
             "roofline": {"bound": "hbm", "kernel": "k_screen", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": int(alg_bytes), "bytes_per_pixel": per_px,

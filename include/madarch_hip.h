@@ -129,11 +129,15 @@ enum {
    /* Eval_Distance_To arithmetic: 1 = reproduce Madarch.Values."/" on floats
     * (L + R, madarch-values.adb:112) as the Ada evaluator does; 0 = GLSL "/" */
    MDH_OPT_ADA_EVAL_DIV = 7,
-   /* 1 (default) = mdh_render may overlap the probe passes of a frame with the
-    * screen pass of the frame before it (second HIP stream, two atlas sets; same
-    * results as the serial order, madarch-renderers.adb:302-321); 0 = strictly
-    * one pass after the other.  Ignored (serial) for sharded renderers and on a
-    * caller-supplied stream. */
+   /* how mdh_render schedules consecutive frames (madarch-renderers.adb:302-321;
+    * the results are those of the serial order in every case):
+    *   0 = strictly one pass after the other;
+    *   1 = the probe passes of a frame overlap the screen pass of the frame before
+    *       it (second HIP stream, two atlas sets);
+    *   2 (default) = also the screen passes of consecutive frames overlap (third
+    *       stream, two framebuffers; falls back to 1 with volumetrics or the
+    *       geometry buffer).
+    * Sharded renderers and renderers on a caller-supplied stream run serially. */
    MDH_OPT_FRAME_OVERLAP = 8
 };
 

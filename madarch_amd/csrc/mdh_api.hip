@@ -136,13 +136,17 @@ struct mdh_renderer {
    // other set while the previous frame's screen pass still reads this one, then flips.
    void *d_rad2[2] = {nullptr, nullptr}, *d_irr2[2] = {nullptr, nullptr};
    int last = 0;
-   int opt_overlap = 1;
+   int opt_overlap = 2;
    hipStream_t probe_stream = nullptr;   // radiance + irradiance passes of pipelined frames
-   hipEvent_t ev_screen[2] = {nullptr, nullptr}, ev_probe = nullptr, ev_join = nullptr;
+   hipStream_t alt_stream = nullptr;     // screen pass of every other pipelined frame
+   hipEvent_t ev_screen[2] = {nullptr, nullptr}, ev_probe[2] = {nullptr, nullptr}, ev_join = nullptr, ev_join_alt = nullptr;
    bool ev_screen_valid[2] = {false, false};
+   bool alt_pending = false; // work on alt_stream that `stream` has not been ordered after yet
    bool main_dirty = true; // work went to `stream` outside a pipelined frame since the probe stream last joined it
    float *d_vis = nullptr;
-   float4 *d_scat = nullptr, *d_fb = nullptr;
+   float4 *d_scat = nullptr;
+   float4 *d_fb2[2] = {nullptr, nullptr}; // two framebuffers: consecutive pipelined frames draw on two streams
+   int fb_last = 0;                       // the one the most recent frame drew
    int *d_gb_index = nullptr, *d_gb_steps = nullptr;
    float *d_gb_t = nullptr;
    KScene ks{};
@@ -155,6 +159,16 @@ struct mdh_renderer {
    hipStream_t own_stream = nullptr;
 };
 
+// Order `stream` after everything pipelined frames put on the alternate screen stream (which
+// itself waited for the probe stream): called before any operation outside a pipelined frame.
+static int join_main(mdh_renderer *r)
+{
+   if (!r->alt_pending) return MDH_OK;
+   HIP_TRY(hipEventRecord(r->ev_join_alt, r->alt_stream));
+   HIP_TRY(hipStreamWaitEvent(r->stream, r->ev_join_alt, 0));
+   r->alt_pending = false;
+   return MDH_OK;
+}
 static hipEvent_t get_event(mdh_renderer *r)
 {
    if (!r->free_events.empty()) { hipEvent_t e = r->free_events.back(); r->free_events.pop_back(); return e; }
@@ -166,6 +180,7 @@ static hipEvent_t get_event(mdh_renderer *r)
 static int resolve_timing(mdh_renderer *r)
 {
    if (r->pending.empty()) return MDH_OK;
+   { int jr = join_main(r); if (jr != MDH_OK) return jr; }
    HIP_TRY(hipStreamSynchronize(r->stream));
    for (auto &p : r->pending) {
       float ms = 0.0f;
@@ -367,15 +382,17 @@ extern "C" int32_t mdh_destroy(mdh_renderer *r)
    if (!r) return MDH_OK;
    (void)hipSetDevice(r->device);
    if (r->probe_stream) (void)hipStreamSynchronize(r->probe_stream);
+   if (r->alt_stream) (void)hipStreamSynchronize(r->alt_stream);
    if (r->stream) (void)hipStreamSynchronize(r->stream);
-   void *ptrs[] = {r->d_table, r->d_part, r->d_warn, r->d_rad2[0], r->d_irr2[0], r->d_rad2[1], r->d_irr2[1], r->d_vis, r->d_scat, r->d_fb, r->d_gb_index, r->d_gb_steps, r->d_gb_t};
+   void *ptrs[] = {r->d_table, r->d_part, r->d_warn, r->d_rad2[0], r->d_irr2[0], r->d_rad2[1], r->d_irr2[1], r->d_vis, r->d_scat, r->d_fb2[0], r->d_fb2[1], r->d_gb_index, r->d_gb_steps, r->d_gb_t};
    for (void *p : ptrs)
       if (p) (void)hipFree(p);
    for (auto &p : r->pending) { (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1); }
    for (auto e : r->free_events) (void)hipEventDestroy(e);
-   for (hipEvent_t e : {r->ev_screen[0], r->ev_screen[1], r->ev_probe, r->ev_join})
+   for (hipEvent_t e : {r->ev_screen[0], r->ev_screen[1], r->ev_probe[0], r->ev_probe[1], r->ev_join, r->ev_join_alt})
       if (e) (void)hipEventDestroy(e);
    if (r->probe_stream) (void)hipStreamDestroy(r->probe_stream);
+   if (r->alt_stream) (void)hipStreamDestroy(r->alt_stream);
    if (r->own_stream) (void)hipStreamDestroy(r->own_stream);
    delete r;
    return MDH_OK;
@@ -447,16 +464,21 @@ extern "C" int32_t mdh_create(int32_t width, int32_t height, const mdh_scene_des
    {
       int lo = 0, hi = 0; // numerically lower = higher priority
       TRY_OR_FAIL(hipDeviceGetStreamPriorityRange(&lo, &hi));
-      const char *pe = getenv("MADARCH_HIP_PROBE_PRIORITY"); // experiments: -1 high, 0 default, 1 low
-      int prio = pe ? atoi(pe) : 0;
+      // the probe passes are the head of each frame's dependency chain: high priority (measured on MI355X:
+      // 3340 vs 3300 Mpix/s at BASELINE config 3).  MADARCH_HIP_PROBE_PRIORITY = -1 high, 0 default, 1 low
+      const char *pe = getenv("MADARCH_HIP_PROBE_PRIORITY");
+      int prio = pe ? atoi(pe) : -1;
       prio = prio < 0 ? hi : (prio > 0 ? lo : 0);
       TRY_OR_FAIL(hipStreamCreateWithPriority(&r->probe_stream, hipStreamNonBlocking, prio));
-      for (hipEvent_t *e : {&r->ev_screen[0], &r->ev_screen[1], &r->ev_probe, &r->ev_join}) TRY_OR_FAIL(hipEventCreateWithFlags(e, hipEventDisableTiming));
+      TRY_OR_FAIL(hipStreamCreateWithFlags(&r->alt_stream, hipStreamNonBlocking));
+      for (hipEvent_t *e : {&r->ev_screen[0], &r->ev_screen[1], &r->ev_probe[0], &r->ev_probe[1], &r->ev_join, &r->ev_join_alt}) TRY_OR_FAIL(hipEventCreateWithFlags(e, hipEventDisableTiming));
    }
    if ((rc = alloc_atlases(r)) != MDH_OK) return fail(rc);
    size_t px = (size_t)width * height;
-   TRY_OR_FAIL(hipMalloc(&r->d_fb, px * sizeof(float4)));
-   TRY_OR_FAIL(hipMemsetAsync(r->d_fb, 0, px * sizeof(float4), r->stream));
+   for (int s = 0; s < 2; ++s) {
+      TRY_OR_FAIL(hipMalloc(&r->d_fb2[s], px * sizeof(float4)));
+      TRY_OR_FAIL(hipMemsetAsync(r->d_fb2[s], 0, px * sizeof(float4), r->stream));
+   }
    TRY_OR_FAIL(hipMalloc(&r->d_gb_index, px * 4));
    TRY_OR_FAIL(hipMalloc(&r->d_gb_steps, px * 4));
    TRY_OR_FAIL(hipMalloc(&r->d_gb_t, px * 4));
@@ -486,6 +508,7 @@ extern "C" int32_t mdh_set_option(mdh_renderer *r, int32_t option, int32_t value
       if (value != 0 && value != 1) return seterr(MDH_E_INVALID, "atlas format is 0 (RGB8) or 1 (fp32)");
       if (value != r->opt_atlas) {
          HIP_TRY(hipSetDevice(r->device));
+         { int jr = join_main(r); if (jr != MDH_OK) return jr; }
          HIP_TRY(hipStreamSynchronize(r->stream));
          r->opt_atlas = value;
          int rc = alloc_atlases(r);
@@ -499,7 +522,7 @@ extern "C" int32_t mdh_set_option(mdh_renderer *r, int32_t option, int32_t value
    case MDH_OPT_WORLD: if (value < 1) return seterr(MDH_E_INVALID, "world < 1"); r->opt_world = value; break;
    case MDH_OPT_TIMING: r->opt_timing = value ? 1 : 0; break;
    case MDH_OPT_ADA_EVAL_DIV: r->opt_ada_div = value ? 1 : 0; break;
-   case MDH_OPT_FRAME_OVERLAP: r->opt_overlap = value ? 1 : 0; break;
+   case MDH_OPT_FRAME_OVERLAP: if (value < 0 || value > 2) return seterr(MDH_E_INVALID, "frame overlap is 0, 1 or 2"); r->opt_overlap = value; break;
    default: return seterr(MDH_E_INVALID, "unknown option");
    }
    return MDH_OK;
@@ -600,7 +623,11 @@ extern "C" int32_t mdh_set_camera_orientation(mdh_renderer *r, const float m[9])
 static int ensure_committed(mdh_renderer *r)
 {
    HIP_TRY(hipSetDevice(r->device));
-   if (r->table_dirty) return commit_scene(r);
+   if (r->table_dirty) {
+      int jr = join_main(r); // commit_scene drains `stream`: order it after the other streams first
+      if (jr != MDH_OK) return jr;
+      return commit_scene(r);
+   }
    return MDH_OK;
 }
 static size_t lds_bytes(const mdh_renderer *r) { return (size_t)r->ks.table_f4 * sizeof(float4); }
@@ -615,6 +642,8 @@ extern "C" int32_t mdh_update_partitioning(mdh_renderer *r, int32_t method)
    if (method < 0 || method > 2) return seterr(MDH_E_INVALID, "bad method");
    int rc = ensure_committed(r);
    if (rc != MDH_OK) return rc;
+   if ((rc = join_main(r)) != MDH_OK) return rc;
+   r->main_dirty = true;
    PartBuildArgs a;
    a.method = method;
    const int *d = r->part.grid_dimensions;
@@ -653,8 +682,9 @@ template <bool PART> static void launch_screen_m(mdh_renderer *r, hipStream_t st
 
 // One pass on stream `st`.  The radiance pass reads the irradiance atlas of set `src` and writes the
 // radiance atlas of set `dst`; every other pass works on set `dst` (in place: src == dst == r->last).
-static int run_pass(mdh_renderer *r, int pass, hipStream_t st, int src, int dst)
+static int run_pass(mdh_renderer *r, int pass, hipStream_t st, int src, int dst, int fbix = -1)
 {
+   if (fbix < 0) fbix = r->fb_last;
    const bool part = r->part.enable != 0;
    KProbes pr = make_probes(r);
    pr.rad = r->d_rad2[dst];
@@ -716,8 +746,8 @@ static int run_pass(mdh_renderer *r, int pass, hipStream_t st, int src, int dst)
       a.n_tiles = a.tiles_x * ((r->H + 7) / 8);
       a.rank = r->opt_rank; a.world = r->opt_world;
       a.ao_steps = r->opt_ao;
-      a.fb = r->d_fb; a.gb_index = r->d_gb_index; a.gb_t = r->d_gb_t; a.gb_steps = r->d_gb_steps;
-      if (a.world > 1) HIP_TRY(hipMemsetAsync(r->d_fb, 0, (size_t)r->W * r->H * sizeof(float4), st)); // other ranks' tiles read 0
+      a.fb = r->d_fb2[fbix]; a.gb_index = r->d_gb_index; a.gb_t = r->d_gb_t; a.gb_steps = r->d_gb_steps;
+      if (a.world > 1) HIP_TRY(hipMemsetAsync(r->d_fb2[fbix], 0, (size_t)r->W * r->H * sizeof(float4), st)); // other ranks' tiles read 0
       int own_tiles = (a.n_tiles - a.rank + a.world - 1) / a.world;
       if (own_tiles > 0) {
          int blocks = (own_tiles + (MDH_BLOCK / 64) - 1) / (MDH_BLOCK / 64);
@@ -742,22 +772,27 @@ extern "C" int32_t mdh_render_pass(mdh_renderer *r, int32_t pass)
    if (!r) return seterr(MDH_E_INVALID, "null renderer");
    int rc = ensure_committed(r);
    if (rc != MDH_OK) return rc;
+   if ((rc = join_main(r)) != MDH_OK) return rc;
    r->main_dirty = true;
    return run_pass(r, pass, r->stream, r->last, r->last);
 }
 // Render (renderers.adb:302-321).
 //
-// Frame overlap (MDH_OPT_FRAME_OVERLAP, on by default, single-GPU renderers on their own stream):
-// the probe passes of frame N+1 do not depend on the screen pass of frame N -- they need the
-// irradiance atlas frame N produced and nothing else -- so they run on a second HIP stream into
-// the other atlas set while screen(N) is still drawing.  The radiance pass ends in a long tail
-// of a few slow wavefronts and the irradiance pass fills a fraction of the chip; the screen pass of
-// the previous frame fills those holes.  Per frame and atlas set `cur`:
-//    probe stream: wait screen(N-2) (last reader of set cur) -> radiance(irr[last] -> rad[cur])
-//                  -> irradiance(rad[cur] -> irr[cur]) -> ev_probe
-//    main stream:  wait ev_probe -> [volumetric passes] -> screen(set cur) -> ev_screen[cur]
-// Every later operation on the main stream is therefore ordered after all probe-stream work, and
-// the results are those of the serial order bit for bit.
+// Frame overlap (MDH_OPT_FRAME_OVERLAP, on by default, single-GPU renderers on their own stream).
+// The probe passes of frame N+1 do not depend on the screen pass of frame N -- they need the
+// irradiance atlas frame N produced and nothing else -- and the screen passes of two frames are
+// independent of each other.  Every kernel of a frame ends in a tail of a few slow wavefronts
+// (the radiance pass spends more than half of its time below 20 % occupancy; the irradiance pass
+// fills a fraction of the chip), so serial frames leave the chip idle a good part of the time.
+// Pipelined frames use three HIP streams, two atlas sets and two framebuffers; frame N, parity c:
+//    probe stream: wait screen(N-2) (last reader of atlas set c)
+//                  -> radiance(irr[c^1] -> rad[c]) -> irradiance(rad[c] -> irr[c]) -> ev_probe[c]
+//    screen stream c (main / alternate): wait ev_probe[c] -> screen(atlas set c -> framebuffer c)
+// so that screen(N+1) starts while screen(N) drains and the probe passes of N+2 fill in behind.
+// With volumetrics or the geometry buffer (single buffers) all screen passes stay on the main
+// stream.  Anything outside a pipelined frame first orders the main stream after the others
+// (join_main), and the next pipelined frame orders the others after the main stream: results are
+// those of the serial order bit for bit.
 extern "C" int32_t mdh_render(mdh_renderer *r)
 {
    if (!r) return seterr(MDH_E_INVALID, "null renderer");
@@ -765,6 +800,7 @@ extern "C" int32_t mdh_render(mdh_renderer *r)
    if (rc != MDH_OK) return rc;
    const bool pipelined = r->opt_overlap && r->opt_mode == 0 && r->opt_world == 1 && r->stream == r->own_stream;
    if (!pipelined) {
+      if ((rc = join_main(r)) != MDH_OK) return rc;
       r->main_dirty = true;
       const int s = r->last;
       if (r->opt_mode == 0) {
@@ -778,31 +814,41 @@ extern "C" int32_t mdh_render(mdh_renderer *r)
       return run_pass(r, MDH_PASS_SCREEN, r->stream, s, s);
    }
    const int prev = r->last, cur = prev ^ 1;
-   if (r->main_dirty) { // the probe stream has to see everything that went to the main stream meanwhile
+   const bool dual = r->opt_overlap > 1 && !r->vol.enabled && !r->opt_gbuffer;
+   hipStream_t screen_stream = (dual && cur) ? r->alt_stream : r->stream;
+   const int fbix = dual ? cur : r->fb_last;
+   if (r->main_dirty) { // the other streams have to see everything that went to the main stream meanwhile
+      if ((rc = join_main(r)) != MDH_OK) return rc;
       HIP_TRY(hipEventRecord(r->ev_join, r->stream));
       HIP_TRY(hipStreamWaitEvent(r->probe_stream, r->ev_join, 0));
+      HIP_TRY(hipStreamWaitEvent(r->alt_stream, r->ev_join, 0));
       r->main_dirty = false;
-   } else if (r->ev_screen_valid[cur]) {
-      HIP_TRY(hipStreamWaitEvent(r->probe_stream, r->ev_screen[cur], 0));
+   } else {
+      if (r->ev_screen_valid[cur]) HIP_TRY(hipStreamWaitEvent(r->probe_stream, r->ev_screen[cur], 0));
+      // single-buffered targets: a screen pass on the main stream after one on the alternate stream
+      if (!dual && r->alt_pending && (rc = join_main(r)) != MDH_OK) return rc;
    }
    if ((rc = run_pass(r, MDH_PASS_RADIANCE, r->probe_stream, prev, cur)) != MDH_OK) return rc;
    if ((rc = run_pass(r, MDH_PASS_IRRADIANCE, r->probe_stream, cur, cur)) != MDH_OK) return rc;
-   HIP_TRY(hipEventRecord(r->ev_probe, r->probe_stream));
-   HIP_TRY(hipStreamWaitEvent(r->stream, r->ev_probe, 0));
-   if (r->vol.enabled) {
-      if ((rc = run_pass(r, MDH_PASS_VISIBILITY, r->stream, cur, cur)) != MDH_OK) return rc;
-      if ((rc = run_pass(r, MDH_PASS_SCATTERING, r->stream, cur, cur)) != MDH_OK) return rc;
+   HIP_TRY(hipEventRecord(r->ev_probe[cur], r->probe_stream));
+   HIP_TRY(hipStreamWaitEvent(screen_stream, r->ev_probe[cur], 0));
+   if (r->vol.enabled) { // (never dual)
+      if ((rc = run_pass(r, MDH_PASS_VISIBILITY, screen_stream, cur, cur)) != MDH_OK) return rc;
+      if ((rc = run_pass(r, MDH_PASS_SCATTERING, screen_stream, cur, cur)) != MDH_OK) return rc;
    }
-   if ((rc = run_pass(r, MDH_PASS_SCREEN, r->stream, cur, cur)) != MDH_OK) return rc;
-   HIP_TRY(hipEventRecord(r->ev_screen[cur], r->stream));
+   if ((rc = run_pass(r, MDH_PASS_SCREEN, screen_stream, cur, cur, fbix)) != MDH_OK) return rc;
+   HIP_TRY(hipEventRecord(r->ev_screen[cur], screen_stream));
    r->ev_screen_valid[cur] = true;
    r->last = cur;
+   r->fb_last = fbix;
+   if (screen_stream == r->alt_stream) r->alt_pending = true;
    return MDH_OK;
 }
 extern "C" int32_t mdh_finish(mdh_renderer *r)
 {
    if (!r) return seterr(MDH_E_INVALID, "null renderer");
    HIP_TRY(hipSetDevice(r->device));
+   { int jr = join_main(r); if (jr != MDH_OK) return jr; }
    HIP_TRY(hipStreamSynchronize(r->stream));
    return resolve_timing(r);
 }
@@ -813,7 +859,8 @@ extern "C" int32_t mdh_read_framebuffer(mdh_renderer *r, float *rgb_out)
    HIP_TRY(hipSetDevice(r->device));
    size_t px = (size_t)r->W * r->H;
    std::vector<float4> tmp(px);
-   HIP_TRY(hipMemcpyAsync(tmp.data(), r->d_fb, px * sizeof(float4), hipMemcpyDeviceToHost, r->stream));
+   { int jr = join_main(r); if (jr != MDH_OK) return jr; }
+   HIP_TRY(hipMemcpyAsync(tmp.data(), r->d_fb2[r->fb_last], px * sizeof(float4), hipMemcpyDeviceToHost, r->stream));
    HIP_TRY(hipStreamSynchronize(r->stream));
    for (size_t i = 0; i < px; ++i) { rgb_out[3 * i] = tmp[i].x; rgb_out[3 * i + 1] = tmp[i].y; rgb_out[3 * i + 2] = tmp[i].z; }
    return MDH_OK;
@@ -823,6 +870,7 @@ extern "C" int32_t mdh_read_gbuffer(mdh_renderer *r, int32_t *index_out, float *
    if (!r) return seterr(MDH_E_INVALID, "null renderer");
    HIP_TRY(hipSetDevice(r->device));
    size_t n = (size_t)r->W * r->H * 4;
+   { int jr = join_main(r); if (jr != MDH_OK) return jr; }
    if (index_out) HIP_TRY(hipMemcpyAsync(index_out, r->d_gb_index, n, hipMemcpyDeviceToHost, r->stream));
    if (t_out) HIP_TRY(hipMemcpyAsync(t_out, r->d_gb_t, n, hipMemcpyDeviceToHost, r->stream));
    if (steps_out) HIP_TRY(hipMemcpyAsync(steps_out, r->d_gb_steps, n, hipMemcpyDeviceToHost, r->stream));
@@ -836,6 +884,7 @@ static int atlas_to_host(mdh_renderer *r, int tex, std::vector<float> &rgb)
    int res = tex == MDH_TEX_RADIANCE ? r->probes.radiance_resolution : r->probes.irradiance_resolution;
    size_t n = (size_t)probe_total(r) * res * res;
    void *src = tex == MDH_TEX_RADIANCE ? r->d_rad2[r->last] : r->d_irr2[r->last];
+   { int jr = join_main(r); if (jr != MDH_OK) return jr; }
    rgb.resize(n * 3);
    if (r->opt_atlas == 0) {
       std::vector<uchar4> tmp(n);
@@ -860,6 +909,7 @@ static float unorm8_host(float x)
 static int atlas_from_host(mdh_renderer *r, int tex, size_t first, size_t n, const float *rgb)
 {
    void *dst = tex == MDH_TEX_RADIANCE ? r->d_rad2[r->last] : r->d_irr2[r->last];
+   { int jr = join_main(r); if (jr != MDH_OK) return jr; }
    r->main_dirty = true;
    if (r->opt_atlas == 0) {
       std::vector<uchar4> tmp(n);
@@ -885,6 +935,7 @@ extern "C" int32_t mdh_read_texture(mdh_renderer *r, int32_t tex, float *out, in
 {
    if (!r || tex < 0 || tex > 3) return seterr(MDH_E_INVALID, "bad argument");
    HIP_TRY(hipSetDevice(r->device));
+   { int jr = join_main(r); if (jr != MDH_OK) return jr; }
    int W, H, C;
    if (tex == MDH_TEX_RADIANCE || tex == MDH_TEX_IRRADIANCE) {
       int res = tex == MDH_TEX_RADIANCE ? r->probes.radiance_resolution : r->probes.irradiance_resolution;
@@ -917,6 +968,8 @@ extern "C" int32_t mdh_write_texture(mdh_renderer *r, int32_t tex, const float *
 {
    if (!r || tex < 0 || tex > 3 || !in) return seterr(MDH_E_INVALID, "bad argument");
    HIP_TRY(hipSetDevice(r->device));
+   { int jr = join_main(r); if (jr != MDH_OK) return jr; }
+   r->main_dirty = true;
    int W, H, C;
    int rc = mdh_read_texture(r, tex, nullptr, &W, &H, &C);
    if (rc != MDH_OK) return rc;
@@ -966,6 +1019,7 @@ extern "C" int32_t mdh_atlas_device_ptr(mdh_renderer *r, int32_t tex, void **dpt
    int b, e;
    own_probes(r, &b, &e);
    int64_t per = (int64_t)res * res * (int64_t)texel_bytes(r);
+   { int jr = join_main(r); if (jr != MDH_OK) return jr; }
    if (dptr) *dptr = tex == MDH_TEX_RADIANCE ? r->d_rad2[r->last] : r->d_irr2[r->last];
    r->main_dirty = true; // the caller may write through the pointer
    if (total_bytes) *total_bytes = (int64_t)atlas_bytes(r, tex);
@@ -976,6 +1030,7 @@ extern "C" int32_t mdh_atlas_device_ptr(mdh_renderer *r, int32_t tex, void **dpt
 extern "C" int32_t mdh_stream(mdh_renderer *r, void **stream)
 {
    if (!r || !stream) return seterr(MDH_E_INVALID, "bad argument");
+   { int jr = join_main(r); if (jr != MDH_OK) return jr; } // the stream handed out is ordered after all work so far
    *stream = (void *)r->stream;
    return MDH_OK;
 }
@@ -983,6 +1038,8 @@ extern "C" int32_t mdh_set_stream(mdh_renderer *r, void *stream)
 {
    if (!r) return seterr(MDH_E_INVALID, "null renderer");
    HIP_TRY(hipSetDevice(r->device));
+   { int jr = join_main(r); if (jr != MDH_OK) return jr; }
+   r->main_dirty = true;
    HIP_TRY(hipStreamSynchronize(r->stream));
    int rc = resolve_timing(r);
    if (rc != MDH_OK) return rc;

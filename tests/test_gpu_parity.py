@@ -99,6 +99,46 @@ def test_sharded_frame_equals_whole_frame(hip):
     assert same_bits(Rs[1].Read_Texture(B.TEX_RADIANCE), whole["radiance"])
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("overlap,gbuffer,scene", [(1, 0, "global_illumination"), (2, 0, "global_illumination"), (2, 1, "global_illumination"),
+                                                   (2, 0, "light_shafts")])
+def test_pipelined_frames_equal_serial_frames(hip, overlap, gbuffer, scene):
+    """MDH_OPT_FRAME_OVERLAP only reschedules: bursts of pipelined frames (three streams, two atlas sets,
+    two framebuffers) with camera and scene edits, single passes and read-backs in between give what
+    the strictly serial renderer gives, bit for bit, at every point where something is read."""
+    from madarch_amd.primitives import spheres
+
+    def drive(level):
+        R = make(scene, 200, 120, hip, probes=SMALL_PROBES)
+        R.Set_Option(B.OPT_GBUFFER, gbuffer)
+        R.Set_Option(B.OPT_FRAME_OVERLAP, level)
+        seen = []
+        for burst in range(4):
+            for f in range(1 + 2 * burst):  # 1, 3, 5, 7 frames without a host read in between
+                R.Set_Camera_Position((2.0 + 0.05 * f, 2.0, 0.1 * burst))
+                R.Render()
+            seen.append(R.Read_Framebuffer())
+            seen.append(R.Read_Texture(B.TEX_IRRADIANCE))
+            if burst == 1:  # a scene edit drains the pipeline
+                R.Set_Primitive(spheres.Sphere, 1, spheres.Create((2.5, 3.0, 3.0), 0.9, 4))
+            if burst == 2:  # single passes work in place on the atlas set the last frame wrote
+                R.Render_Pass(B.PASS_RADIANCE)
+                R.Render_Pass(B.PASS_IRRADIANCE)
+                R.Render_Pass(B.PASS_SCREEN)
+                seen.append(R.Read_Framebuffer())
+                seen.append(R.Read_Texture(B.TEX_RADIANCE))
+        R.Render()
+        R.Render()
+        seen.append(R.Read_Texture(B.TEX_RADIANCE))
+        seen.append(R.Read_Framebuffer())
+        return seen
+
+    serial, piped = drive(0), drive(overlap)
+    assert len(serial) == len(piped)
+    for i, (a, b) in enumerate(zip(serial, piped)):
+        assert same_bits(a, b), "output %d differs between the serial and the pipelined schedule" % i
+
+
 # ---------------------------------------------------------------- BASELINE.json's full size
 @pytest.fixture(scope="module")
 def full_size(hip):
