@@ -339,6 +339,8 @@ static KProbes make_probes(const mdh_renderer *r)
    p.fmt = r->opt_atlas;
    auto log2_or_neg = [](int v) { int s = 0; while ((1 << s) < v) ++s; return (1 << s) == v ? s : -1; };
    p.rshift = log2_or_neg(p.rres); p.ishift = log2_or_neg(p.ires); p.pcx_shift = log2_or_neg(p.pcx);
+   p.inv_pcx = log2_or_neg(p.pcx) >= 0 ? 1.0f / (float)p.pcx : 0.0f;
+   p.inv_pcy = log2_or_neg(p.pcy) >= 0 ? 1.0f / (float)p.pcy : 0.0f;
    p.rad = r->d_rad2[r->last]; p.irr = r->d_irr2[r->last];
    own_probes(r, &p.probe_begin, &p.probe_end);
    return p;

@@ -83,6 +83,7 @@ struct KProbes {
    int rres, ires;    // radiance / irradiance resolution
    int fmt;           // 0 = RGBA8 unorm texels, 1 = float4 texels
    int rshift, ishift, pcx_shift; // log2 of rres / ires / pcx when a power of two, else -1
+   float inv_pcx, inv_pcy;        // 1 / pcx, 1 / pcy when a power of two (x / 2^k == x * 2^-k exactly), else 0
    void *rad;         // probe-major [probe][y][x]
    void *irr;
    int probe_begin, probe_end; // slice this rank updates
@@ -616,10 +617,13 @@ MDH_DEV i3 world_to_grid(const KProbes &pr, f3 p)
    return g;
 }
 MDH_DEV int grid_to_probe_id(const KProbes &pr, i3 g) { return g.z * pr.gx * pr.gy + g.y * pr.gx + g.x; }
+// x / probe_count: a multiplication when the count is a power of two (exact: the same real value, rounded once)
+MDH_DEV float div_pcx(const KProbes &pr, float x) { return pr.inv_pcx != 0.0f ? x * pr.inv_pcx : x / (float)pr.pcx; }
+MDH_DEV float div_pcy(const KProbes &pr, float y) { return pr.inv_pcy != 0.0f ? y * pr.inv_pcy : y / (float)pr.pcy; }
 MDH_DEV f2 probe_id_to_coord(const KProbes &pr, int id)
 {
    int y = pr.pcx_shift >= 0 ? (id >> pr.pcx_shift) : (id / pr.pcx), x = id - y * pr.pcx;
-   return F2((float)x / (float)pr.pcx, (float)y / (float)pr.pcy);
+   return F2(div_pcx(pr, (float)x), div_pcy(pr, (float)y));
 }
 // glsl/probe_utils.glsl:58-92
 MDH_DEV float sign_not_zero(float v) { return v >= 0.0f ? 1.0f : -1.0f; }

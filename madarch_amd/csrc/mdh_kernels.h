@@ -27,7 +27,7 @@
 #define MDH_SCR_QVIS 0
 #endif
 #ifndef MDH_WAVES_PER_SIMD
-#define MDH_WAVES_PER_SIMD 6 // register budget of the march kernels (measured: 6 > 5 > 8 > 4 > 3 > 2 waves/SIMD)
+#define MDH_WAVES_PER_SIMD 5 // register budget of the march kernels (measured, pipelined frames: 5 > 6 > 4 waves/SIMD)
 #endif
 
 // ------------------------------------------------------------------------ screen pass

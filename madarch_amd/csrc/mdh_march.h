@@ -21,6 +21,9 @@
 #ifndef MDH_TAP_EARLY
 #define MDH_TAP_EARLY 1
 #endif
+#ifndef MDH_DEDUPE_FOLDED
+#define MDH_DEDUPE_FOLDED 0 // register ring for folded corners: measured no gain (VGPR pressure), see DESIGN.md
+#endif
 #ifndef MDH_SKIP_NULL_RAYS
 #define MDH_SKIP_NULL_RAYS 1
 #endif
@@ -353,9 +356,43 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
                   PH_ADD(pt, 2);
                   if (QVIS && ctx == 0) vis_bits = queued_visibility<PART>(sc, pr, pk, P, N, gp, folded, sd0);
                   PH_ADD(pt, 5);
+                  // Folded corners also repeat the whole irradiance term of their twin (same probe: same
+                  // direction, same visibility, same tap); only the trilinear factor differs.  When `folded`
+                  // is the same in all lanes (a tile on one wall) the twin's sqrt(irradiance) and its weight
+                  // before the trilinear factor are kept in a small ring and the corner costs a dozen
+                  // operations; the sum over i keeps its order.  fu = that common value, else 0.
+                  int fu = 0;
+#if MDH_DEDUPE_FOLDED
+                  if (ctx == 0) {
+                     const int f0 = __builtin_amdgcn_readfirstlane(folded);
+                     if (__ballot(folded != f0) == 0ull) fu = f0;
+                  }
+#endif
+                  f3 ring_s0 = F3(0.0f, 0.0f, 0.0f), ring_s1 = ring_s0, ring_s2 = ring_s0, ring_s3 = ring_s0;
+                  float ring_w0 = 0.0f, ring_w1 = 0.0f, ring_w2 = 0.0f, ring_w3 = 0.0f;
 #pragma unroll 1
                   for (int i = 0; i < 8; ++i) {
+                     // ctx 1: a folded corner has the weight of its twin, which is not strictly larger
+                     if (ctx == 1 && (i & folded)) continue;
+                     // ring slot of the distinct corner behind i: the bits of i outside fu, packed
+                     int k = 0;
+                     {
+                        int nb = 0;
+                        for (int bit = 0; bit < 3; ++bit)
+                           if (!((fu >> bit) & 1)) { k |= ((i >> bit) & 1) << nb; ++nb; }
+                        k &= 3;
+                     }
+                     f3 s_term = F3(0.0f, 0.0f, 0.0f); // sqrt(irradiance tap) of this corner's probe
+                     float wpre = 0.0f;                // its weight before the trilinear factor
                      const i3 q = cage_probe(pr, gp, i);
+                     if (i & fu) { // (scalar branch)
+                        switch (k) {
+                        case 0: s_term = ring_s0; wpre = ring_w0; break;
+                        case 1: s_term = ring_s1; wpre = ring_w1; break;
+                        case 2: s_term = ring_s2; wpre = ring_w2; break;
+                        default: s_term = ring_s3; wpre = ring_w3; break;
+                        }
+                     } else {
                      const f3 pw = grid_to_world(pr, q);
                      const f3 hvec = (ctx == 0) ? (pw - P) : (P - pw);
                      const float dist = length(hvec);
@@ -370,7 +407,7 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
                         f2 rid = ray_dir_to_ray_id(N);
                         rid = F2(clamp_(rid.x, irr_min, irr_max), clamp_(rid.y, irr_min, irr_max));
                         const f2 base = probe_id_to_coord(pr, grid_to_probe_id(pr, q));
-                        tap = atlas_tap_issue(pr.irr, pr.fmt, pr.pcx, pr.pcy, pr.ires, pr.ishift, base.x + rid.x / (float)pr.pcx, base.y + rid.y / (float)pr.pcy);
+                        tap = atlas_tap_issue(pr.irr, pr.fmt, pr.pcx, pr.pcy, pr.ires, pr.ishift, base.x + div_pcx(pr, rid.x), base.y + div_pcy(pr, rid.y));
                      }
 #endif
                      // raycast_visibility, raymarching.glsl:39-56
@@ -392,11 +429,11 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
                      // is >= 0, a probe with d <= best cannot win whatever its visibility.
                      if (ctx == 1 && accw >= 0.0f && dot(-vd, -N) <= accw) vmax = 0.0f;
 #endif
+                     bool first = MDH_SHARE_FIRST_STEP != 0;
+                     PH_ADD(pt, 4);
 #ifdef MDH_ABL_NO_VIS
                      if (false)
 #endif
-                     bool first = MDH_SHARE_FIRST_STEP != 0;
-                     PH_ADD(pt, 4);
                      if (!(QVIS && !REFLECT)) // (with the queue and no second point this loop is dead code)
                      while (total < vmax) {
                         MDH_DIAG_STEP(3 + ctx);
@@ -413,27 +450,41 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
                         weight *= vis;
                         const float crush = 0.2f;
                         if (weight < crush) weight *= weight * weight * (1.0f / (crush * crush));
-                        const f3 alpha = P / F3(pr.sx, pr.sy, pr.sz) - F3((float)gp.x, (float)gp.y, (float)gp.z);
-                        f3 tri = F3(mix_(1.0f - alpha.x, alpha.x, (float)(i & 1)), mix_(1.0f - alpha.y, alpha.y, (float)((i >> 1) & 1)),
-                                    mix_(1.0f - alpha.z, alpha.z, (float)((i >> 2) & 1)));
-                        weight *= tri.x * tri.y * tri.z;
+                        wpre = weight;
+#ifdef MDH_ABL_NO_TAPS
+                        f3 tx = F3((float)q.x, (float)q.y, N.x);
+#elif MDH_TAP_EARLY
+                        f3 tx = atlas_tap_resolve(pr.irr, pr.fmt, tap, u8_tab);
+#else
                         const float irr_min = 0.5f / (float)pr.ires, irr_max = 1.0f - irr_min;
                         f2 rid = ray_dir_to_ray_id(N);
                         rid = F2(clamp_(rid.x, irr_min, irr_max), clamp_(rid.y, irr_min, irr_max));
                         f2 base = probe_id_to_coord(pr, grid_to_probe_id(pr, q));
-#ifdef MDH_ABL_NO_TAPS
-                        f3 tx = F3(base.x, base.y, rid.x);
-#elif MDH_TAP_EARLY
-                        f3 tx = atlas_tap_resolve(pr.irr, pr.fmt, tap, u8_tab);
-#else
-                        f3 tx = atlas_sample(pr.irr, pr.fmt, pr.pcx, pr.pcy, pr.ires, pr.ishift, base.x + rid.x / (float)pr.pcx, base.y + rid.y / (float)pr.pcy, u8_tab);
+                        f3 tx = atlas_sample(pr.irr, pr.fmt, pr.pcx, pr.pcy, pr.ires, pr.ishift, base.x + div_pcx(pr, rid.x), base.y + div_pcy(pr, rid.y), u8_tab);
 #endif
-                        acc = acc + sqrt3(tx) * weight;
-                        accw += weight;
+                        s_term = sqrt3(tx);
+                        if (fu) { // (scalar) keep it for the corners folded onto this one
+                           switch (k) {
+                           case 0: ring_s0 = s_term; ring_w0 = wpre; break;
+                           case 1: ring_s1 = s_term; ring_w1 = wpre; break;
+                           case 2: ring_s2 = s_term; ring_w2 = wpre; break;
+                           default: ring_s3 = s_term; ring_w3 = wpre; break;
+                           }
+                        }
                      } else { // render_probes.glsl:170-183; probe_to_spec = -vd
                         float weight = dot(-vd, -N);
                         weight *= vis;
                         if (weight > accw) { accw = weight; best_q = q.x | (q.y << 10) | (q.z << 20); acc = -vd; }
+                     }
+                     }
+                     if (ctx == 0) { // render_probes.glsl:34-62: the trilinear factor and the sum
+                        float weight = wpre;
+                        const f3 alpha = P / F3(pr.sx, pr.sy, pr.sz) - F3((float)gp.x, (float)gp.y, (float)gp.z);
+                        f3 tri = F3(mix_(1.0f - alpha.x, alpha.x, (float)(i & 1)), mix_(1.0f - alpha.y, alpha.y, (float)((i >> 1) & 1)),
+                                    mix_(1.0f - alpha.z, alpha.z, (float)((i >> 2) & 1)));
+                        weight *= tri.x * tri.y * tri.z;
+                        acc = acc + s_term * weight;
+                        accw += weight;
                      }
                      PH_ADD(pt, 6);
                   }
@@ -457,7 +508,7 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
                      const float rmin = 0.5f / (float)pr.rres, rmax = 1.0f - rmin;
                      f2 brid = ray_dir_to_ray_id(acc);
                      brid = F2(clamp_(brid.x, rmin, rmax), clamp_(brid.y, rmin, rmax));
-                     f3 radiance = atlas_sample(pr.rad, pr.fmt, pr.pcx, pr.pcy, pr.rres, pr.rshift, base.x + brid.x / (float)pr.pcx, base.y + brid.y / (float)pr.pcy, u8_tab);
+                     f3 radiance = atlas_sample(pr.rad, pr.fmt, pr.pcx, pr.pcy, pr.rres, pr.rshift, base.x + div_pcx(pr, brid.x), base.y + div_pcy(pr, brid.y), u8_tab);
                      specular_col = radiance + specular_col;
                   }
                   PH_ADD(pt, 7);
