@@ -82,6 +82,30 @@ def measured_traffic(workload, world):
     return None, None
 
 
+VALU_PEAK_WAVE_INSTS = 256 * 4 * 2.4e9 / 2  # 256 CUs x 4 SIMDs, one wave64 VALU instruction per 2 cycles at 2.4 GHz (MI355X_MICROARCH.md)
+
+
+def measured_valu(workload, world, passes):
+    """Wave-level VALU instructions per k_screen launch (SQ_INSTS_VALU of the committed PMC pass) against
+    the chip's VALU issue peak over the kernel's duration in this run -- the roofline that really bounds
+    the path.  None when no profile matches."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
+        try:
+            t = json.load(open(path))
+            if t.get("workload") == workload and t.get("n_gpus") == world:
+                insts = float(t["kernels"]["k_screen"]["SQ_INSTS_VALU"])
+                lanes = float(t["kernels"]["k_screen"]["SQ_THREAD_CYCLES_VALU"]) / float(t["kernels"]["k_screen"]["SQ_ACTIVE_INST_VALU"])
+                ms = passes["screen"]["ms_avg"]
+                rate = insts / (ms * 1e-3)
+                return {"kernel": "k_screen", "wave_insts_per_launch": int(insts), "achieved_wave_insts_per_s": round(rate, 1),
+                        "peak_wave_insts_per_s": VALU_PEAK_WAVE_INSTS, "frac": round(rate / VALU_PEAK_WAVE_INSTS, 4),
+                        "active_lanes_per_inst": round(lanes, 1), "kernel_ms": ms, "source": os.path.basename(path)}
+        except (OSError, KeyError, ValueError, ZeroDivisionError):
+            continue
+    return None
+
+
 def cpu_baseline(workload):
     """The CPU oracle (a C restatement of the reference's path -- the Ada/GLSL reference
     cannot be built here) on the host cores: one warm-up frame, one timed frame."""
@@ -111,6 +135,7 @@ def main():
     ap.add_argument("--mode", type=int, default=None, help="override the screen mode (ablation runs only)")
     ap.add_argument("--serial", action="store_true", help="MDH_OPT_FRAME_OVERLAP = 0: one pass after the other (per-kernel timing runs)")
     ap.add_argument("--overlap", type=int, default=None, help="MDH_OPT_FRAME_OVERLAP value (default: the library's)")
+    ap.add_argument("--no-serial-segment", action="store_true", help="skip the untimed serial frames that give clean per-kernel durations")
     args = ap.parse_args()
 
     import torch
@@ -167,11 +192,30 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
-    passes = {}
-    for p, name in enumerate(B.PASS_NAMES):
-        ms, n = R.Pass_Time(p)
-        if n:
-            passes[name] = {"ms_avg": round(ms / n, 4), "launches": n}
+    def pass_times():
+        out = {}
+        for p, name in enumerate(B.PASS_NAMES):
+            ms, n = R.Pass_Time(p)
+            if n:
+                out[name] = {"ms_avg": round(ms / n, 4), "launches": n}
+        return out
+
+    passes = pass_times()
+    overlap = R.Get_Option(B.OPT_FRAME_OVERLAP) if world == 1 else 0
+    passes_serial = None
+    if overlap and not args.no_serial_segment:
+        # Pipelined frames share the chip between kernels, which stretches every launch.  A short
+        # untimed run of the strictly serial schedule gives each kernel's duration on its own.
+        R.Set_Option(B.OPT_FRAME_OVERLAP, 0)
+        for _ in range(3):
+            frame.Render()
+        sync()
+        R.Reset_Pass_Times()
+        for _ in range(10):
+            frame.Render()
+        sync()
+        passes_serial = pass_times()
+        R.Set_Option(B.OPT_FRAME_OVERLAP, overlap)
 
     if rank == 0:
         W, H = R.Width, R.Height
@@ -189,7 +233,7 @@ def main():
             "config": {"workload": args.workload, "scene": scene, "width": W, "height": H,
                        "probe_grid": "8x8x8" if probes == "gi8" else "4x3x3", "atlas": args.atlas,
                        "screen_mode": mode, "parallelism": "tiles+probes/%d" % world,
-                       "frame_overlap": R.Get_Option(B.OPT_FRAME_OVERLAP) if world == 1 else 0},
+                       "frame_overlap": overlap},
             "roofline": {"bound": "hbm", "kernel": "k_screen", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": int(alg_bytes), "bytes_per_pixel": per_px,
@@ -197,6 +241,15 @@ def main():
                          "note": "the path is fp32-VALU bound (sphere tracing), not HBM bound; see DESIGN.md 'Roofline'"},
             "passes": passes,
         }
+        if passes_serial:
+            sms = passes_serial["screen"]["ms_avg"]
+            out["passes_serial"] = passes_serial
+            out["roofline"]["kernel_ms_serial"] = sms
+            out["roofline"]["achieved_serial"] = round(alg_bytes / (sms * 1e-3) / 1e9, 3)
+            out["roofline"]["note"] += "; kernel_ms_avg is measured inside the timed (pipelined) region where kernels of neighbouring frames share the chip, kernel_ms_serial with one kernel on the chip"
+        valu = measured_valu(args.workload, world, passes_serial or passes)
+        if valu:
+            out["valu_issue"] = valu
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.workload)
         print(json.dumps(out), flush=True)
