@@ -26,6 +26,9 @@
 #ifndef MDH_SCR_QVIS
 #define MDH_SCR_QVIS 0
 #endif
+#ifndef MDH_SCAT_BATCH
+#define MDH_SCAT_BATCH 8 // scattering steps whose froxel taps are in flight together
+#endif
 #ifndef MDH_WAVES_PER_SIMD
 #define MDH_WAVES_PER_SIMD 5 // register budget of the march kernels (measured, pipelined frames: 5 > 6 > 4 waves/SIMD)
 #endif
@@ -238,17 +241,28 @@ template <bool PART> __global__ __launch_bounds__(MDH_BLOCK) void k_scattering(K
    const f2 norm_pos = F2(0.5f * (px + 1.0f), 0.5f * (py + 1.0f));
    const float max_depth = vol.vstep * (float)vol.vz; // volumetrics.glsl:3-4
    f3 to = from + dir * max_depth;
-   int idx = -1, steps;
+   int steps;
    float t;
-   f3 coll;
-   if (raycast<PART>(sc, from, dir, idx, coll, t, steps)) to = coll;
+   // raycast (raymarching.glsl:25-37) without the arg-min: only the collision point is used here
+   if (march_plain<PART>(sc, from, dir, sc.max_dist, t, steps)) to = from + dir * t;
    const float len = min_(length(to - from), max_depth);
    f3 L = F3(0.0f, 0.0f, 0.0f);
-   for (float f = 0.0f; f < len; f += vol.sstep) {
-      const float rel = __builtin_floorf(f / vol.vstep); // sample_visibility :9-15
-      float tx[3];
-      tex_sample<3>(vol.vis, vol.vw, vol.vh * vol.vz, norm_pos.x, (norm_pos.y + rel) / (float)vol.vz, tx);
-      L = L + F3(tx[0], tx[1], tx[2]) * exp_(-f * MDH_TAU);
+   // The froxel taps of consecutive steps are independent, but each costs a trip to L2/HBM and the
+   // pass has one wavefront per SIMD: steps go in batches of MDH_SCAT_BATCH whose loads are all in
+   // flight together, then fold into L in step order (a step past `len` loads a valid texel and is
+   // not added).  f runs through the same values as the reference's loop.
+   for (float f = 0.0f; f < len;) {
+      float fs[MDH_SCAT_BATCH], tx[MDH_SCAT_BATCH][3];
+#pragma unroll
+      for (int k = 0; k < MDH_SCAT_BATCH; ++k) {
+         fs[k] = f;
+         const float rel = __builtin_floorf(f / vol.vstep); // sample_visibility :9-15
+         tex_sample<3>(vol.vis, vol.vw, vol.vh * vol.vz, norm_pos.x, (norm_pos.y + rel) / (float)vol.vz, tx[k]);
+         f += vol.sstep;
+      }
+#pragma unroll
+      for (int k = 0; k < MDH_SCAT_BATCH; ++k)
+         if (fs[k] < len) L = L + F3(tx[k][0], tx[k][1], tx[k][2]) * exp_(-fs[k] * MDH_TAU);
    }
    L = L * vol.sstep;
    vol.scat[(size_t)j * W + i] = make_float4(L.x, L.y, L.z, len);
