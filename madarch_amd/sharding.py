@@ -95,15 +95,15 @@ class ShardedFrame:
 
     def Render(self):
         R = self.R
-        if self.world == 1:  # nothing to exchange: the library's own frame (which may pipeline frames)
+        if self.world == 1 and self.exchange is None:  # the library's own frame (which may pipeline frames)
             R.Render()
             return
         if R.Get_Option(B.OPT_SCREEN_MODE) == 0:
             R.Render_Pass(B.PASS_RADIANCE)
-            if self.world > 1:
+            if self.exchange is not None:
                 self.exchange.all_gather(R, B.TEX_RADIANCE, self.rank, self.world)
             R.Render_Pass(B.PASS_IRRADIANCE)
-            if self.world > 1:
+            if self.exchange is not None:
                 self.exchange.all_gather(R, B.TEX_IRRADIANCE, self.rank, self.world)
             if R.Volumetrics.Enabled:
                 R.Render_Pass(B.PASS_VISIBILITY)
