@@ -136,6 +136,7 @@ def main():
     ap.add_argument("--serial", action="store_true", help="MDH_OPT_FRAME_OVERLAP = 0: one pass after the other (per-kernel timing runs)")
     ap.add_argument("--overlap", type=int, default=None, help="MDH_OPT_FRAME_OVERLAP value (default: the library's)")
     ap.add_argument("--no-serial-segment", action="store_true", help="skip the untimed serial frames that give clean per-kernel durations")
+    ap.add_argument("--rehearse-rccl", action="store_true", help="one rank, but through the RCCL exchange path of the sharded frame (rehearsal of the N > 1 code path on one GPU)")
     args = ap.parse_args()
 
     import torch
@@ -151,10 +152,14 @@ def main():
         args.gpus = world
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.rehearse_rccl:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_PORT", "29531")
+        if world > 1:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
 
     R = make_renderer(args.workload, B.hip_binding(), device=local_rank)
     R.Set_Option(B.OPT_ATLAS_FORMAT, 0 if args.atlas == "rgb8" else 1)
@@ -164,7 +169,7 @@ def main():
         R.Set_Option(B.OPT_FRAME_OVERLAP, 0)
     elif args.overlap is not None:
         R.Set_Option(B.OPT_FRAME_OVERLAP, args.overlap)
-    exchange = sharding.DeviceExchange(dist, R, torch.device("cuda", local_rank)) if world > 1 else None
+    exchange = sharding.DeviceExchange(dist, R, torch.device("cuda", local_rank)) if dist is not None else None
     frame = sharding.ShardedFrame(R, rank, world, exchange)
 
     def sync():
@@ -201,7 +206,7 @@ def main():
         return out
 
     passes = pass_times()
-    overlap = R.Get_Option(B.OPT_FRAME_OVERLAP) if world == 1 else 0
+    overlap = R.Get_Option(B.OPT_FRAME_OVERLAP)
     passes_serial = None
     if overlap and not args.no_serial_segment:
         # Pipelined frames share the chip between kernels, which stretches every launch.  A short
@@ -232,7 +237,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "scene": scene, "width": W, "height": H,
                        "probe_grid": "8x8x8" if probes == "gi8" else "4x3x3", "atlas": args.atlas,
-                       "screen_mode": mode, "parallelism": "tiles+probes/%d" % world,
+                       "screen_mode": mode, "parallelism": "tiles+probes/%d" % world + (" (RCCL rehearsal)" if args.rehearse_rccl else ""),
                        "frame_overlap": overlap},
             "roofline": {"bound": "hbm", "kernel": "k_screen", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
@@ -253,7 +258,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.workload)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 

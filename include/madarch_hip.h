@@ -200,6 +200,17 @@ int32_t mdh_render(mdh_renderer *r);
 /* one pass only (for one-process-per-GPU runs that exchange atlas slices
  * between the passes, see DESIGN.md "Multi-GPU") */
 int32_t mdh_render_pass(mdh_renderer *r, int32_t pass);
+/* Render in three steps, for callers that put work of their own between the
+ * passes: mdh_frame_begin, mdh_frame_probe_pass(MDH_PASS_RADIANCE), [exchange],
+ * mdh_frame_probe_pass(MDH_PASS_IRRADIANCE), [exchange], mdh_frame_end (volumetric
+ * passes + screen pass).  mdh_render is exactly that sequence without the exchanges,
+ * and frames opened this way are kept in flight the same way (MDH_OPT_FRAME_OVERLAP).
+ * While a frame is open the atlas reads, writes and device pointers refer to the
+ * atlas set that frame is producing, and the caller's device work on it must be
+ * ordered on the stream mdh_probe_stream names. */
+int32_t mdh_frame_begin(mdh_renderer *r);
+int32_t mdh_frame_probe_pass(mdh_renderer *r, int32_t pass);
+int32_t mdh_frame_end(mdh_renderer *r);
 int32_t mdh_finish(mdh_renderer *r);
 
 /* replaces Swap_Buffers (renderers.adb:320): linear RGB floats, H*W*3, row 0 = top.
@@ -235,6 +246,8 @@ int32_t mdh_stream(mdh_renderer *r, void **stream);
 /* enqueue on the caller's stream instead (e.g. the one an RCCL communicator is
  * ordered with); NULL returns to the renderer's own stream */
 int32_t mdh_set_stream(mdh_renderer *r, void *stream);
+/* the stream the probe passes of an open frame run on (hipStream_t) */
+int32_t mdh_probe_stream(mdh_renderer *r, void **stream);
 
 /* Renderers.Eval_Distance_To (madarch-renderers.adb:499-526), batched: for
  * each of n points the closest distance over the listed kinds (initial

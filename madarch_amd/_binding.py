@@ -92,6 +92,9 @@ ABI = {
     "update_partitioning": (_I, [_P, _I]),
     "render": (_I, [_P]),
     "render_pass": (_I, [_P, _I]),
+    "frame_begin": (_I, [_P]),
+    "frame_probe_pass": (_I, [_P, _I]),
+    "frame_end": (_I, [_P]),
     "finish": (_I, [_P]),
     "read_framebuffer": (_I, [_P, _P]),
     "read_gbuffer": (_I, [_P, _P, _P, _P]),
@@ -116,6 +119,7 @@ HIP_ONLY_ABI = {
                               C.POINTER(C.c_int64)]),
     "stream": (_I, [_P, C.POINTER(_P)]),
     "set_stream": (_I, [_P, _P]),
+    "probe_stream": (_I, [_P, C.POINTER(_P)]),
 }
 
 

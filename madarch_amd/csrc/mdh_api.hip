@@ -142,6 +142,9 @@ struct mdh_renderer {
    hipEvent_t ev_screen[2] = {nullptr, nullptr}, ev_probe[2] = {nullptr, nullptr}, ev_join = nullptr, ev_join_alt = nullptr;
    bool ev_screen_valid[2] = {false, false};
    bool alt_pending = false; // work on alt_stream that `stream` has not been ordered after yet
+   // an open frame (mdh_frame_begin .. mdh_frame_end)
+   bool in_frame = false, frame_pipelined = false;
+   int frame_cur = 0;
    bool main_dirty = true; // work went to `stream` outside a pipelined frame since the probe stream last joined it
    float *d_vis = nullptr;
    float4 *d_scat = nullptr;
@@ -772,6 +775,7 @@ static int run_pass(mdh_renderer *r, int pass, hipStream_t st, int src, int dst,
 extern "C" int32_t mdh_render_pass(mdh_renderer *r, int32_t pass)
 {
    if (!r) return seterr(MDH_E_INVALID, "null renderer");
+   if (r->in_frame) return seterr(MDH_E_STATE, "a frame is open: use mdh_frame_probe_pass / mdh_frame_end");
    int rc = ensure_committed(r);
    if (rc != MDH_OK) return rc;
    if ((rc = join_main(r)) != MDH_OK) return rc;
@@ -795,43 +799,65 @@ extern "C" int32_t mdh_render_pass(mdh_renderer *r, int32_t pass)
 // stream.  Anything outside a pipelined frame first orders the main stream after the others
 // (join_main), and the next pipelined frame orders the others after the main stream: results are
 // those of the serial order bit for bit.
-extern "C" int32_t mdh_render(mdh_renderer *r)
+// A frame in three steps, for callers that put work of their own between the passes (the
+// one-process-per-GPU runs all-gather the atlas slices after each probe pass, on the stream
+// mdh_probe_stream names): begin -> probe passes -> end.  mdh_render is exactly
+// begin, radiance, irradiance, end.
+static hipStream_t frame_probe_stream(const mdh_renderer *r) { return r->frame_pipelined ? r->probe_stream : r->stream; }
+extern "C" int32_t mdh_frame_begin(mdh_renderer *r)
 {
    if (!r) return seterr(MDH_E_INVALID, "null renderer");
+   if (r->in_frame) return seterr(MDH_E_STATE, "a frame is already open");
    int rc = ensure_committed(r);
    if (rc != MDH_OK) return rc;
-   const bool pipelined = r->opt_overlap && r->opt_mode == 0 && r->opt_world == 1 && r->stream == r->own_stream;
-   if (!pipelined) {
+   r->frame_pipelined = r->opt_overlap && r->opt_mode == 0 && r->stream == r->own_stream;
+   if (!r->frame_pipelined) {
       if ((rc = join_main(r)) != MDH_OK) return rc;
       r->main_dirty = true;
-      const int s = r->last;
-      if (r->opt_mode == 0) {
-         if ((rc = run_pass(r, MDH_PASS_RADIANCE, r->stream, s, s)) != MDH_OK) return rc;
-         if ((rc = run_pass(r, MDH_PASS_IRRADIANCE, r->stream, s, s)) != MDH_OK) return rc;
-         if (r->vol.enabled) {
-            if ((rc = run_pass(r, MDH_PASS_VISIBILITY, r->stream, s, s)) != MDH_OK) return rc;
-            if ((rc = run_pass(r, MDH_PASS_SCATTERING, r->stream, s, s)) != MDH_OK) return rc;
-         }
+      r->frame_cur = r->last;
+   } else {
+      const int cur = r->last ^ 1;
+      if (r->main_dirty) { // the other streams have to see everything that went to the main stream meanwhile
+         if ((rc = join_main(r)) != MDH_OK) return rc;
+         HIP_TRY(hipEventRecord(r->ev_join, r->stream));
+         HIP_TRY(hipStreamWaitEvent(r->probe_stream, r->ev_join, 0));
+         HIP_TRY(hipStreamWaitEvent(r->alt_stream, r->ev_join, 0));
+         r->main_dirty = false;
+      } else if (r->ev_screen_valid[cur]) {
+         HIP_TRY(hipStreamWaitEvent(r->probe_stream, r->ev_screen[cur], 0));
       }
-      return run_pass(r, MDH_PASS_SCREEN, r->stream, s, s);
+      r->frame_cur = cur;
    }
-   const int prev = r->last, cur = prev ^ 1;
+   r->in_frame = true;
+   return MDH_OK;
+}
+extern "C" int32_t mdh_frame_probe_pass(mdh_renderer *r, int32_t pass)
+{
+   if (!r) return seterr(MDH_E_INVALID, "null renderer");
+   if (!r->in_frame) return seterr(MDH_E_STATE, "no open frame");
+   if (pass != MDH_PASS_RADIANCE && pass != MDH_PASS_IRRADIANCE) return seterr(MDH_E_INVALID, "not a probe pass");
+   if (r->opt_mode != 0) return MDH_OK; // modes 1 and 2 draw without probes (renderers.adb:302-321 runs them anyway; nothing reads them)
+   return run_pass(r, pass, frame_probe_stream(r), r->last, r->frame_cur);
+}
+extern "C" int32_t mdh_frame_end(mdh_renderer *r)
+{
+   if (!r) return seterr(MDH_E_INVALID, "null renderer");
+   if (!r->in_frame) return seterr(MDH_E_STATE, "no open frame");
+   r->in_frame = false;
+   int rc;
+   const int cur = r->frame_cur;
+   if (!r->frame_pipelined) {
+      if (r->opt_mode == 0 && r->vol.enabled) {
+         if ((rc = run_pass(r, MDH_PASS_VISIBILITY, r->stream, cur, cur)) != MDH_OK) return rc;
+         if ((rc = run_pass(r, MDH_PASS_SCATTERING, r->stream, cur, cur)) != MDH_OK) return rc;
+      }
+      return run_pass(r, MDH_PASS_SCREEN, r->stream, cur, cur);
+   }
    const bool dual = r->opt_overlap > 1 && !r->vol.enabled && !r->opt_gbuffer;
+   // single-buffered targets: a screen pass on the main stream after one on the alternate stream
+   if (!dual && r->alt_pending && (rc = join_main(r)) != MDH_OK) return rc;
    hipStream_t screen_stream = (dual && cur) ? r->alt_stream : r->stream;
    const int fbix = dual ? cur : r->fb_last;
-   if (r->main_dirty) { // the other streams have to see everything that went to the main stream meanwhile
-      if ((rc = join_main(r)) != MDH_OK) return rc;
-      HIP_TRY(hipEventRecord(r->ev_join, r->stream));
-      HIP_TRY(hipStreamWaitEvent(r->probe_stream, r->ev_join, 0));
-      HIP_TRY(hipStreamWaitEvent(r->alt_stream, r->ev_join, 0));
-      r->main_dirty = false;
-   } else {
-      if (r->ev_screen_valid[cur]) HIP_TRY(hipStreamWaitEvent(r->probe_stream, r->ev_screen[cur], 0));
-      // single-buffered targets: a screen pass on the main stream after one on the alternate stream
-      if (!dual && r->alt_pending && (rc = join_main(r)) != MDH_OK) return rc;
-   }
-   if ((rc = run_pass(r, MDH_PASS_RADIANCE, r->probe_stream, prev, cur)) != MDH_OK) return rc;
-   if ((rc = run_pass(r, MDH_PASS_IRRADIANCE, r->probe_stream, cur, cur)) != MDH_OK) return rc;
    HIP_TRY(hipEventRecord(r->ev_probe[cur], r->probe_stream));
    HIP_TRY(hipStreamWaitEvent(screen_stream, r->ev_probe[cur], 0));
    if (r->vol.enabled) { // (never dual)
@@ -844,6 +870,24 @@ extern "C" int32_t mdh_render(mdh_renderer *r)
    r->last = cur;
    r->fb_last = fbix;
    if (screen_stream == r->alt_stream) r->alt_pending = true;
+   return MDH_OK;
+}
+extern "C" int32_t mdh_render(mdh_renderer *r)
+{
+   if (!r) return seterr(MDH_E_INVALID, "null renderer");
+   int rc;
+   if ((rc = mdh_frame_begin(r)) != MDH_OK) return rc;
+   if ((rc = mdh_frame_probe_pass(r, MDH_PASS_RADIANCE)) != MDH_OK || (rc = mdh_frame_probe_pass(r, MDH_PASS_IRRADIANCE)) != MDH_OK) {
+      r->in_frame = false;
+      return rc;
+   }
+   return mdh_frame_end(r);
+}
+// the stream the probe passes of the open frame run on (what a caller's collectives must be ordered on)
+extern "C" int32_t mdh_probe_stream(mdh_renderer *r, void **stream)
+{
+   if (!r || !stream) return seterr(MDH_E_INVALID, "bad argument");
+   *stream = (void *)((r->opt_overlap && r->stream == r->own_stream) ? r->probe_stream : r->stream);
    return MDH_OK;
 }
 extern "C" int32_t mdh_finish(mdh_renderer *r)
@@ -880,23 +924,29 @@ extern "C" int32_t mdh_read_gbuffer(mdh_renderer *r, int32_t *index_out, float *
    return MDH_OK;
 }
 
+// The atlas set and the stream reads, writes and device pointers refer to: inside an open frame the
+// set that frame is producing, on the stream its probe passes run on; otherwise the last frame's
+// set on the main stream.
+static int atlas_set(const mdh_renderer *r) { return r->in_frame ? r->frame_cur : r->last; }
+static hipStream_t atlas_stream(const mdh_renderer *r) { return r->in_frame ? frame_probe_stream(r) : r->stream; }
 // host copies of the probe-major atlases as float RGB per texel
 static int atlas_to_host(mdh_renderer *r, int tex, std::vector<float> &rgb)
 {
    int res = tex == MDH_TEX_RADIANCE ? r->probes.radiance_resolution : r->probes.irradiance_resolution;
    size_t n = (size_t)probe_total(r) * res * res;
-   void *src = tex == MDH_TEX_RADIANCE ? r->d_rad2[r->last] : r->d_irr2[r->last];
-   { int jr = join_main(r); if (jr != MDH_OK) return jr; }
+   void *src = tex == MDH_TEX_RADIANCE ? r->d_rad2[atlas_set(r)] : r->d_irr2[atlas_set(r)];
+   hipStream_t st = atlas_stream(r);
+   if (!r->in_frame) { int jr = join_main(r); if (jr != MDH_OK) return jr; }
    rgb.resize(n * 3);
    if (r->opt_atlas == 0) {
       std::vector<uchar4> tmp(n);
-      HIP_TRY(hipMemcpyAsync(tmp.data(), src, n * 4, hipMemcpyDeviceToHost, r->stream));
-      HIP_TRY(hipStreamSynchronize(r->stream));
+      HIP_TRY(hipMemcpyAsync(tmp.data(), src, n * 4, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
       for (size_t i = 0; i < n; ++i) { rgb[3 * i] = (float)tmp[i].x / 255.0f; rgb[3 * i + 1] = (float)tmp[i].y / 255.0f; rgb[3 * i + 2] = (float)tmp[i].z / 255.0f; }
    } else {
       std::vector<float4> tmp(n);
-      HIP_TRY(hipMemcpyAsync(tmp.data(), src, n * 16, hipMemcpyDeviceToHost, r->stream));
-      HIP_TRY(hipStreamSynchronize(r->stream));
+      HIP_TRY(hipMemcpyAsync(tmp.data(), src, n * 16, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
       for (size_t i = 0; i < n; ++i) { rgb[3 * i] = tmp[i].x; rgb[3 * i + 1] = tmp[i].y; rgb[3 * i + 2] = tmp[i].z; }
    }
    return MDH_OK;
@@ -910,25 +960,29 @@ static float unorm8_host(float x)
 // upload texels [first, first + n) of a probe-major atlas from float RGB
 static int atlas_from_host(mdh_renderer *r, int tex, size_t first, size_t n, const float *rgb)
 {
-   void *dst = tex == MDH_TEX_RADIANCE ? r->d_rad2[r->last] : r->d_irr2[r->last];
-   { int jr = join_main(r); if (jr != MDH_OK) return jr; }
-   r->main_dirty = true;
+   void *dst = tex == MDH_TEX_RADIANCE ? r->d_rad2[atlas_set(r)] : r->d_irr2[atlas_set(r)];
+   hipStream_t st = atlas_stream(r);
+   if (!r->in_frame) {
+      int jr = join_main(r);
+      if (jr != MDH_OK) return jr;
+      r->main_dirty = true;
+   }
    if (r->opt_atlas == 0) {
       std::vector<uchar4> tmp(n);
       for (size_t i = 0; i < n; ++i) {
          tmp[i].x = (unsigned char)unorm8_host(rgb[3 * i]); tmp[i].y = (unsigned char)unorm8_host(rgb[3 * i + 1]);
          tmp[i].z = (unsigned char)unorm8_host(rgb[3 * i + 2]); tmp[i].w = 255;
       }
-      HIP_TRY(hipMemcpyAsync((uchar4 *)dst + first, tmp.data(), n * 4, hipMemcpyHostToDevice, r->stream));
-      HIP_TRY(hipStreamSynchronize(r->stream));
+      HIP_TRY(hipMemcpyAsync((uchar4 *)dst + first, tmp.data(), n * 4, hipMemcpyHostToDevice, st));
+      HIP_TRY(hipStreamSynchronize(st));
    } else {
       std::vector<float4> tmp(n);
       for (size_t i = 0; i < n; ++i) {
          float a = rgb[3 * i], b = rgb[3 * i + 1], c = rgb[3 * i + 2];
          tmp[i] = mk4(a != a ? 0.0f : a, b != b ? 0.0f : b, c != c ? 0.0f : c, 1.0f);
       }
-      HIP_TRY(hipMemcpyAsync((float4 *)dst + first, tmp.data(), n * 16, hipMemcpyHostToDevice, r->stream));
-      HIP_TRY(hipStreamSynchronize(r->stream));
+      HIP_TRY(hipMemcpyAsync((float4 *)dst + first, tmp.data(), n * 16, hipMemcpyHostToDevice, st));
+      HIP_TRY(hipStreamSynchronize(st));
    }
    return MDH_OK;
 }
@@ -1021,9 +1075,12 @@ extern "C" int32_t mdh_atlas_device_ptr(mdh_renderer *r, int32_t tex, void **dpt
    int b, e;
    own_probes(r, &b, &e);
    int64_t per = (int64_t)res * res * (int64_t)texel_bytes(r);
-   { int jr = join_main(r); if (jr != MDH_OK) return jr; }
-   if (dptr) *dptr = tex == MDH_TEX_RADIANCE ? r->d_rad2[r->last] : r->d_irr2[r->last];
-   r->main_dirty = true; // the caller may write through the pointer
+   if (!r->in_frame) { // (inside a frame the caller works on the probe stream, which the frame orders)
+      int jr = join_main(r);
+      if (jr != MDH_OK) return jr;
+      r->main_dirty = true; // the caller may write through the pointer
+   }
+   if (dptr) *dptr = tex == MDH_TEX_RADIANCE ? r->d_rad2[atlas_set(r)] : r->d_irr2[atlas_set(r)];
    if (total_bytes) *total_bytes = (int64_t)atlas_bytes(r, tex);
    if (own_offset) *own_offset = per * b;
    if (own_bytes) *own_bytes = per * (e - b);

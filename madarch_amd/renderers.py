@@ -117,6 +117,16 @@ class Renderer:
     def Render_Pass(self, Pass):
         self._b.check(self._b.render_pass(self._h, int(Pass)))
 
+    # Render in three steps, for the sharded runs that exchange atlas slices between the passes
+    def Frame_Begin(self):
+        self._b.check(self._b.frame_begin(self._h))
+
+    def Frame_Probe_Pass(self, Pass):
+        self._b.check(self._b.frame_probe_pass(self._h, int(Pass)))
+
+    def Frame_End(self):
+        self._b.check(self._b.frame_end(self._h))
+
     def Finish(self):
         self._b.check(self._b.finish(self._h))
 

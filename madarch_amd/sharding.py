@@ -4,6 +4,7 @@ The reference is a single-GPU program (madarch/madarch-renderers.adb:302-321 run
 its passes back to back); what follows is the build's own design (DESIGN.md
 "Multi-GPU").  Per frame and rank r of N:
 
+  0. Frame_Begin: the library picks the atlas set of this frame (frames are kept in flight)
   1. radiance pass for the probes [r P/N, (r+1) P/N)        -- no communication
   2. all-gather of the radiance atlas slices                 -- RCCL over xGMI
   3. irradiance pass for the same probes (needs the whole radiance atlas because
@@ -54,35 +55,38 @@ class _DevicePtr:
 
 class DeviceExchange:
     """In-place RCCL all-gather on the probe-major atlases (backend "nccl" = RCCL).
-    The renderer is switched to torch's current stream so that kernels and
-    collectives are ordered on one stream."""
+    The collective is issued with the renderer's probe stream as torch's current
+    stream, so it is ordered between the probe passes of the open frame and the
+    screen pass of the previous frame keeps running beside it."""
 
     def __init__(self, dist, renderer, device, group=None):
         import torch
         self.dist, self.group, self.torch = dist, group, torch
         self.device = device
         b = renderer._b
-        stream = torch.cuda.current_stream(device).cuda_stream
-        b.check(b.set_stream(renderer._h, C.c_void_p(stream)))
+        ptr = C.c_void_p()
+        b.check(b.probe_stream(renderer._h, C.byref(ptr)))
+        self.stream = torch.cuda.ExternalStream(ptr.value or 0, device=device)
         self._views = {}
 
     def _view(self, renderer, tex):
-        # (re)query: the atlas is reallocated when the format option changes
+        # (re)query: there are two atlas sets, and they are reallocated when the format option changes
         b = renderer._b
         ptr, total, off, own = C.c_void_p(), C.c_int64(), C.c_int64(), C.c_int64()
         b.check(b.atlas_device_ptr(renderer._h, tex, C.byref(ptr), C.byref(total), C.byref(off), C.byref(own)))
         key = (tex, ptr.value, total.value)
         if key not in self._views:
-            t = self.torch.as_tensor(_DevicePtr(ptr.value, total.value), device=self.device)
-            self._views = {k: v for k, v in self._views.items() if k[0] != tex}
-            self._views[key] = t
+            if len(self._views) >= 8:
+                self._views.clear()
+            self._views[key] = self.torch.as_tensor(_DevicePtr(ptr.value, total.value), device=self.device)
         return self._views[key], off.value, own.value, total.value
 
     def all_gather(self, renderer, tex, rank, world):
         full, off, own, total = self._view(renderer, tex)
         if own * world != total:
             raise ValueError("probe count %d is not divisible by the world size %d" % (renderer.Probe_Total(), world))
-        self.dist.all_gather_into_tensor(full, full[off:off + own], group=self.group)
+        with self.torch.cuda.stream(self.stream):
+            self.dist.all_gather_into_tensor(full, full[off:off + own], group=self.group)
 
 
 class ShardedFrame:
@@ -95,20 +99,21 @@ class ShardedFrame:
 
     def Render(self):
         R = self.R
-        if self.world == 1 and self.exchange is None:  # the library's own frame (which may pipeline frames)
+        if self.world == 1 and self.exchange is None:  # the library's own frame
             R.Render()
             return
+        # the same frame with the exchanges between its probe passes; the library keeps such frames
+        # in flight like its own (MDH_OPT_FRAME_OVERLAP): probe passes and collectives on the probe
+        # stream, the screen pass of the previous frame beside them
+        R.Frame_Begin()
         if R.Get_Option(B.OPT_SCREEN_MODE) == 0:
-            R.Render_Pass(B.PASS_RADIANCE)
+            R.Frame_Probe_Pass(B.PASS_RADIANCE)
             if self.exchange is not None:
                 self.exchange.all_gather(R, B.TEX_RADIANCE, self.rank, self.world)
-            R.Render_Pass(B.PASS_IRRADIANCE)
+            R.Frame_Probe_Pass(B.PASS_IRRADIANCE)
             if self.exchange is not None:
                 self.exchange.all_gather(R, B.TEX_IRRADIANCE, self.rank, self.world)
-            if R.Volumetrics.Enabled:
-                R.Render_Pass(B.PASS_VISIBILITY)
-                R.Render_Pass(B.PASS_SCATTERING)
-        R.Render_Pass(B.PASS_SCREEN)
+        R.Frame_End()
 
     def Gather_Framebuffer(self, dist=None, group=None):
         """Sum of the ranks' framebuffers (each pixel is non-zero on one rank only);

@@ -1359,6 +1359,28 @@ int32_t orc_render(orc_renderer *r)
    pass_screen(r);
    return MDH_OK;
 }
+/* the three-step form of Render (include/madarch_hip.h: mdh_frame_begin / _probe_pass / _end);
+ * here the steps simply run one after the other */
+int32_t orc_frame_begin(orc_renderer *r)
+{
+   if (!r) return seterr(MDH_E_INVALID, "null renderer");
+   r->sdf_evals = 0;
+   return MDH_OK;
+}
+int32_t orc_frame_probe_pass(orc_renderer *r, int32_t pass)
+{
+   if (!r) return seterr(MDH_E_INVALID, "null renderer");
+   if (pass != MDH_PASS_RADIANCE && pass != MDH_PASS_IRRADIANCE) return seterr(MDH_E_INVALID, "not a probe pass");
+   if (r->opt_mode != 0) return MDH_OK;
+   return orc_render_pass(r, pass);
+}
+int32_t orc_frame_end(orc_renderer *r)
+{
+   if (!r) return seterr(MDH_E_INVALID, "null renderer");
+   if (r->opt_mode == 0 && r->vol.enabled) { pass_visibility(r); pass_scattering(r); }
+   pass_screen(r);
+   return MDH_OK;
+}
 int32_t orc_finish(orc_renderer *r) { (void)r; return MDH_OK; }
 
 int32_t orc_read_framebuffer(orc_renderer *r, float *rgb_out)

@@ -99,6 +99,41 @@ def test_sharded_frame_equals_whole_frame(hip):
     assert same_bits(Rs[1].Read_Texture(B.TEX_RADIANCE), whole["radiance"])
 
 
+def test_sharded_frames_in_flight_equal_whole_frames(hip):
+    """The same two ranks through the three-step frame (Frame_Begin / Frame_Probe_Pass / Frame_End) that
+    madarch_amd.sharding drives: frames stay in flight (two atlas sets, three streams per renderer) while
+    the slices are exchanged inside the open frame."""
+    frames = 5
+    W = make("global_illumination", 120, 72, hip, probes=SMALL_PROBES)
+    W.Set_Option(B.OPT_GBUFFER, 0)
+    W.Set_Option(B.OPT_FRAME_OVERLAP, 0)
+    for _ in range(frames):
+        W.Render()
+    want = {"image": W.Read_Framebuffer(), "irradiance": W.Read_Texture(B.TEX_IRRADIANCE), "radiance": W.Read_Texture(B.TEX_RADIANCE)}
+    Rs = [make("global_illumination", 120, 72, hip, probes=SMALL_PROBES) for _ in range(2)]
+    for r, R in enumerate(Rs):
+        R.Set_Option(B.OPT_GBUFFER, 0)
+        R.Set_Option(B.OPT_RANK, r)
+        R.Set_Option(B.OPT_WORLD, 2)
+    P = Rs[0].Probe_Total()
+    for _ in range(frames):
+        for R in Rs:
+            R.Frame_Begin()
+        for p, tex in ((B.PASS_RADIANCE, B.TEX_RADIANCE), (B.PASS_IRRADIANCE, B.TEX_IRRADIANCE)):
+            for R in Rs:
+                R.Frame_Probe_Pass(p)
+            lo = Rs[0].Read_Atlas_Slice(tex, 0, P // 2)
+            hi = Rs[1].Read_Atlas_Slice(tex, P // 2, P - P // 2)
+            Rs[0].Write_Atlas_Slice(tex, P // 2, hi)
+            Rs[1].Write_Atlas_Slice(tex, 0, lo)
+        for R in Rs:
+            R.Frame_End()
+    img = Rs[0].Read_Framebuffer() + Rs[1].Read_Framebuffer()
+    assert same_bits(img, want["image"])
+    assert same_bits(Rs[0].Read_Texture(B.TEX_IRRADIANCE), want["irradiance"])
+    assert same_bits(Rs[1].Read_Texture(B.TEX_RADIANCE), want["radiance"])
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("overlap,gbuffer,scene", [(1, 0, "global_illumination"), (2, 0, "global_illumination"), (2, 1, "global_illumination"),
                                                    (2, 0, "light_shafts")])

@@ -1,5 +1,6 @@
 """The device-side exchange of the sharded frame (madarch_amd.sharding.DeviceExchange): the atlas
-is wrapped as a torch tensor without a copy and all-gathered in place with RCCL.  With one GPU on
+set of the open frame is wrapped as a torch tensor without a copy and all-gathered in place with
+RCCL on the renderer's probe stream.  With one GPU on
 the test box the group has a single rank, which still drives the whole code path (pointer
 aliasing, stream hand-over, in-place all_gather_into_tensor); the 2-rank logic is covered on the
 CPU by test_sharding_gloo.py and on the GPU through the host exchange by
@@ -29,11 +30,9 @@ R = make("global_illumination", 64, 40, hip, probes=SMALL_PROBES)
 ex = sharding.DeviceExchange(dist, R, torch.device("cuda", 0))
 frame = sharding.ShardedFrame(R, 0, 1, ex)
 for _ in range(2):
-    R.Render_Pass(B.PASS_RADIANCE)
-    ex.all_gather(R, B.TEX_RADIANCE, 0, 1)      # in place, one rank: must leave the atlas intact
-    R.Render_Pass(B.PASS_IRRADIANCE)
-    ex.all_gather(R, B.TEX_IRRADIANCE, 0, 1)
-    R.Render_Pass(B.PASS_SCREEN)
+    frame.Render()                               # Frame_Begin, probe passes with the in-place all-gathers
+                                                 # (one rank: must leave the atlas intact) on the probe stream, Frame_End
+R.Finish()
 torch.cuda.synchronize()
 # the torch view really aliases the library's atlas
 full, off, own, total = ex._view(R, B.TEX_IRRADIANCE)
