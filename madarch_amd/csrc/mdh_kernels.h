@@ -146,10 +146,16 @@ template <bool PART> __global__ __launch_bounds__(MDH_BLOCK, MDH_WAVES_PER_SIMD)
 // once (bilinear fetch + octahedral decode, spread over all lanes) into LDS, then every
 // lane owns one output texel and folds the taps in the reference's y, x order with LDS
 // broadcast reads -- ~13 VALU per tap and lane instead of ~370.
-#define MDH_IRR_BLOCK 64
+#ifndef MDH_IRR_BLOCK
+#define MDH_IRR_BLOCK 256 // all of them evaluate taps; the first ires^2 (one wavefront at 8x8) fold
+#endif
+#ifndef MDH_IRR_PACKED
+#define MDH_IRR_PACKED 1
+#endif
+typedef float pk2 __attribute__((ext_vector_type(2))); // two fp32 per VALU instruction (v_pk_mul_f32 / v_pk_add_f32: IEEE per component)
 __global__ __launch_bounds__(MDH_IRR_BLOCK) void k_irradiance(KProbes pr)
 {
-   extern __shared__ float4 s_taps[]; // [2 * rres * rres]: {rad.xyz, -} {dir.xyz, -}
+   extern __shared__ float4 s_taps[]; // [2 * rres * rres]: {rad.xyz, 1} {dir.xyz, -}
    const int probe = pr.probe_begin + blockIdx.x;
    if (probe >= pr.probe_end) return;
    const int ntaps = pr.rres * pr.rres;
@@ -163,7 +169,7 @@ __global__ __launch_bounds__(MDH_IRR_BLOCK) void k_irradiance(KProbes pr)
       f2 c = F2(clamp_(rad_coord.x + (float)xx * step.x, step.x, 1.0f - step.x), clamp_(rad_coord.y + (float)yy * step.y, step.y, 1.0f - step.y));
       f3 rad = atlas_sample(pr.rad, pr.fmt, pr.pcx, pr.pcy, pr.rres, pr.rshift, c.x, c.y, -1);
       f3 rad_dir = ray_id_to_ray_dir(F2(fract_(c.x * pcx), fract_(c.y * pcy)));
-      s_taps[2 * tap] = make_float4(rad.x, rad.y, rad.z, 0.0f);
+      s_taps[2 * tap] = make_float4(rad.x, rad.y, rad.z, 1.0f);
       s_taps[2 * tap + 1] = make_float4(rad_dir.x, rad_dir.y, rad_dir.z, 0.0f);
    }
    __syncthreads();
@@ -174,12 +180,29 @@ __global__ __launch_bounds__(MDH_IRR_BLOCK) void k_irradiance(KProbes pr)
       const f3 irr_dir = ray_id_to_ray_dir(F2(fract_(nc.x * pcx), fract_(nc.y * pcy)));
       f3 irradiance = F3(0.0f, 0.0f, 0.0f);
       float total_weight = 0.0f;
+#if MDH_IRR_PACKED
+      // the same operations, two per instruction: (x, y) and (z, weight) pairs.  1.0f * w = w exactly.
+      pk2 acc_xy = {0.0f, 0.0f}, acc_zw = {0.0f, 0.0f};
+      const pk2 dir_xy = {irr_dir.x, irr_dir.y};
+      for (int tap = 0; tap < ntaps; ++tap) {
+         const float4 r = s_taps[2 * tap], d = s_taps[2 * tap + 1];
+         const pk2 d_xy = {d.x, d.y}, r_xy = {r.x, r.y}, r_z1 = {r.z, r.w};
+         const pk2 p = dir_xy * d_xy;
+         const float w = max_((p.x + p.y) + irr_dir.z * d.z, 0.0f);
+         const pk2 ww = {w, w};
+         acc_xy = acc_xy + r_xy * ww;
+         acc_zw = acc_zw + r_z1 * ww;
+      }
+      irradiance = F3(acc_xy.x, acc_xy.y, acc_zw.x);
+      total_weight = acc_zw.y;
+#else
       for (int tap = 0; tap < ntaps; ++tap) {
          const float4 r = s_taps[2 * tap], d = s_taps[2 * tap + 1];
          float w = max_(dot(irr_dir, xyz(d)), 0.0f);
          irradiance = irradiance + xyz(r) * w;
          total_weight += w;
       }
+#endif
       irradiance = irradiance / total_weight;
       atlas_store(pr.irr, pr.fmt, atlas_index(pr.pcx, pr.ires, pr.ishift, i, j), irradiance);
    }
