@@ -60,13 +60,64 @@ typedef struct {
 /* One primitive or light kind with its declared maximum:
  * Scenes.Primitive_Count / Light_Count (madarch-scenes.ads:15-23).  Built-in
  * names: "Sphere", "Plane", "Box", "Triangle" (madarch-primitives-*.ads),
- * "PointLight", "SpotLight" (madarch-lights-*.ads). */
+ * "PointLight", "SpotLight" (madarch-lights-*.ads).
+ *
+ * Any other primitive name is a USER-DEFINED kind (Primitives.Create,
+ * madarch-primitives.ads:24-30): its Distance, Normal and Material expressions --
+ * the Exprs trees the reference turns into GLSL text (Exprs.To_GLSL,
+ * madarch-exprs.adb:325-711) -- arrive as three MDH_X programs (below) that the
+ * kernels interpret.  Built-in kinds leave the program fields NULL / 0. */
 typedef struct {
    const char *name;
    int32_t max_count;
    int32_t n_components;
    const mdh_component *components;
+   const int32_t *dist_code;     /* Distance (prim, x) -> float in R0            */
+   int32_t dist_len;
+   const int32_t *normal_code;   /* Normal (prim, x)   -> vec3 in R0, R1, R2     */
+   int32_t normal_len;
+   const int32_t *material_code; /* Material (prim)    -> int (raw bits) in R0   */
+   int32_t material_len;
 } mdh_kind_decl;
+
+/* ---- MDH_X: the register program a user-defined kind's expressions compile to.
+ *
+ * 64 registers R0..R63 of 32 raw bits per ray; a program is a straight line of
+ * int32 words, one instruction per word (two for MDH_X_LIT and MDH_X_SEL):
+ *     word = op | dst << 8 | a << 16 | b << 24
+ * Vector expressions are lowered by the front end to scalar instructions in the
+ * order the GLSL contract of DESIGN.md section 5 fixes: a vec3 lives in three
+ * registers, dot = (x x' + y y') + z z', dot2 (v) = dot (v, v), length = sqrt (dot2),
+ * normalize = v / length component by component, cross = (ay bz - az by, az bx - ax bz,
+ * ax by - ay bx), clamp (x, l, u) = min (max (x, l), u), Min (A, B, C) = min (min (A, B), C)
+ * (madarch-exprs.adb:154-155); If_Then_Else evaluates both sides and selects (the
+ * expressions have no side effects); Let_In binds registers.  Float literals are
+ * rounded through Single'Image like every literal of the generated GLSL
+ * (madarch-exprs.adb:330-336).  Arithmetic is IEEE fp32, one operation per
+ * instruction, division and square root correctly rounded. */
+enum {
+   MDH_X_LIT = 0,    /* R[dst] = the next word (raw bits)                          */
+   MDH_X_MOV = 1,    /* R[dst] = R[a]                                              */
+   MDH_X_COMP = 2,   /* R[dst] = float a of the instance: components in declaration
+                        order, a vec3 takes 3 floats, float / int 1 (raw bits)     */
+   MDH_X_POINT = 3,  /* R[dst] = x[a], a = 0, 1, 2: the point argument            */
+   MDH_X_ADD = 4, MDH_X_SUB = 5, MDH_X_MUL = 6,
+   MDH_X_DIV = 7,    /* true division: components of vector "/"                    */
+   MDH_X_DIVF = 8,   /* Float "/" Float: true division in the render passes; L + R in
+                        Eval_Distance_To when MDH_OPT_ADA_EVAL_DIV is set, as
+                        Madarch.Values."/" computes it (madarch-values.adb:112)     */
+   MDH_X_NEG = 9, MDH_X_ABS = 10, MDH_X_FLOOR = 11,
+   MDH_X_SIGN = 12,  /* 1, -1 or 0 (GLSL sign)                                     */
+   MDH_X_MIN = 13, MDH_X_MAX = 14, MDH_X_SQRT = 15,
+   MDH_X_POW = 16,   /* the fp32 pow of the shading path (oracle/orc_math.h)       */
+   MDH_X_LT = 17, MDH_X_GT = 18, MDH_X_LE = 19, MDH_X_GE = 20, /* 1.0f or 0.0f    */
+   MDH_X_SEL = 21,   /* R[dst] = R[a] != 0 ? R[b] : R[c], c = low byte of the next word */
+   MDH_X_ITOF = 22,  /* To_Float: R[dst] = (float) (int) R[a]                      */
+   MDH_X_ACOS = 23,  /* the fp32 acos of the shading path                           */
+   MDH_X_OPS = 24    /* sin, cos, tan, asin, atan: not implemented (MDH_E_UNSUPPORTED_KIND) */
+};
+#define MDH_X_REGS 64
+#define MDH_X_MAX_WORDS 4096 /* per program */
 
 /* = Scenes.Partitioning_Settings (madarch-scenes.ads:30-41) */
 typedef struct {

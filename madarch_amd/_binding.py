@@ -33,7 +33,10 @@ class mdh_component(C.Structure):
 
 class mdh_kind_decl(C.Structure):
     _fields_ = [("name", C.c_char_p), ("max_count", C.c_int32), ("n_components", C.c_int32),
-                ("components", C.POINTER(mdh_component))]
+                ("components", C.POINTER(mdh_component)),
+                ("dist_code", C.POINTER(C.c_int32)), ("dist_len", C.c_int32),
+                ("normal_code", C.POINTER(C.c_int32)), ("normal_len", C.c_int32),
+                ("material_code", C.POINTER(C.c_int32)), ("material_len", C.c_int32)]
 
 
 class mdh_partitioning(C.Structure):

@@ -46,6 +46,9 @@ struct Kind {
    int comp_kind[8], comp_off[8];
    int elem_size = 0, stride = 0, count_off = 0, array_off = 0;
    int f_a = -1, f_b = -1, f_c = -1, f_d = -1; // resolved field offsets
+   // user-defined kinds (PK_CUSTOM): the three MDH_X programs and the packed instance size
+   std::vector<int32_t> x_dist, x_nrm, x_mat;
+   int inst_floats = 0;
    int offset_of(const char *name, int kind) const
    {
       for (int i = 0; i < ncomp; ++i)
@@ -53,6 +56,28 @@ struct Kind {
       return -1;
    }
 };
+
+// An MDH_X program is accepted only if every word is a known instruction with in-range
+// operands (nothing the caller hands over is trusted to index the register file or the instance).
+static bool valid_program(const int32_t *code, int n, int inst_floats, bool has_point)
+{
+   if (!code || n < 1 || n > MDH_X_MAX_WORDS) return false;
+   for (int pc = 0; pc < n; ++pc) {
+      const uint32_t w = (uint32_t)code[pc];
+      const int op = w & 255, d = (w >> 8) & 255, a = (w >> 16) & 255, b = (w >> 24) & 255;
+      if (op >= MDH_X_OPS || d >= MDH_X_REGS) return false;
+      switch (op) {
+      case MDH_X_LIT: if (++pc >= n) return false; break;
+      case MDH_X_COMP: if (a >= inst_floats) return false; break;
+      case MDH_X_POINT: if (a > 2 || !has_point) return false; break;
+      case MDH_X_SEL:
+         if (a >= MDH_X_REGS || b >= MDH_X_REGS || ++pc >= n || (uint32_t)code[pc] >= MDH_X_REGS) return false;
+         break;
+      default: if (a >= MDH_X_REGS || b >= MDH_X_REGS) return false; break;
+      }
+   }
+   return true;
+}
 
 static bool resolve_kind(Kind &k, const mdh_kind_decl &d, bool is_light)
 {
@@ -62,6 +87,8 @@ static bool resolve_kind(Kind &k, const mdh_kind_decl &d, bool is_light)
    k.type = -1;
    for (int t = 0; t < (is_light ? 2 : 4); ++t)
       if (strcmp(d.name, is_light ? L[t] : P[t]) == 0) k.type = t;
+   const bool custom = k.type < 0 && !is_light && d.dist_code && d.normal_code && d.material_code;
+   if (custom) k.type = PK_CUSTOM;
    if (k.type < 0 || d.n_components < 1 || d.n_components > 8 || d.max_count < 0) return false;
    k.max_count = d.max_count;
    k.ncomp = d.n_components;
@@ -75,6 +102,19 @@ static bool resolve_kind(Kind &k, const mdh_kind_decl &d, bool is_light)
    }
    k.elem_size = off;
    k.stride = pad_to(off, 16);
+   if (custom) {
+      for (int i = 0; i < k.ncomp; ++i) {
+         if (k.comp_kind[i] != MDH_VEC3 && k.comp_kind[i] != MDH_FLOAT && k.comp_kind[i] != MDH_INT) return false;
+         k.inst_floats += k.comp_kind[i] == MDH_VEC3 ? 3 : 1;
+      }
+      if (!valid_program(d.dist_code, d.dist_len, k.inst_floats, true) || !valid_program(d.normal_code, d.normal_len, k.inst_floats, true) ||
+          !valid_program(d.material_code, d.material_len, k.inst_floats, false))
+         return false;
+      k.x_dist.assign(d.dist_code, d.dist_code + d.dist_len);
+      k.x_nrm.assign(d.normal_code, d.normal_code + d.normal_len);
+      k.x_mat.assign(d.material_code, d.material_code + d.material_len);
+      return true;
+   }
    if (!is_light) {
       k.f_d = k.offset_of("material_id", MDH_INT);
       switch (k.type) {
@@ -237,6 +277,23 @@ static int commit_scene(mdh_renderer *r)
       if (n < 0) n = 0;
       if (n > kd.max_count) n = kd.max_count;
       H[H_KTYPE + k] = kd.type; H[H_KCOUNT + k] = n; H[H_KBASE + k] = r->prim_base[k]; H[H_KMAX + k] = kd.max_count; H[H_KSLOT + k] = (int)t.size();
+      if (kd.type == PK_CUSTOM) { // instances packed as MDH_X_COMP addresses them: components in order, vec3 = 3 floats
+         const int stride = (kd.inst_floats + 3) / 4;
+         H[H_KSTRIDE + k] = stride;
+         for (int i = 0; i < n; ++i) {
+            const int b = kd.array_off + kd.stride * i;
+            float buf[32] = {0};
+            int f = 0;
+            for (int c = 0; c < kd.ncomp; ++c) {
+               const int nf = kd.comp_kind[c] == MDH_VEC3 ? 3 : 1;
+               memcpy(buf + f, r->scene_ubo.data() + b + kd.comp_off[c], 4 * nf); // ints travel as raw bits
+               f += nf;
+            }
+            for (int q = 0; q < stride; ++q) t.push_back(mk4(buf[4 * q], buf[4 * q + 1], buf[4 * q + 2], buf[4 * q + 3]));
+         }
+         continue;
+      }
+      H[H_KSTRIDE + k] = kd.type == PK_TRIANGLE ? 3 : (kd.type == PK_BOX ? 2 : 1);
       s.tcount[kd.type] = n; s.tslot[kd.type] = (int)t.size();
       for (int i = 0; i < n; ++i) {
          int b = kd.array_off + kd.stride * i;
@@ -278,8 +335,25 @@ static int commit_scene(mdh_renderer *r)
       }
    }
    // material ids (int32), 4 per float4
+   // the MDH_X programs of the user-defined kinds (ints, read through hdr ())
    for (int k = 0; k < r->npk; ++k) {
       const Kind &kd = r->pk[k];
+      if (kd.type != PK_CUSTOM) continue;
+      const std::vector<int32_t> *progs[3] = {&kd.x_dist, &kd.x_nrm, &kd.x_mat};
+      const int hs[3] = {H_XDIST, H_XNRM, H_XMAT}, hn[3] = {H_XDISTN, H_XNRMN, H_XMATN};
+      for (int q = 0; q < 3; ++q) {
+         H[hs[q] + k] = (int)t.size() * 4;
+         H[hn[q] + k] = (int)progs[q]->size();
+         for (size_t w0 = 0; w0 < progs[q]->size(); w0 += 4) {
+            float m[4] = {0, 0, 0, 0};
+            for (size_t j = 0; j < 4 && w0 + j < progs[q]->size(); ++j) m[j] = i_as_f((*progs[q])[w0 + j]);
+            t.push_back(mk4(m[0], m[1], m[2], m[3]));
+         }
+      }
+   }
+   for (int k = 0; k < r->npk; ++k) {
+      const Kind &kd = r->pk[k];
+      if (kd.type == PK_CUSTOM) continue;
       H[H_KMAT + k] = (int)t.size() * 4;
       for (int i0 = 0; i0 < H[H_KCOUNT + k]; i0 += 4) {
          float m[4] = {0, 0, 0, 0};
@@ -421,12 +495,15 @@ extern "C" int32_t mdh_create(int32_t width, int32_t height, const mdh_scene_des
    // Compute_Scene_GPU_Type (scenes.adb:1268-1345)
    int off = 0, base = 0;
    for (int k = 0; k < r->npk; ++k) {
-      if (!resolve_kind(r->pk[k], scene->prim_kinds[k], false)) { delete r; return seterr(MDH_E_UNSUPPORTED_KIND, "primitive kind is not one of Sphere, Plane, Box, Triangle with their components"); }
+      if (!resolve_kind(r->pk[k], scene->prim_kinds[k], false)) { delete r; return seterr(MDH_E_UNSUPPORTED_KIND, "primitive kind is neither one of Sphere, Plane, Box, Triangle with their components nor a user-defined kind with three valid MDH_X programs"); }
       off = pad_to(off, 4); r->pk[k].count_off = off; off += 4;
       off = pad_to(off, 16); r->pk[k].array_off = off; off += r->pk[k].stride * r->pk[k].max_count;
       r->prim_base[k] = base; base += r->pk[k].max_count;
       if (r->pk[k].max_count > 4095) { delete r; return seterr(MDH_E_INVALID, "declared primitive count above 4095"); }
    }
+   for (int k = 0; k < r->npk; ++k)
+      for (int j = 0; j < k; ++j)
+         if (r->pk[k].type != PK_CUSTOM && r->pk[k].type == r->pk[j].type) { delete r; return seterr(MDH_E_INVALID, "a built-in primitive kind is declared twice"); }
    for (int k = 0; k < r->nlk; ++k) {
       if (!resolve_kind(r->lk[k], scene->light_kinds[k], true)) { delete r; return seterr(MDH_E_UNSUPPORTED_KIND, "light kind is not PointLight or SpotLight with their components"); }
       off = pad_to(off, 4); r->lk[k].count_off = off; off += 4;
@@ -673,12 +750,12 @@ extern "C" int32_t mdh_update_partitioning(mdh_renderer *r, int32_t method)
    return MDH_OK;
 }
 
-template <bool PART, int MODE> static void launch_screen_g(mdh_renderer *r, hipStream_t st, const KProbes &pr, const KVolumetrics &vol, const KCamera &cam, const ScreenArgs &a, int blocks)
+template <int PART, int MODE> static void launch_screen_g(mdh_renderer *r, hipStream_t st, const KProbes &pr, const KVolumetrics &vol, const KCamera &cam, const ScreenArgs &a, int blocks)
 {
    if (r->opt_gbuffer) hipLaunchKernelGGL((k_screen<PART, MODE, true>), dim3(blocks), dim3(MDH_BLOCK), lds_bytes_march(r), st, r->ks, pr, vol, cam, a);
    else hipLaunchKernelGGL((k_screen<PART, MODE, false>), dim3(blocks), dim3(MDH_BLOCK), lds_bytes_march(r), st, r->ks, pr, vol, cam, a);
 }
-template <bool PART> static void launch_screen_m(mdh_renderer *r, hipStream_t st, const KProbes &pr, const KVolumetrics &vol, const KCamera &cam, const ScreenArgs &a, int blocks)
+template <int PART> static void launch_screen_m(mdh_renderer *r, hipStream_t st, const KProbes &pr, const KVolumetrics &vol, const KCamera &cam, const ScreenArgs &a, int blocks)
 {
    if (r->opt_mode == 0) launch_screen_g<PART, 0>(r, st, pr, vol, cam, a, blocks);
    else if (r->opt_mode == 1) launch_screen_g<PART, 1>(r, st, pr, vol, cam, a, blocks);
@@ -690,7 +767,19 @@ template <bool PART> static void launch_screen_m(mdh_renderer *r, hipStream_t st
 static int run_pass(mdh_renderer *r, int pass, hipStream_t st, int src, int dst, int fbix = -1)
 {
    if (fbix < 0) fbix = r->fb_last;
-   const bool part = r->part.enable != 0;
+   // kernel variant: bit 0 = space partition, bit 1 = user-defined kinds (mdh_device.h, MDH_PF_*)
+   bool has_custom = false;
+   for (int k = 0; k < r->npk; ++k) has_custom = has_custom || r->pk[k].type == PK_CUSTOM;
+   const int pf = (r->part.enable != 0 ? MDH_PF_PART : 0) | (has_custom ? MDH_PF_CUSTOM : 0);
+#define MDH_LAUNCH_PF(KERNEL, GRID, BLOCK, LDS, ...)                                                      \
+   do {                                                                                                   \
+      switch (pf) {                                                                                       \
+      case 0: hipLaunchKernelGGL(KERNEL<0>, GRID, BLOCK, LDS, st, __VA_ARGS__); break;                     \
+      case 1: hipLaunchKernelGGL(KERNEL<1>, GRID, BLOCK, LDS, st, __VA_ARGS__); break;                     \
+      case 2: hipLaunchKernelGGL(KERNEL<2>, GRID, BLOCK, LDS, st, __VA_ARGS__); break;                     \
+      default: hipLaunchKernelGGL(KERNEL<3>, GRID, BLOCK, LDS, st, __VA_ARGS__); break;                    \
+      }                                                                                                   \
+   } while (0)
    KProbes pr = make_probes(r);
    pr.rad = r->d_rad2[dst];
    pr.irr = r->d_irr2[pass == MDH_PASS_RADIANCE ? src : dst];
@@ -711,8 +800,7 @@ static int run_pass(mdh_renderer *r, int pass, hipStream_t st, int src, int dst,
       }
       if (n > 0) {
          int blocks = (int)((n + MDH_BLOCK - 1) / MDH_BLOCK);
-         if (part) hipLaunchKernelGGL(k_radiance<true>, dim3(blocks), dim3(MDH_BLOCK), lds_bytes_march(r), st, r->ks, pr);
-         else hipLaunchKernelGGL(k_radiance<false>, dim3(blocks), dim3(MDH_BLOCK), lds_bytes_march(r), st, r->ks, pr);
+         MDH_LAUNCH_PF(k_radiance, dim3(blocks), dim3(MDH_BLOCK), lds_bytes_march(r), r->ks, pr);
       }
       break;
    }
@@ -728,8 +816,7 @@ static int run_pass(mdh_renderer *r, int pass, hipStream_t st, int src, int dst,
       long n = (long)vol.vw * vol.vh * vol.vz;
       if (n > 0) {
          int blocks = (int)((n + MDH_BLOCK - 1) / MDH_BLOCK);
-         if (part) hipLaunchKernelGGL(k_visibility<true>, dim3(blocks), dim3(MDH_BLOCK), lds_bytes(r), st, r->ks, vol, cam);
-         else hipLaunchKernelGGL(k_visibility<false>, dim3(blocks), dim3(MDH_BLOCK), lds_bytes(r), st, r->ks, vol, cam);
+         MDH_LAUNCH_PF(k_visibility, dim3(blocks), dim3(MDH_BLOCK), lds_bytes(r), r->ks, vol, cam);
       }
       break;
    }
@@ -738,8 +825,7 @@ static int run_pass(mdh_renderer *r, int pass, hipStream_t st, int src, int dst,
       long n = (long)vol.sw * vol.sh;
       if (n > 0) {
          int blocks = (int)((n + MDH_BLOCK - 1) / MDH_BLOCK);
-         if (part) hipLaunchKernelGGL(k_scattering<true>, dim3(blocks), dim3(MDH_BLOCK), lds_bytes(r), st, r->ks, vol, cam);
-         else hipLaunchKernelGGL(k_scattering<false>, dim3(blocks), dim3(MDH_BLOCK), lds_bytes(r), st, r->ks, vol, cam);
+         MDH_LAUNCH_PF(k_scattering, dim3(blocks), dim3(MDH_BLOCK), lds_bytes(r), r->ks, vol, cam);
       }
       break;
    }
@@ -756,8 +842,12 @@ static int run_pass(mdh_renderer *r, int pass, hipStream_t st, int src, int dst,
       int own_tiles = (a.n_tiles - a.rank + a.world - 1) / a.world;
       if (own_tiles > 0) {
          int blocks = (own_tiles + (MDH_BLOCK / 64) - 1) / (MDH_BLOCK / 64);
-         if (part) launch_screen_m<true>(r, st, pr, vol, cam, a, blocks);
-         else launch_screen_m<false>(r, st, pr, vol, cam, a, blocks);
+         switch (pf) {
+         case 0: launch_screen_m<0>(r, st, pr, vol, cam, a, blocks); break;
+         case 1: launch_screen_m<1>(r, st, pr, vol, cam, a, blocks); break;
+         case 2: launch_screen_m<2>(r, st, pr, vol, cam, a, blocks); break;
+         default: launch_screen_m<3>(r, st, pr, vol, cam, a, blocks); break;
+         }
       }
       break;
    }

@@ -25,10 +25,10 @@
 #define MDH_TRI static __device__ __noinline__
 #endif
 
-#define MDH_MAX_KINDS 4
+#define MDH_MAX_KINDS 8
 #define MDH_MAX_LIGHT_KINDS 4
 
-enum { PK_SPHERE = 0, PK_PLANE = 1, PK_BOX = 2, PK_TRIANGLE = 3 };
+enum { PK_SPHERE = 0, PK_PLANE = 1, PK_BOX = 2, PK_TRIANGLE = 3, PK_CUSTOM = 4 }; // PK_CUSTOM: a user-defined kind (MDH_X programs)
 enum { LK_POINT = 0, LK_SPOT = 1 };
 
 // ---------------------------------------------------------------- kernel argument blocks
@@ -63,17 +63,20 @@ struct KScene {
 // and the arg-min tie-break follow, scenes.adb:656-666) and the light kinds
 enum {
    H_NK = 0,
-   H_KTYPE = 1,   // [4] PK_*
-   H_KCOUNT = 5,  // [4] runtime count (prim_<K>_count, scenes.adb:560-565)
-   H_KBASE = 9,   // [4] flat index base = sum of earlier DECLARED counts
-   H_KMAX = 13,   // [4] declared count
-   H_KSLOT = 17,  // [4] first float4 of the kind's geometry
-   H_KMAT = 21,   // [4] first int of the kind's material ids
-   H_NL = 25,
-   H_LTYPE = 26,  // [4]
-   H_LCOUNT = 30, // [4]
-   H_LSLOT = 34,  // [4]
-   H_INTS = 40    // 10 float4
+   H_NL = 1,
+   H_KTYPE = 8,    // [8] PK_*
+   H_KCOUNT = 16,  // [8] runtime count (prim_<K>_count, scenes.adb:560-565)
+   H_KBASE = 24,   // [8] flat index base = sum of earlier DECLARED counts
+   H_KMAX = 32,    // [8] declared count
+   H_KSLOT = 40,   // [8] first float4 of the kind's geometry
+   H_KMAT = 48,    // [8] first int of the kind's material ids (built-in kinds)
+   H_KSTRIDE = 56, // [8] float4 per instance
+   // user-defined kinds: first int and length of the MDH_X programs (include/madarch_hip.h)
+   H_XDIST = 64, H_XDISTN = 72, H_XNRM = 80, H_XNRMN = 88, H_XMAT = 96, H_XMATN = 104,
+   H_LTYPE = 112,  // [4]
+   H_LCOUNT = 116, // [4]
+   H_LSLOT = 120,  // [4]
+   H_INTS = 124    // 31 float4
 };
 
 struct KProbes {
@@ -318,6 +321,70 @@ template <bool ADA_DIV> MDH_TRI f3 nrm_triangle(f3 a, f3 b, f3 c, f3 p)
    return normalize(F3(fx, fy, fz));
 }
 
+// ------------------------------------------------------------- user-defined kinds: MDH_X
+// The interpreter of the register programs include/madarch_hip.h specifies (one IEEE fp32
+// operation per instruction).  The program is wave-uniform -- its words come out of the LDS table
+// through readfirstlane, the dispatch is scalar branches -- while the instance (`ent`, a float
+// index into the table) and the point are per lane.  The 64 registers are one vector value whose
+// element index is uniform, which hipcc maps onto VGPRs with s_set_gpr_idx (no scratch).
+// (two banks of 32: a 32-dword tuple is the widest register class gfx950 indexes dynamically)
+typedef float xbank __attribute__((ext_vector_type(32)));
+struct XRegs {
+   xbank lo, hi;
+   __device__ __forceinline__ float get(int i) const { return (i & 32) ? hi[i & 31] : lo[i & 31]; } // i is wave-uniform: a scalar branch
+   __device__ __forceinline__ void put(int i, float v)
+   {
+      if (i & 32) hi[i & 31] = v;
+      else lo[i & 31] = v;
+   }
+};
+template <bool ADA_DIV> static __device__ __noinline__ f3 xrun(int code, int n, int ent, f3 x)
+{
+   XRegs R;
+   R.lo = 0.0f; R.hi = 0.0f;
+#pragma unroll 1
+   for (int pc = 0; pc < n; ++pc) {
+      const int w = hdr(code + pc);
+      const int op = w & 255, d = (w >> 8) & 63, a = (w >> 16) & 255, b = (w >> 24) & 63;
+      const float va = R.get(a & 63), vb = R.get(b);
+      float r;
+      switch (op) {
+      case 0: r = __builtin_bit_cast(float, hdr(code + ++pc)); break;                  // LIT
+      case 1: r = va; break;                                                          // MOV
+      case 2: r = tab_float(ent + a); break;                                          // COMP
+      case 3: r = a == 0 ? x.x : (a == 1 ? x.y : x.z); break;                         // POINT
+      case 4: r = va + vb; break;
+      case 5: r = va - vb; break;
+      case 6: r = va * vb; break;
+      case 7: r = va / vb; break;
+      case 8: r = ADA_DIV ? va + vb : va / vb; break;                                 // DIVF
+      case 9: r = -va; break;
+      case 10: r = __builtin_fabsf(va); break;
+      case 11: r = __builtin_floorf(va); break;
+      case 12: r = sign_(va); break;
+      case 13: r = min_(va, vb); break;
+      case 14: r = max_(va, vb); break;
+      case 15: r = sqrt_(va); break;
+      case 16: r = pow_(va, vb); break;
+      case 17: r = va < vb ? 1.0f : 0.0f; break;
+      case 18: r = va > vb ? 1.0f : 0.0f; break;
+      case 19: r = va <= vb ? 1.0f : 0.0f; break;
+      case 20: r = va >= vb ? 1.0f : 0.0f; break;
+      case 21: { const float vc = R.get(hdr(code + ++pc) & 63); r = va != 0.0f ? vb : vc; break; } // SEL
+      case 22: r = (float)__builtin_bit_cast(int, va); break;                          // ITOF
+      case 23: r = acos_(va); break;
+      default: r = 0.0f; break;
+      }
+      R.put(d, r);
+   }
+   return F3(R.get(0), R.get(1), R.get(2));
+}
+// distance of instance i of user-defined kind k (scene order); k uniform, i per lane
+template <bool ADA_DIV> MDH_DEV float xdist(int k, int i, f3 x)
+{
+   return xrun<ADA_DIV>(hdr(H_XDIST + k), hdr(H_XDISTN + k), (hdr(H_KSLOT + k) + hdr(H_KSTRIDE + k) * i) * 4, x).x;
+}
+
 // dist_to_<Kind>(prims[i], x); `slot` = first float4 of the primitive (any lane value)
 MDH_DEV float prim_dist(int type, int slot, f3 x)
 {
@@ -346,7 +413,7 @@ MDH_DEV float prim_dist(int type, int slot, f3 x)
 #ifndef MDH_CULL
 #define MDH_CULL 1
 #endif
-MDH_DEV float closest_primitive(const KScene &sc, f3 x)
+template <bool CUSTOM> MDH_DEV float closest_primitive(const KScene &sc, f3 x)
 {
    float closest = sc.max_dist;
    if (sc.n_axis > 0) { // six adds for all axis-aligned planes together
@@ -392,11 +459,21 @@ MDH_DEV float closest_primitive(const KScene &sc, f3 x)
       for (int i = 0; i < n; ++i)
          closest = min_(closest, sd_triangle<false>(xyz(s_tab[s0 + 3 * i]), xyz(s_tab[s0 + 3 * i + 1]), xyz(s_tab[s0 + 3 * i + 2]), x));
    }
+   if (CUSTOM) { // user-defined kinds: their Distance programs, interpreted
+      const int nk = hdr(H_NK);
+#pragma unroll 1
+      for (int k = 0; k < nk; ++k) {
+         if (hdr(H_KTYPE + k) != PK_CUSTOM) continue;
+         const int n = hdr(H_KCOUNT + k);
+#pragma unroll 1
+         for (int i = 0; i < n; ++i) closest = min_(closest, xdist<false>(k, i, x));
+      }
+   }
    return closest;
 }
 // closest_primitive_info (scenes.adb:631-674): kinds in SCENE order (the arg-min keeps the
 // first of equal distances).  Only evaluated at hit points, so compact rather than fast.
-MDH_DEV float closest_primitive_info(const KScene &sc, f3 x, int &index)
+template <bool CUSTOM> MDH_DEV float closest_primitive_info(const KScene &sc, f3 x, int &index)
 {
    float closest = sc.max_dist;
    const int nk = hdr(H_NK);
@@ -405,7 +482,7 @@ MDH_DEV float closest_primitive_info(const KScene &sc, f3 x, int &index)
       const int n = hdr(H_KCOUNT + k), s0 = hdr(H_KSLOT + k), base = hdr(H_KBASE + k), type = hdr(H_KTYPE + k);
 #pragma unroll 1
       for (int i = 0; i < n; ++i) {
-         float d = prim_dist(type, s0 + prim_slots(type) * i, x);
+         float d = (CUSTOM && type == PK_CUSTOM) ? xdist<false>(k, i, x) : prim_dist(type, s0 + prim_slots(type) * i, x);
          if (d < closest) { closest = d; index = base + i; }
       }
    }
@@ -414,7 +491,7 @@ MDH_DEV float closest_primitive_info(const KScene &sc, f3 x, int &index)
 
 // material id and normal of a flat index: primitive_info (scenes.adb:676-729),
 // kind found by successive subtraction of the DECLARED counts
-MDH_DEV void primitive_info(const KScene &sc, int index, f3 pos, f3 &normal, int &material_id)
+template <bool CUSTOM> MDH_DEV void primitive_info(const KScene &sc, int index, f3 pos, f3 &normal, int &material_id)
 {
    normal = F3(0.0f, 0.0f, 0.0f);
    material_id = 0;
@@ -424,6 +501,12 @@ MDH_DEV void primitive_info(const KScene &sc, int index, f3 pos, f3 &normal, int
       const int kmax = hdr(H_KMAX + k);
       if (index < kmax) {
          const int type = hdr(H_KTYPE + k);
+         if (CUSTOM && type == PK_CUSTOM) { // the kind's Normal and Material programs on this lane's instance
+            const int ent = (hdr(H_KSLOT + k) + hdr(H_KSTRIDE + k) * index) * 4;
+            normal = xrun<false>(hdr(H_XNRM + k), hdr(H_XNRMN + k), ent, pos);
+            material_id = __builtin_bit_cast(int, xrun<false>(hdr(H_XMAT + k), hdr(H_XMATN + k), ent, pos).x);
+            return;
+         }
          const int slot = hdr(H_KSLOT + k) + prim_slots(type) * index; // per-lane LDS gather
          material_id = tab_int(hdr(H_KMAT + k) + index);
          float4 a = s_tab[slot];
@@ -454,11 +537,11 @@ MDH_DEV int partition_cell(const KScene &sc, f3 x, bool &fallback)
 }
 // partitioning_closest[_info] (scenes.adb:839-1118): per-lane cell record from HBM/L2,
 // per-lane primitive gather from LDS
-template <bool INFO> MDH_DEV float partitioning_lookup(const KScene &sc, f3 x, int &index)
+template <bool INFO, bool CUSTOM> MDH_DEV float partitioning_lookup(const KScene &sc, f3 x, int &index)
 {
    bool fb;
    int cell = partition_cell(sc, x, fb);
-   if (fb) return INFO ? closest_primitive_info(sc, x, index) : closest_primitive(sc, x);
+   if (fb) return INFO ? closest_primitive_info<CUSTOM>(sc, x, index) : closest_primitive<CUSTOM>(sc, x);
    float closest = sc.max_dist;
    if (cell < 0 || cell >= sc.part_cells) return closest;
    const int nk = hdr(H_NK);
@@ -470,7 +553,7 @@ template <bool INFO> MDH_DEV float partitioning_lookup(const KScene &sc, f3 x, i
       const int stop = min(size, sc.part_index_count);
       for (; i < stop; ++i) {
          int pi = rec[nk + i];
-         float d = prim_dist(type, s0 + prim_slots(type) * pi, x);
+         float d = (CUSTOM && type == PK_CUSTOM) ? xdist<false>(k, pi, x) : prim_dist(type, s0 + prim_slots(type) * pi, x);
          if (INFO) { if (d < closest) { closest = d; index = base + pi; } }
          else closest = min_(closest, d);
       }
@@ -478,21 +561,24 @@ template <bool INFO> MDH_DEV float partitioning_lookup(const KScene &sc, f3 x, i
    }
    return closest;
 }
-template <bool PART> MDH_DEV float sdf(const KScene &sc, f3 x)
+// PART is a set of flags: bit 0 = the space partition is on, bit 1 = the scene has user-defined kinds
+#define MDH_PF_PART 1
+#define MDH_PF_CUSTOM 2
+template <int PART> MDH_DEV float sdf(const KScene &sc, f3 x)
 {
    int dummy;
-   if (PART) return partitioning_lookup<false>(sc, x, dummy);
-   return closest_primitive(sc, x);
+   if (PART & MDH_PF_PART) return partitioning_lookup<false, (PART & MDH_PF_CUSTOM) != 0>(sc, x, dummy);
+   return closest_primitive<(PART & MDH_PF_CUSTOM) != 0>(sc, x);
 }
-template <bool PART> MDH_DEV float sdf_info(const KScene &sc, f3 x, int &index)
+template <int PART> MDH_DEV float sdf_info(const KScene &sc, f3 x, int &index)
 {
-   if (PART) return partitioning_lookup<true>(sc, x, index);
-   return closest_primitive_info(sc, x, index);
+   if (PART & MDH_PF_PART) return partitioning_lookup<true, (PART & MDH_PF_CUSTOM) != 0>(sc, x, index);
+   return closest_primitive_info<(PART & MDH_PF_CUSTOM) != 0>(sc, x, index);
 }
 
 // ------------------------------------------------------------------------- raymarching
 // glsl/raymarching.glsl:25-37
-template <bool PART> MDH_DEV bool raycast(const KScene &sc, f3 from, f3 dir, int &index, f3 &coll, float &t_out, int &steps)
+template <int PART> MDH_DEV bool raycast(const KScene &sc, f3 from, f3 dir, int &index, f3 &coll, float &t_out, int &steps)
 {
    int n = 0;
    for (float total = 0.0f; total < sc.max_dist;) {
@@ -510,7 +596,7 @@ template <bool PART> MDH_DEV bool raycast(const KScene &sc, f3 from, f3 dir, int
    return false;
 }
 // glsl/raymarching.glsl:39-56: raycast_visibility = 1 - float(hit)
-template <bool PART> MDH_DEV float raycast_visibility(const KScene &sc, f3 from, f3 dir, float max_dist)
+template <int PART> MDH_DEV float raycast_visibility(const KScene &sc, f3 from, f3 dir, float max_dist)
 {
    for (float total = 0.0f; total < max_dist;) {
       float dist = sdf<PART>(sc, from + dir * total);

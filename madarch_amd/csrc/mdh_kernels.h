@@ -20,6 +20,8 @@
 #ifndef MDH_RAD_PROBES_PER_WAVE
 #define MDH_RAD_PROBES_PER_WAVE 64 // 1, 4, 16 or 64 (measured on MI355X: see DESIGN.md)
 #endif
+// kernels of scenes with user-defined kinds carry the 64-register file of the MDH_X interpreter
+#define MDH_OCC(PART) (((PART) & MDH_PF_CUSTOM) ? 2 : MDH_WAVES_PER_SIMD)
 #ifndef MDH_RAD_QVIS
 #define MDH_RAD_QVIS 1 // probe-visibility rays through the wave's ray queue (mdh_march.h: queued_visibility)
 #endif
@@ -47,8 +49,8 @@ struct ScreenArgs {
 
 // draw_screen.glsl:20-30.  One wavefront per 8x8 pixel tile: lane = (y & 7) * 8 + (x & 7);
 // the tile's 64 pixels run through the ray state machine of mdh_march.h together.
-template <bool PART, int MODE, bool GBUF>
-__global__ __launch_bounds__(MDH_BLOCK, MDH_WAVES_PER_SIMD) void k_screen(KScene sc, KProbes pr, KVolumetrics vol, KCamera cam, ScreenArgs a)
+template <int PART, int MODE, bool GBUF>
+__global__ __launch_bounds__(MDH_BLOCK, MDH_OCC(PART)) void k_screen(KScene sc, KProbes pr, KVolumetrics vol, KCamera cam, ScreenArgs a)
 {
    stage_table(sc);
    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -89,7 +91,7 @@ __global__ __launch_bounds__(MDH_BLOCK, MDH_WAVES_PER_SIMD) void k_screen(KScene
 // ---------------------------------------------------------------------- radiance pass
 // compute_probe_radiance.glsl:16-27.  One wavefront per 8x8 texel tile of one probe's
 // octahedral map; all 64 rays of a wave leave the same probe position.
-template <bool PART> __global__ __launch_bounds__(MDH_BLOCK, MDH_WAVES_PER_SIMD) void k_radiance(KScene sc, KProbes pr)
+template <int PART> __global__ __launch_bounds__(MDH_BLOCK, MDH_OCC(PART)) void k_radiance(KScene sc, KProbes pr)
 {
    stage_table(sc);
    const int per_probe = pr.rres * pr.rres;
@@ -210,7 +212,7 @@ __global__ __launch_bounds__(MDH_IRR_BLOCK) void k_irradiance(KProbes pr)
 
 // -------------------------------------------------------------------- visibility pass
 // compute_frustrum_visibility.glsl:8-42: one froxel (x, y, depth slice) per lane
-template <bool PART> __global__ __launch_bounds__(MDH_BLOCK) void k_visibility(KScene sc, KVolumetrics vol, KCamera cam)
+template <int PART> __global__ __launch_bounds__(MDH_BLOCK) void k_visibility(KScene sc, KVolumetrics vol, KCamera cam)
 {
    stage_table(sc);
    const int W = vol.vw, H = vol.vh * vol.vz;
@@ -251,7 +253,7 @@ template <bool PART> __global__ __launch_bounds__(MDH_BLOCK) void k_visibility(K
 
 // -------------------------------------------------------------------- scattering pass
 // accumulate_scattering.glsl:9-48
-template <bool PART> __global__ __launch_bounds__(MDH_BLOCK) void k_scattering(KScene sc, KVolumetrics vol, KCamera cam)
+template <int PART> __global__ __launch_bounds__(MDH_BLOCK) void k_scattering(KScene sc, KVolumetrics vol, KCamera cam)
 {
    stage_table(sc);
    const int W = vol.sw, H = vol.sh;
@@ -308,6 +310,13 @@ template <bool ADA_DIV> MDH_DEV float part_dist(const KScene &sc, int k, int i, 
 {
    // k may differ per lane here (candidate lists): plain per-lane header reads, not hdr()
    const int type = tab_int(H_KTYPE + k), slot = tab_int(H_KSLOT + k) + prim_slots(type) * i;
+   if (type == PK_CUSTOM) { // the program must be wave-uniform: one round per user-defined kind, its lanes active
+      float r = 0.0f;
+      const int nk = hdr(H_NK);
+      for (int kk = 0; kk < nk; ++kk)
+         if (hdr(H_KTYPE + kk) == PK_CUSTOM && k == kk) r = xdist<ADA_DIV>(kk, i, x);
+      return r;
+   }
    if (type == PK_TRIANGLE) return sd_triangle<ADA_DIV>(xyz(s_tab[slot]), xyz(s_tab[slot + 1]), xyz(s_tab[slot + 2]), x);
    return prim_dist(type, slot, x);
 }
@@ -329,7 +338,7 @@ __global__ __launch_bounds__(64) void k_partition_build(KScene sc, PartBuildArgs
    unsigned char accepted[MDH_PART_MAX_PRE];
    if (a.method == 2) {
       const f3 center = (F3((float)X, (float)Y, (float)Z) + F3s(0.5f)) * sp + off;
-      const float thr = closest_primitive(sc, center) + a.gpu_diag;
+      const float thr = closest_primitive<true>(sc, center) + a.gpu_diag;
       for (int k = 0; k < nk; ++k)
          for (int i = 0; i < hdr(H_KCOUNT + k); ++i)
             if (part_dist<false>(sc, k, i, center) < thr && npre < MDH_PART_MAX_PRE) { pre[npre] = (unsigned short)((k << 12) | i); accepted[npre++] = 1; }
@@ -417,6 +426,7 @@ template <bool ADA_DIV> __global__ __launch_bounds__(64) void k_eval_distance(KS
             const int slot = hdr(H_KSLOT + k) + prim_slots(type) * i;
             float4 A = s_tab[slot];
             switch (type) {
+            case PK_CUSTOM: normal = xrun<ADA_DIV>(hdr(H_XNRM + k), hdr(H_XNRMN + k), (hdr(H_KSLOT + k) + hdr(H_KSTRIDE + k) * i) * 4, p); break;
             case PK_SPHERE: normal = normalize(p - xyz(A)); break;
             case PK_PLANE: normal = xyz(A); break;
             case PK_BOX: normal = nrm_box(A, s_tab[slot + 1], p); break;

@@ -110,7 +110,7 @@ struct DiagWaveTimer {
 #endif
 
 // raymarching.glsl:25-51: plain sphere trace until a hit or tmax; `steps` counts SDF evaluations
-template <bool PART> MDH_DEV bool march_plain(const KScene &sc, f3 o, f3 d, float tmax, float &t_out, int &steps)
+template <int PART> MDH_DEV bool march_plain(const KScene &sc, f3 o, f3 d, float tmax, float &t_out, int &steps)
 {
    int n = 0;
    bool h = false;
@@ -173,7 +173,7 @@ MDH_DEV unsigned short *qvis_entry(float *pk, int wbase, int j)
 {
    return (unsigned short *)(pk + (12 + (j >> 7)) * MDH_BLOCK + wbase) + (j & 127);
 }
-template <bool PART>
+template <int PART>
 MDH_DEV int queued_visibility(const KScene &sc, const KProbes &pr, float *pk, f3 P, f3 N, i3 gp, int folded, float sd0)
 {
    const int lane = threadIdx.x & 63, wbase = threadIdx.x & ~63;
@@ -245,7 +245,7 @@ MDH_DEV int queued_visibility(const KScene &sc, const KProbes &pr, float *pk, f3
    return bits | words[threadIdx.x];
 }
 
-template <bool PART, int MODE, bool REFLECT, bool QVIS>
+template <int PART, int MODE, bool REFLECT, bool QVIS>
 MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCfg cfg, bool lane_valid, f3 from, f3 dir_in,
                             PrimaryHit &ph, bool &hit, f3 &pos_out)
 {
@@ -276,7 +276,7 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
             (void)sdf_info<PART>(sc, P, index);
             f3 N;
             int pm;
-            primitive_info(sc, index, P, N, pm);
+            primitive_info<(PART & MDH_PF_CUSTOM) != 0>(sc, index, P, N, pm);
             if (ctx == 0) {
                mat_id = pm;
                ph.index = index; ph.t = t;

@@ -34,7 +34,7 @@
 #define MAX_KINDS 8
 #define MAX_MATERIALS 20 /* glsl/materials.glsl:9 */
 
-enum { PK_SPHERE = 0, PK_PLANE = 1, PK_BOX = 2, PK_TRIANGLE = 3 };
+enum { PK_SPHERE = 0, PK_PLANE = 1, PK_BOX = 2, PK_TRIANGLE = 3, PK_CUSTOM = 4 }; /* PK_CUSTOM: user-defined kind (MDH_X programs, include/madarch_hip.h) */
 enum { LK_POINT = 0, LK_SPOT = 1 };
 
 /* oracle-only options (>= 100) */
@@ -69,6 +69,11 @@ typedef struct {
    int count_off, array_off;
    /* resolved field offsets inside an element */
    int f_a, f_b, f_c, f_mat;
+   /* user-defined kinds: the three MDH_X programs and, for MDH_X_COMP, the byte offset inside an
+    * element of every float of the packed instance (components in order, vec3 = 3 floats) */
+   int32_t *x_code[3];
+   int x_len[3];
+   int x_float_off[24], inst_floats;
 } kind_t;
 
 static int comp_offset(const kind_t *k, const char *name, int kind)
@@ -226,9 +231,59 @@ static void make_entity(const orc_renderer *r, const kind_t *k, int i, entity *e
    }
 }
 
+/* The MDH_X register programs of a user-defined kind (include/madarch_hip.h): the oracle's own
+ * interpreter, a plain switch over the instruction list.  which: 0 Distance, 1 Normal, 2 Material. */
+static void orc_xrun(const orc_renderer *r, const kind_t *k, int which, int inst, v3 x, int ada_div, float out[3])
+{
+   float R[MDH_X_REGS];
+   memset(R, 0, sizeof R);
+   const int32_t *code = k->x_code[which];
+   const int n = k->x_len[which], base = k->array_off + k->stride * inst;
+   for (int pc = 0; pc < n; ++pc) {
+      const uint32_t w = (uint32_t)code[pc];
+      const int op = w & 255, d = (w >> 8) & 63, a = (w >> 16) & 255, b = (w >> 24) & 63;
+      const float va = R[a & 63], vb = R[b];
+      float res = 0.0f;
+      switch (op) {
+      case MDH_X_LIT: memcpy(&res, &code[++pc], 4); break;
+      case MDH_X_MOV: res = va; break;
+      case MDH_X_COMP: res = ubo_f(r, base + k->x_float_off[a]); break;
+      case MDH_X_POINT: res = a == 0 ? x.x : (a == 1 ? x.y : x.z); break;
+      case MDH_X_ADD: res = va + vb; break;
+      case MDH_X_SUB: res = va - vb; break;
+      case MDH_X_MUL: res = va * vb; break;
+      case MDH_X_DIV: res = va / vb; break;
+      case MDH_X_DIVF: res = ada_div ? va + vb : va / vb; break;
+      case MDH_X_NEG: res = -va; break;
+      case MDH_X_ABS: res = fabsf(va); break;
+      case MDH_X_FLOOR: res = floorf(va); break;
+      case MDH_X_SIGN: res = sign_(va); break;
+      case MDH_X_MIN: res = fmin_(va, vb); break;
+      case MDH_X_MAX: res = fmax_(va, vb); break;
+      case MDH_X_SQRT: res = sqrtf(va); break;
+      case MDH_X_POW: res = pow_(va, vb); break;
+      case MDH_X_LT: res = va < vb ? 1.0f : 0.0f; break;
+      case MDH_X_GT: res = va > vb ? 1.0f : 0.0f; break;
+      case MDH_X_LE: res = va <= vb ? 1.0f : 0.0f; break;
+      case MDH_X_GE: res = va >= vb ? 1.0f : 0.0f; break;
+      case MDH_X_SEL: { const float vc = R[code[++pc] & 63]; res = va != 0.0f ? vb : vc; break; }
+      case MDH_X_ITOF: { int32_t iv; memcpy(&iv, &va, 4); res = (float)iv; break; }
+      case MDH_X_ACOS: res = acos_(va); break;
+      default: break;
+      }
+      R[d] = res;
+   }
+   out[0] = R[0]; out[1] = R[1]; out[2] = R[2];
+}
+
 /* dist_to_<Kind>(prims[i], x) as emitted by scenes.adb:417-455 */
 static inline float prim_dist(const orc_renderer *r, const kind_t *k, int i, v3 x)
 {
+   if (k->type == PK_CUSTOM) {
+      float o[3];
+      orc_xrun(r, k, 0, i, x, 0, o);
+      return o[0];
+   }
    if (r->opt_sdf_mode == 1) {
       entity e;
       make_entity(r, k, i, &e);
@@ -245,6 +300,11 @@ static inline float prim_dist(const orc_renderer *r, const kind_t *k, int i, v3 
 /* <Kind>_normal(prims[i], x) as emitted by scenes.adb:457-495 */
 static inline v3 prim_normal(const orc_renderer *r, const kind_t *k, int i, v3 x)
 {
+   if (k->type == PK_CUSTOM) {
+      float o[3];
+      orc_xrun(r, k, 1, i, x, 0, o);
+      return V3(o[0], o[1], o[2]);
+   }
    if (r->opt_sdf_mode == 1) {
       entity e;
       make_entity(r, k, i, &e);
@@ -291,7 +351,12 @@ static void primitive_info(const orc_renderer *r, int index, v3 pos, v3 *normal,
       const kind_t *kk = &r->pk[k];
       if (index < kk->max_count) {
          *normal = prim_normal(r, kk, index, pos);
-         *material_id = ubo_i(r, kk->array_off + kk->stride * index + kk->f_mat);
+         if (kk->type == PK_CUSTOM) {
+            float o[3];
+            orc_xrun(r, kk, 2, index, pos, 0, o);
+            memcpy(material_id, &o[0], 4);
+         } else
+            *material_id = ubo_i(r, kk->array_off + kk->stride * index + kk->f_mat);
          return;
       }
       index -= kk->max_count;
@@ -365,6 +430,11 @@ static float partitioning_closest_info(const orc_renderer *r, v3 x, int *index)
 /* Primitives.Eval_Dist on the host copy (madarch-primitives.adb:90-108): always the tree evaluator */
 static float host_eval_dist(const orc_renderer *r, int k, int i, v3 p)
 {
+   if (r->pk[k].type == PK_CUSTOM) { /* the CPU builders evaluate with Madarch.Values: "/" on floats adds */
+      float o[3];
+      orc_xrun(r, &r->pk[k], 0, i, p, 1, o);
+      return o[0];
+   }
    entity e;
    make_entity(r, &r->pk[k], i, &e);
    return orc_eval_dist(r->pk[k].type, &e, p);
@@ -1112,6 +1182,8 @@ static int resolve_kind(kind_t *k, const mdh_kind_decl *d, int is_light)
    int n = is_light ? 2 : 4;
    for (int t = 0; t < n; ++t)
       if (strcmp(d->name, is_light ? LIGHT_NAMES[t] : PRIM_NAMES[t]) == 0) k->type = t;
+   int custom = k->type < 0 && !is_light && d->dist_code && d->normal_code && d->material_code;
+   if (custom) k->type = PK_CUSTOM;
    if (k->type < 0 || d->n_components > 8 || d->n_components < 1) return 0;
    k->max_count = d->max_count;
    k->ncomp = d->n_components;
@@ -1121,6 +1193,26 @@ static int resolve_kind(kind_t *k, const mdh_kind_decl *d, int is_light)
    }
    layout_kind(k);
    k->f_a = k->f_b = k->f_c = k->f_mat = -1;
+   if (custom) {
+      const int32_t *src[3] = {d->dist_code, d->normal_code, d->material_code};
+      const int len[3] = {d->dist_len, d->normal_len, d->material_len};
+      k->inst_floats = 0;
+      for (int c = 0; c < k->ncomp; ++c)
+         for (int j = 0; j < (k->comp_kind[c] == MDH_VEC3 ? 3 : 1); ++j) k->x_float_off[k->inst_floats++] = k->comp_off[c] + 4 * j;
+      for (int q = 0; q < 3; ++q) {
+         if (len[q] < 1 || len[q] > MDH_X_MAX_WORDS) return 0;
+         for (int pc = 0; pc < len[q]; ++pc) { /* the operands this interpreter indexes with */
+            const uint32_t w = (uint32_t)src[q][pc];
+            const int op = w & 255, a = (w >> 16) & 255;
+            if (op >= MDH_X_OPS || (op == MDH_X_COMP && a >= k->inst_floats)) return 0;
+            if (op == MDH_X_LIT || op == MDH_X_SEL) { if (++pc >= len[q]) return 0; }
+         }
+         k->x_code[q] = (int32_t *)malloc(sizeof(int32_t) * (size_t)len[q]);
+         memcpy(k->x_code[q], src[q], sizeof(int32_t) * (size_t)len[q]);
+         k->x_len[q] = len[q];
+      }
+      return 1;
+   }
    if (!is_light) {
       k->f_mat = comp_offset(k, "material_id", MDH_INT);
       switch (k->type) {
@@ -1202,6 +1294,8 @@ int32_t orc_destroy(orc_renderer *r)
 {
    if (!r) return MDH_OK;
    for (int i = 0; i < 4; ++i) free(r->tex[i].data);
+   for (int k = 0; k < r->npk; ++k)
+      for (int q = 0; q < 3; ++q) free(r->pk[k].x_code[q]);
    free(r->scene_ubo); free(r->part_table); free(r->fb); free(r->gb_index); free(r->gb_steps); free(r->gb_t);
    free(r);
    return MDH_OK;
@@ -1458,6 +1552,12 @@ int32_t orc_eval_distance_to(orc_renderer *r, int32_t n, const float *pts, const
          int k = kind_ixs[a];
          if (k < 0 || k >= r->npk) return seterr(MDH_E_INVALID, "bad kind index");
          for (int i = 0; i < r->host_count[k]; ++i) {
+            if (r->pk[k].type == PK_CUSTOM) { /* the kind's own expressions, with Madarch.Values."/" when asked */
+               float o[3];
+               orc_xrun(r, &r->pk[k], 0, i, p, r->opt_ada_div, o);
+               if (o[0] < closest) { closest = o[0]; orc_xrun(r, &r->pk[k], 1, i, p, r->opt_ada_div, o); normal = V3(o[0], o[1], o[2]); }
+               continue;
+            }
             entity e;
             make_entity(r, &r->pk[k], i, &e);
             float d = orc_eval_dist(r->pk[k].type, &e, p);
