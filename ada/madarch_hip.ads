@@ -31,6 +31,14 @@ package Madarch_HIP is
       Max_Count    : int;
       N_Components : int;
       Components   : System.Address;   --  const mdh_component *
+      --  user-defined kinds (Primitives.Create): the Distance, Normal and Material
+      --  expressions as MDH_X register programs; Null_Address / 0 for built-in kinds
+      Dist_Code     : System.Address := System.Null_Address;   --  const int32_t *
+      Dist_Len      : int := 0;
+      Normal_Code   : System.Address := System.Null_Address;
+      Normal_Len    : int := 0;
+      Material_Code : System.Address := System.Null_Address;
+      Material_Len  : int := 0;
    end record with Convention => C;
    type Kind_Decl_Array is array (size_t range <>) of aliased Kind_Decl
      with Convention => C;
