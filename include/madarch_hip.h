@@ -114,7 +114,9 @@ enum {
    MDH_X_SEL = 21,   /* R[dst] = R[a] != 0 ? R[b] : R[c], c = low byte of the next word */
    MDH_X_ITOF = 22,  /* To_Float: R[dst] = (float) (int) R[a]                      */
    MDH_X_ACOS = 23,  /* the fp32 acos of the shading path                           */
-   MDH_X_OPS = 24    /* sin, cos, tan, asin, atan: not implemented (MDH_E_UNSUPPORTED_KIND) */
+   MDH_X_SIN = 24, MDH_X_COS = 25, MDH_X_TAN = 26, MDH_X_ASIN = 27, MDH_X_ATAN = 28,
+                     /* explicit fp32 algorithms (oracle/orc_math.h), a few 1e-7 absolute */
+   MDH_X_OPS = 29
 };
 #define MDH_X_REGS 64
 #define MDH_X_MAX_WORDS 4096 /* per program */

@@ -190,6 +190,8 @@ struct mdh_renderer {
    float4 *d_scat = nullptr;
    float4 *d_fb2[2] = {nullptr, nullptr}; // two framebuffers: consecutive pipelined frames draw on two streams
    int fb_last = 0;                       // the one the most recent frame drew
+   // (rank, world) whose tiles are the only non-zero pixels of a framebuffer; {0, 1}: every pixel may be set
+   int fb_owner[2][2] = {{-1, -1}, {-1, -1}};
    int *d_gb_index = nullptr, *d_gb_steps = nullptr;
    float *d_gb_t = nullptr;
    KScene ks{};
@@ -838,7 +840,10 @@ static int run_pass(mdh_renderer *r, int pass, hipStream_t st, int src, int dst,
       a.rank = r->opt_rank; a.world = r->opt_world;
       a.ao_steps = r->opt_ao;
       a.fb = r->d_fb2[fbix]; a.gb_index = r->d_gb_index; a.gb_t = r->d_gb_t; a.gb_steps = r->d_gb_steps;
-      if (a.world > 1) HIP_TRY(hipMemsetAsync(r->d_fb2[fbix], 0, (size_t)r->W * r->H * sizeof(float4), st)); // other ranks' tiles read 0
+      // other ranks' tiles read 0: cleared when the buffer last held another rank's (or a whole) frame, not every frame
+      if (a.world > 1 && (r->fb_owner[fbix][0] != a.rank || r->fb_owner[fbix][1] != a.world))
+         HIP_TRY(hipMemsetAsync(r->d_fb2[fbix], 0, (size_t)r->W * r->H * sizeof(float4), st));
+      r->fb_owner[fbix][0] = a.rank; r->fb_owner[fbix][1] = a.world;
       int own_tiles = (a.n_tiles - a.rank + a.world - 1) / a.world;
       if (own_tiles > 0) {
          int blocks = (own_tiles + (MDH_BLOCK / 64) - 1) / (MDH_BLOCK / 64);

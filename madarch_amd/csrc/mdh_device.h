@@ -199,6 +199,52 @@ MDH_DEV float acos_(float x)
    float r = sqrt_(1.0f - ax) * p;
    return x < 0.0f ? 3.14159265358979f - r : r;
 }
+MDH_DEV float asin_(float x) { return 1.5707963267948966f - acos_(x); }
+// sin / cos / tan / atan: the operation sequences of oracle/orc_math.h (Cody-Waite reduction + Cephes polynomials)
+MDH_DEV void sincos_core_(float x, float &s, float &c, int &q)
+{
+   float kf = __builtin_rintf(x * 0.636619772367581f);
+   if (!(__builtin_fabsf(kf) < 1.0e9f)) kf = 0.0f;
+   float r = ((x - kf * 1.5703125f) - kf * 4.837512969970703125e-4f) - kf * 7.54978995489188216e-8f;
+   float z = r * r;
+   float ps = -1.9515295891e-4f;
+   ps = ps * z + 8.3321608736e-3f;
+   ps = ps * z + -1.6666654611e-1f;
+   s = (ps * z) * r + r;
+   float pc = 2.443315711809948e-5f;
+   pc = pc * z + -1.388731625493765e-3f;
+   pc = pc * z + 4.166664568298827e-2f;
+   c = ((pc * z) * z - 0.5f * z) + 1.0f;
+   q = (int)kf & 3;
+}
+MDH_DEV float sin_(float x)
+{
+   float s, c; int q;
+   sincos_core_(x, s, c, q);
+   float r = (q & 1) ? c : s;
+   return (q & 2) ? -r : r;
+}
+MDH_DEV float cos_(float x)
+{
+   float s, c; int q;
+   sincos_core_(x, s, c, q);
+   float r = (q & 1) ? s : c;
+   return ((q + 1) & 2) ? -r : r;
+}
+MDH_DEV float tan_(float x) { return sin_(x) / cos_(x); }
+MDH_DEV float atan_(float x)
+{
+   float ax = __builtin_fabsf(x), y = 0.0f, t = ax;
+   if (ax > 2.414213562373095f) { y = 1.5707963267948966f; t = -(1.0f / ax); }
+   else if (ax > 0.4142135623730950f) { y = 0.7853981633974483f; t = (ax - 1.0f) / (ax + 1.0f); }
+   float z = t * t;
+   float p = 8.05374449538e-2f;
+   p = p * z + -1.38776856032e-1f;
+   p = p * z + 1.99777106478e-1f;
+   p = p * z + -3.33329491539e-1f;
+   y = y + ((p * z) * t + t);
+   return x < 0.0f ? -y : y;
+}
 MDH_DEV float exp2_(float z)
 {
    if (z != z) return z;
@@ -383,6 +429,11 @@ template <bool ADA_DIV> MDH_XRUN f3 xrun(int code, int n, int ent, f3 x)
       case 21: { const int c = hdr(code + ++pc) & 63; float vc; XGET(c, vc); r = va != 0.0f ? vb : vc; break; } // SEL
       case 22: r = (float)__builtin_bit_cast(int, va); break;                          // ITOF
       case 23: r = acos_(va); break;
+      case 24: r = sin_(va); break;
+      case 25: r = cos_(va); break;
+      case 26: r = tan_(va); break;
+      case 27: r = asin_(va); break;
+      case 28: r = atan_(va); break;
       default: r = 0.0f; break;
       }
       XPUT(d, r);

@@ -8,7 +8,8 @@ would emit, operation for operation, in the order DESIGN.md section 5 fixes.
 
 The tree is built with the reference's names: Literal, Value_Identifier, Struct_Identifier,
 Construct_Vector3, the arithmetic and comparison operators, Dot, Cross, Min, Max, Clamp, Length,
-Normalize, Abs_Value, To_Float, Sign, Floor, Sqrt, Dot2, Acos, Get, If_Then_Else, Let_In.
+Normalize, Abs_Value, To_Float, Sign, Floor, Sqrt, Dot2, Sin, Cos, Tan, Asin, Acos, Atan, Get,
+If_Then_Else, Let_In, Forward_Difference (Madarch.Exprs.Derivatives).
 """
 import struct
 
@@ -25,13 +26,14 @@ class Type_Inference_Error(Exception):  # exprs.ads:125
 
 
 class Unsupported_Expr(Exception):
-    """A node the MDH_X programs cannot express yet (sin, cos, tan, asin, atan, External_Call,
-    integer arithmetic)."""
+    """A node the MDH_X programs cannot express (External_Call, integer arithmetic, an expression
+    that needs more than 64 registers)."""
 
 
 # ---- opcodes: include/madarch_hip.h, enum MDH_X_*
 X_LIT, X_MOV, X_COMP, X_POINT, X_ADD, X_SUB, X_MUL, X_DIV, X_DIVF, X_NEG, X_ABS, X_FLOOR, X_SIGN = range(13)
 X_MIN, X_MAX, X_SQRT, X_POW, X_LT, X_GT, X_LE, X_GE, X_SEL, X_ITOF, X_ACOS = range(13, 24)
+X_SIN, X_COS, X_TAN, X_ASIN, X_ATAN = range(24, 29)
 X_REGS, X_MAX_WORDS = 64, 4096
 
 
@@ -329,8 +331,6 @@ class _Compiler:
 
     def builtin(self, e, env):
         b = e.builtin
-        if b in ("sin", "cos", "tan", "asin", "atan"):
-            raise Unsupported_Expr("builtin %r has no MDH_X instruction yet" % b)
         args = [self.expr(a, env) for a in e.args]
 
         def done(kind, out):
@@ -387,10 +387,11 @@ class _Compiler:
             for d, s in zip(out, regs):
                 self.emit({"neg": X_NEG, "abs": X_ABS, "floor": X_FLOOR}[b], d, s)
             return done(k, out)
-        if b in ("sign", "sqrt", "acos"):
+        if b in ("sign", "sqrt", "acos", "sin", "cos", "tan", "asin", "atan"):
             v = want(0, Float_Kind)
             d, = self.alloc()
-            self.emit({"sign": X_SIGN, "sqrt": X_SQRT, "acos": X_ACOS}[b], d, v[0])
+            self.emit({"sign": X_SIGN, "sqrt": X_SQRT, "acos": X_ACOS, "sin": X_SIN, "cos": X_COS, "tan": X_TAN,
+                       "asin": X_ASIN, "atan": X_ATAN}[b], d, v[0])
             return done(Float_Kind, [d])
         if b in ("min", "max"):  # GLSL min / max: component-wise, a scalar operand is broadcast
             (kx, x, _), (ky, y, _) = args[0], args[1]

@@ -269,6 +269,11 @@ static void orc_xrun(const orc_renderer *r, const kind_t *k, int which, int inst
       case MDH_X_SEL: { const float vc = R[code[++pc] & 63]; res = va != 0.0f ? vb : vc; break; }
       case MDH_X_ITOF: { int32_t iv; memcpy(&iv, &va, 4); res = (float)iv; break; }
       case MDH_X_ACOS: res = acos_(va); break;
+      case MDH_X_SIN: res = sin_(va); break;
+      case MDH_X_COS: res = cos_(va); break;
+      case MDH_X_TAN: res = tan_(va); break;
+      case MDH_X_ASIN: res = asin_(va); break;
+      case MDH_X_ATAN: res = atan_(va); break;
       default: break;
       }
       R[d] = res;
@@ -1710,3 +1715,8 @@ float orc_exprs_sdf(int32_t type, const float *a, const float *b, const float *c
 float orc_acos(float x) { return acos_(x); }
 float orc_exp(float x) { return exp_(x); }
 float orc_pow(float x, float y) { return pow_(x, y); }
+float orc_sin(float x) { return sin_(x); }
+float orc_cos(float x) { return cos_(x); }
+float orc_tan(float x) { return tan_(x); }
+float orc_asin(float x) { return asin_(x); }
+float orc_atan(float x) { return atan_(x); }

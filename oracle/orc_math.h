@@ -103,6 +103,58 @@ ORC_INLINE float acos_(float x)
    float r = sqrtf(1.0f - ax) * p;
    return x < 0.0f ? 3.14159265358979f - r : r;
 }
+/* asin = pi/2 - acos (same polynomial; absolute error < 2e-7) */
+ORC_INLINE float asin_(float x) { return 1.5707963267948966f - acos_(x); }
+/* sin / cos: k = rint (x 2/pi), r = ((x - k C1) - k C2) - k C3 with C1 + C2 + C3 = pi/2 split so that the
+ * first two products are exact for |k| < 2^13 (Cody-Waite), then the degree-7 / degree-8 polynomials of
+ * the Cephes single-precision library on [-pi/4, pi/4] and the quadrant symmetries.  |x| up to ~1e4
+ * keeps the error within a few 1e-7; beyond that the reduction loses accuracy (the result stays bounded). */
+ORC_INLINE void sincos_core_(float x, float *s, float *c, int *q)
+{
+   float kf = rintf(x * 0.636619772367581f);
+   if (!(fabsf(kf) < 1.0e9f)) kf = 0.0f; /* huge or NaN arguments: no reduction (NaN propagates below) */
+   float r = ((x - kf * 1.5703125f) - kf * 4.837512969970703125e-4f) - kf * 7.54978995489188216e-8f;
+   float z = r * r;
+   float ps = -1.9515295891e-4f;
+   ps = ps * z + 8.3321608736e-3f;
+   ps = ps * z + -1.6666654611e-1f;
+   *s = (ps * z) * r + r;
+   float pc = 2.443315711809948e-5f;
+   pc = pc * z + -1.388731625493765e-3f;
+   pc = pc * z + 4.166664568298827e-2f;
+   *c = ((pc * z) * z - 0.5f * z) + 1.0f;
+   *q = (int)kf & 3;
+}
+ORC_INLINE float sin_(float x)
+{
+   float s, c; int q;
+   sincos_core_(x, &s, &c, &q);
+   float r = (q & 1) ? c : s;
+   return (q & 2) ? -r : r;
+}
+ORC_INLINE float cos_(float x)
+{
+   float s, c; int q;
+   sincos_core_(x, &s, &c, &q);
+   float r = (q & 1) ? s : c;
+   return ((q + 1) & 2) ? -r : r;
+}
+ORC_INLINE float tan_(float x) { return sin_(x) / cos_(x); }
+/* atan: Cephes atanf -- reduce to |t| <= tan (pi/8) by atan x = pi/2 - atan (1/x) and atan x = pi/4 +
+ * atan ((x - 1) / (x + 1)), then an odd degree-9 polynomial */
+ORC_INLINE float atan_(float x)
+{
+   float ax = fabsf(x), y = 0.0f, t = ax;
+   if (ax > 2.414213562373095f) { y = 1.5707963267948966f; t = -(1.0f / ax); }
+   else if (ax > 0.4142135623730950f) { y = 0.7853981633974483f; t = (ax - 1.0f) / (ax + 1.0f); }
+   float z = t * t;
+   float p = 8.05374449538e-2f;
+   p = p * z + -1.38776856032e-1f;
+   p = p * z + 1.99777106478e-1f;
+   p = p * z + -3.33329491539e-1f;
+   y = y + ((p * z) * t + t);
+   return x < 0.0f ? -y : y;
+}
 /* 2^z: n = rint(z), 2^(z - n) = exp(u) with u = (z - n) ln2 in [-0.347, 0.347] by its Taylor
  * polynomial of degree 7 (truncation < 6e-9), scaled by 2^n through the exponent field */
 ORC_INLINE float exp2_(float z)

@@ -139,3 +139,24 @@ Capsule = primitives.Create(
 def capsule(a, b, r, thin, thick):
     return entities.Create([(C_A, values.Vector3(a)), (C_B, values.Vector3(b)), (C_Radius, values.Float(r)),
                             (C_Mat_Thin, values.Int(thin)), (C_Mat_Thick, values.Int(thick))])
+
+
+# a rippled slab that exercises the trigonometric builtins: 0.4 (p.y - h - a sin (f p.x) cos (f p.z)) plus terms
+# with tan, asin and atan of bounded arguments (the factor keeps the field a conservative bound)
+W_Height, W_Amp, W_Freq = components.Create("height", FK), components.Create("amp", FK), components.Create("freq", FK)
+
+
+def _ripple_distance(S, P):
+    f = S.Get(W_Freq)
+    wave = (P.Get(X) * f).Sin() * (P.Get(Z) * f).Cos()
+    extra = ((P.Get(X) * Literal(values.Float(0.1))).Tan() + (wave * Literal(values.Float(0.5))).Asin() + P.Get(Z).Atan()) * Literal(values.Float(0.01))
+    return (P.Get(Y) - S.Get(W_Height) - S.Get(W_Amp) * wave - extra) * Literal(values.Float(0.4))
+
+
+Ripple = primitives.Create(
+    "Ripple", (W_Height, W_Amp, W_Freq, Material_Id), _ripple_distance,
+    lambda S, P: Forward_Difference(_ripple_distance(S, Value_Identifier("DX")), "DX", P, 0.0005).Normalize(), _material)
+
+
+def ripple(height, amp, freq, m):
+    return entities.Create([(W_Height, values.Float(height)), (W_Amp, values.Float(amp)), (W_Freq, values.Float(freq)), (Material_Id, values.Int(m))])

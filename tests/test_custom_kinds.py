@@ -52,6 +52,7 @@ def room(binding, custom, W=56, H=40, mode=0, partition=False, extra=()):
 
 
 EXTRA = ((ck.Torus, [ck.torus((3.0, 1.2, 2.5), 0.8, 0.25, 3)]),
+         (ck.Ripple, [ck.ripple(-0.6, 0.15, 2.5, 1)]),
          (ck.Capsule, [ck.capsule((1.0, 3.0, 4.0), (2.0, 4.5, 3.0), 0.2, 1, 2), ck.capsule((4.5, 0.5, 2.0), (5.5, 1.5, 2.2), 0.4, 1, 2)]))
 
 
@@ -72,7 +73,7 @@ def test_compiler_lowers_in_the_order_of_the_glsl_contract():
     # literals go through Single'Image (6 digits) like every literal of the generated GLSL
     assert exprs.image_roundtrip(0.1234567) == np.float32(0.123457) and exprs.image_roundtrip(0.000001) == np.float32(1e-6)
     with pytest.raises(exprs.Unsupported_Expr):
-        exprs.compile_program(P.Get(0).Sin(), ck.My_Sphere.comps, values.Float_Kind, "x")
+        exprs.compile_program(exprs.External_Call("noise", [S], [P]), ck.My_Sphere.comps, values.Float_Kind, "x")
     with pytest.raises(exprs.Type_Inference_Error):
         exprs.compile_program(P + exprs.Value_Identifier("nobody"), ck.My_Sphere.comps, values.Vector3_Kind, "x")
 
@@ -141,14 +142,14 @@ def test_hip_restated_kinds_equal_the_built_in_kinds(hip, mode, partition):
 def test_hip_new_kinds_against_the_oracle(hip, orc, partition):
     outs = [snapshot(room(b, False, W=72, H=48, partition=partition, extra=EXTRA), 2) for b in (hip, orc)]
     assert_same(*outs)
-    assert (outs[0]["gb_index"] >= 21).any()  # pixels whose primary hit is a torus or a capsule (flat index after 6 + 8 + 4 + 3)
+    assert (outs[0]["gb_index"] >= 21).any()  # pixels whose primary hit is a torus, the ripple or a capsule (flat index after 6 + 8 + 4 + 3)
     pts = np.random.default_rng(7).uniform(-1.0, 7.0, (500, 3)).astype(np.float32)
     for ada in (0, 1):
         res = []
         for b in (hip, orc):
             R = room(b, True, extra=EXTRA)
             R.Set_Option(B.OPT_ADA_EVAL_DIV, ada)
-            res.append(R.Eval_Distances_To(pts, [ck.My_Triangle, ck.Torus, ck.Capsule, ck.My_Box]))
+            res.append(R.Eval_Distances_To(pts, [ck.My_Triangle, ck.Torus, ck.Capsule, ck.My_Box, ck.Ripple]))
         assert same_bits(res[0][0], res[1][0]) and same_bits(res[0][1], res[1][1])
 
 

@@ -252,3 +252,10 @@ def test_transcendental_algorithms_against_libm(orc):
     assert lib.orc_pow(0.0, 0.4545) == 0.0
     assert np.isnan(lib.orc_pow(-0.5, 0.4545)) and np.isnan(lib.orc_pow(float("nan"), 0.4545))
     assert lib.orc_exp(0.0) == 1.0 and lib.orc_acos(1.0) == 0.0
+    # the trigonometric builtins of the user-defined kinds (MDH_X_SIN .. MDH_X_ATAN)
+    for name, ref, lo, hi, tol in (("sin", np.sin, -50, 50, 2e-7), ("cos", np.cos, -50, 50, 2e-7), ("atan", np.arctan, -100, 100, 3e-7),
+                                   ("asin", np.arcsin, -1, 1, 6e-7), ("tan", np.tan, -1.5, 1.5, 3e-6)):
+        f = getattr(lib, "orc_" + name)
+        f.restype, f.argtypes = C.c_float, [C.c_float]
+        for x in rng.uniform(lo, hi, 3000).astype(np.float32):
+            assert abs(f(float(x)) - ref(np.float64(x))) < tol, (name, x)
