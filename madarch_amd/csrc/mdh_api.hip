@@ -982,7 +982,8 @@ extern "C" int32_t mdh_render(mdh_renderer *r)
 extern "C" int32_t mdh_probe_stream(mdh_renderer *r, void **stream)
 {
    if (!r || !stream) return seterr(MDH_E_INVALID, "bad argument");
-   *stream = (void *)((r->opt_overlap && r->stream == r->own_stream) ? r->probe_stream : r->stream);
+   if (r->in_frame) *stream = (void *)frame_probe_stream(r);
+   else *stream = (void *)((r->opt_overlap && r->opt_mode == 0 && r->stream == r->own_stream) ? r->probe_stream : r->stream);
    return MDH_OK;
 }
 extern "C" int32_t mdh_finish(mdh_renderer *r)

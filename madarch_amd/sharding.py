@@ -63,11 +63,19 @@ class DeviceExchange:
         import torch
         self.dist, self.group, self.torch = dist, group, torch
         self.device = device
+        self._streams = {}
+        self._views = {}
+
+    def _stream(self, renderer):
+        # asked per call: the library runs the probe passes on its probe stream when frames are kept in
+        # flight and on its main stream when they are not (MDH_OPT_FRAME_OVERLAP, caller-supplied streams)
         b = renderer._b
         ptr = C.c_void_p()
         b.check(b.probe_stream(renderer._h, C.byref(ptr)))
-        self.stream = torch.cuda.ExternalStream(ptr.value or 0, device=device)
-        self._views = {}
+        key = ptr.value or 0
+        if key not in self._streams:
+            self._streams[key] = self.torch.cuda.ExternalStream(key, device=self.device)
+        return self._streams[key]
 
     def _view(self, renderer, tex):
         # (re)query: there are two atlas sets, and they are reallocated when the format option changes
@@ -85,7 +93,7 @@ class DeviceExchange:
         full, off, own, total = self._view(renderer, tex)
         if own * world != total:
             raise ValueError("probe count %d is not divisible by the world size %d" % (renderer.Probe_Total(), world))
-        with self.torch.cuda.stream(self.stream):
+        with self.torch.cuda.stream(self._stream(renderer)):
             self.dist.all_gather_into_tensor(full, full[off:off + own], group=self.group)
 
 
