@@ -66,7 +66,14 @@ typedef struct {
  * madarch-primitives.ads:24-30): its Distance, Normal and Material expressions --
  * the Exprs trees the reference turns into GLSL text (Exprs.To_GLSL,
  * madarch-exprs.adb:325-711) -- arrive as three MDH_X programs (below) that the
- * kernels interpret.  Built-in kinds leave the program fields NULL / 0. */
+ * kernels interpret.  Built-in kinds leave the program fields NULL / 0.
+ *
+ * Any other LIGHT name is a user-defined light kind (Lights.Create,
+ * madarch-lights.ads:20-24) with two programs in the same fields:
+ *   dist_code   = Sample (l, pos, normal, dir, dist) -> vec3 radiance in R0, R1, R2
+ *   normal_code = Position (l)                        -> vec3 in R0, R1, R2
+ * wrapped as the generated sample_<Light> is (madarch-scenes.adb:497-549):
+ * dir = Position (l) - pos; dist = length (dir); dir /= dist; return Sample (...). */
 typedef struct {
    const char *name;
    int32_t max_count;
@@ -93,14 +100,16 @@ typedef struct {
  * (madarch-exprs.adb:154-155); If_Then_Else evaluates both sides and selects (the
  * expressions have no side effects); Let_In binds registers.  Float literals are
  * rounded through Single'Image like every literal of the generated GLSL
- * (madarch-exprs.adb:330-336).  Arithmetic is IEEE fp32, one operation per
+ * (madarch-exprs.adb:330-336); E ** n with a literal integer n = 2..16 is repeated
+ * multiplication, squaring from the most significant bit of n ((x^2)^2 x for n = 5).  Arithmetic is IEEE fp32, one operation per
  * instruction, division and square root correctly rounded. */
 enum {
    MDH_X_LIT = 0,    /* R[dst] = the next word (raw bits)                          */
    MDH_X_MOV = 1,    /* R[dst] = R[a]                                              */
    MDH_X_COMP = 2,   /* R[dst] = float a of the instance: components in declaration
                         order, a vec3 takes 3 floats, float / int 1 (raw bits)     */
-   MDH_X_POINT = 3,  /* R[dst] = x[a], a = 0, 1, 2: the point argument            */
+   MDH_X_POINT = 3,  /* R[dst] = argument float a.  Primitive programs: a = 0..2, the point.
+                        Light Sample: 0..2 pos, 3..5 normal, 6..8 dir, 9 dist          */
    MDH_X_ADD = 4, MDH_X_SUB = 5, MDH_X_MUL = 6,
    MDH_X_DIV = 7,    /* true division: components of vector "/"                    */
    MDH_X_DIVF = 8,   /* Float "/" Float: true division in the render passes; L + R in

@@ -59,7 +59,7 @@ struct Kind {
 
 // An MDH_X program is accepted only if every word is a known instruction with in-range
 // operands (nothing the caller hands over is trusted to index the register file or the instance).
-static bool valid_program(const int32_t *code, int n, int inst_floats, bool has_point)
+static bool valid_program(const int32_t *code, int n, int inst_floats, int n_args)
 {
    if (!code || n < 1 || n > MDH_X_MAX_WORDS) return false;
    for (int pc = 0; pc < n; ++pc) {
@@ -69,7 +69,7 @@ static bool valid_program(const int32_t *code, int n, int inst_floats, bool has_
       switch (op) {
       case MDH_X_LIT: if (++pc >= n) return false; break;
       case MDH_X_COMP: if (a >= inst_floats) return false; break;
-      case MDH_X_POINT: if (a > 2 || !has_point) return false; break;
+      case MDH_X_POINT: if (a >= n_args) return false; break;
       case MDH_X_SEL:
          if (a >= MDH_X_REGS || b >= MDH_X_REGS || ++pc >= n || (uint32_t)code[pc] >= MDH_X_REGS) return false;
          break;
@@ -87,8 +87,8 @@ static bool resolve_kind(Kind &k, const mdh_kind_decl &d, bool is_light)
    k.type = -1;
    for (int t = 0; t < (is_light ? 2 : 4); ++t)
       if (strcmp(d.name, is_light ? L[t] : P[t]) == 0) k.type = t;
-   const bool custom = k.type < 0 && !is_light && d.dist_code && d.normal_code && d.material_code;
-   if (custom) k.type = PK_CUSTOM;
+   const bool custom = k.type < 0 && d.dist_code && d.normal_code && (is_light || d.material_code);
+   if (custom) k.type = is_light ? (int)LK_CUSTOM : (int)PK_CUSTOM;
    if (k.type < 0 || d.n_components < 1 || d.n_components > 8 || d.max_count < 0) return false;
    k.max_count = d.max_count;
    k.ncomp = d.n_components;
@@ -107,12 +107,14 @@ static bool resolve_kind(Kind &k, const mdh_kind_decl &d, bool is_light)
          if (k.comp_kind[i] != MDH_VEC3 && k.comp_kind[i] != MDH_FLOAT && k.comp_kind[i] != MDH_INT) return false;
          k.inst_floats += k.comp_kind[i] == MDH_VEC3 ? 3 : 1;
       }
-      if (!valid_program(d.dist_code, d.dist_len, k.inst_floats, true) || !valid_program(d.normal_code, d.normal_len, k.inst_floats, true) ||
-          !valid_program(d.material_code, d.material_len, k.inst_floats, false))
+      if (is_light) { // Sample (pos, normal, dir, dist: 10 argument floats) and Position (none)
+         if (!valid_program(d.dist_code, d.dist_len, k.inst_floats, 10) || !valid_program(d.normal_code, d.normal_len, k.inst_floats, 0)) return false;
+      } else if (!valid_program(d.dist_code, d.dist_len, k.inst_floats, 3) || !valid_program(d.normal_code, d.normal_len, k.inst_floats, 3) ||
+                 !valid_program(d.material_code, d.material_len, k.inst_floats, 0))
          return false;
       k.x_dist.assign(d.dist_code, d.dist_code + d.dist_len);
       k.x_nrm.assign(d.normal_code, d.normal_code + d.normal_len);
-      k.x_mat.assign(d.material_code, d.material_code + d.material_len);
+      if (!is_light) k.x_mat.assign(d.material_code, d.material_code + d.material_len);
       return true;
    }
    if (!is_light) {
@@ -369,6 +371,33 @@ static int commit_scene(mdh_renderer *r)
       if (n < 0) n = 0;
       if (n > kd.max_count) n = kd.max_count;
       H[H_LTYPE + k] = kd.type; H[H_LCOUNT + k] = n; H[H_LSLOT + k] = (int)t.size();
+      if (kd.type == LK_CUSTOM) { // instance floats as MDH_X_COMP addresses them, then the two programs
+         const int stride = (kd.inst_floats + 3) / 4;
+         H[H_LSTRIDE + k] = stride;
+         for (int i = 0; i < n; ++i) {
+            const int b = kd.array_off + kd.stride * i;
+            float buf[32] = {0};
+            int f = 0;
+            for (int c = 0; c < kd.ncomp; ++c) {
+               const int nf = kd.comp_kind[c] == MDH_VEC3 ? 3 : 1;
+               memcpy(buf + f, r->scene_ubo.data() + b + kd.comp_off[c], 4 * nf);
+               f += nf;
+            }
+            for (int q = 0; q < stride; ++q) t.push_back(mk4(buf[4 * q], buf[4 * q + 1], buf[4 * q + 2], buf[4 * q + 3]));
+         }
+         const std::vector<int32_t> *progs[2] = {&kd.x_dist, &kd.x_nrm};
+         const int hs[2] = {H_XLSAMPLE, H_XLPOS}, hn[2] = {H_XLSAMPLEN, H_XLPOSN};
+         for (int q = 0; q < 2; ++q) {
+            H[hs[q] + k] = (int)t.size() * 4;
+            H[hn[q] + k] = (int)progs[q]->size();
+            for (size_t w0 = 0; w0 < progs[q]->size(); w0 += 4) {
+               float m4[4] = {0, 0, 0, 0};
+               for (size_t j = 0; j < 4 && w0 + j < progs[q]->size(); ++j) m4[j] = i_as_f((*progs[q])[w0 + j]);
+               t.push_back(mk4(m4[0], m4[1], m4[2], m4[3]));
+            }
+         }
+         continue;
+      }
       for (int i = 0; i < n; ++i) {
          int b = kd.array_off + kd.stride * i;
          if (kd.type == LK_POINT) { t.push_back(rd_v3w(r, b + kd.f_a, 0.0f)); t.push_back(rd_v3w(r, b + kd.f_b, 0.0f)); }
@@ -507,7 +536,7 @@ extern "C" int32_t mdh_create(int32_t width, int32_t height, const mdh_scene_des
       for (int j = 0; j < k; ++j)
          if (r->pk[k].type != PK_CUSTOM && r->pk[k].type == r->pk[j].type) { delete r; return seterr(MDH_E_INVALID, "a built-in primitive kind is declared twice"); }
    for (int k = 0; k < r->nlk; ++k) {
-      if (!resolve_kind(r->lk[k], scene->light_kinds[k], true)) { delete r; return seterr(MDH_E_UNSUPPORTED_KIND, "light kind is not PointLight or SpotLight with their components"); }
+      if (!resolve_kind(r->lk[k], scene->light_kinds[k], true)) { delete r; return seterr(MDH_E_UNSUPPORTED_KIND, "light kind is neither PointLight or SpotLight with their components nor a user-defined kind with valid Sample and Position programs"); }
       off = pad_to(off, 4); r->lk[k].count_off = off; off += 4;
       off = pad_to(off, 16); r->lk[k].array_off = off; off += r->lk[k].stride * r->lk[k].max_count;
    }
@@ -772,6 +801,7 @@ static int run_pass(mdh_renderer *r, int pass, hipStream_t st, int src, int dst,
    // kernel variant: bit 0 = space partition, bit 1 = user-defined kinds (mdh_device.h, MDH_PF_*)
    bool has_custom = false;
    for (int k = 0; k < r->npk; ++k) has_custom = has_custom || r->pk[k].type == PK_CUSTOM;
+   for (int k = 0; k < r->nlk; ++k) has_custom = has_custom || r->lk[k].type == LK_CUSTOM;
    const int pf = (r->part.enable != 0 ? MDH_PF_PART : 0) | (has_custom ? MDH_PF_CUSTOM : 0);
 #define MDH_LAUNCH_PF(KERNEL, GRID, BLOCK, LDS, ...)                                                      \
    do {                                                                                                   \

@@ -29,7 +29,7 @@
 #define MDH_MAX_LIGHT_KINDS 4
 
 enum { PK_SPHERE = 0, PK_PLANE = 1, PK_BOX = 2, PK_TRIANGLE = 3, PK_CUSTOM = 4 }; // PK_CUSTOM: a user-defined kind (MDH_X programs)
-enum { LK_POINT = 0, LK_SPOT = 1 };
+enum { LK_POINT = 0, LK_SPOT = 1, LK_CUSTOM = 2 }; // LK_CUSTOM: a user-defined light kind (MDH_X Sample and Position programs)
 
 // ---------------------------------------------------------------- kernel argument blocks
 // Uniform scene header.  The part the march loops need on every step lives in SGPRs (kernel
@@ -76,7 +76,10 @@ enum {
    H_LTYPE = 112,  // [4]
    H_LCOUNT = 116, // [4]
    H_LSLOT = 120,  // [4]
-   H_INTS = 124    // 31 float4
+   H_LSTRIDE = 124, // [4] float4 per instance
+   // user-defined light kinds: Sample and Position programs
+   H_XLSAMPLE = 128, H_XLSAMPLEN = 132, H_XLPOS = 136, H_XLPOSN = 140,
+   H_INTS = 144    // 36 float4
 };
 
 struct KProbes {
@@ -393,7 +396,8 @@ typedef float xbank __attribute__((ext_vector_type(32)));
       lo[(i) & 31] = ((i) & 32) ? o0_ : (v);                                                       \
       hi[(i) & 31] = ((i) & 32) ? (v) : o1_;                                                       \
    } while (0)
-template <bool ADA_DIV> MDH_XRUN f3 xrun(int code, int n, int ent, f3 x)
+// x = argument floats 0..2 (the point / pos); nrm, dir, dist = floats 3..9 of a light's Sample program
+template <bool ADA_DIV> MDH_XRUN f3 xrun(int code, int n, int ent, f3 x, f3 nrm = F3(0.0f, 0.0f, 0.0f), f3 dir = F3(0.0f, 0.0f, 0.0f), float dist = 0.0f)
 {
    xbank lo = 0.0f, hi = 0.0f;
 #pragma unroll 1
@@ -408,7 +412,9 @@ template <bool ADA_DIV> MDH_XRUN f3 xrun(int code, int n, int ent, f3 x)
       case 0: r = __builtin_bit_cast(float, hdr(code + ++pc)); break;                  // LIT
       case 1: r = va; break;                                                          // MOV
       case 2: r = tab_float(ent + a); break;                                          // COMP
-      case 3: r = a == 0 ? x.x : (a == 1 ? x.y : x.z); break;                         // POINT
+      case 3: // POINT (a is wave-uniform)
+         r = a == 0 ? x.x : a == 1 ? x.y : a == 2 ? x.z : a == 3 ? nrm.x : a == 4 ? nrm.y : a == 5 ? nrm.z : a == 6 ? dir.x : a == 7 ? dir.y : a == 8 ? dir.z : dist;
+         break;
       case 4: r = va + vb; break;
       case 5: r = va - vb; break;
       case 6: r = va * vb; break;
@@ -669,13 +675,20 @@ template <int PART> MDH_DEV float raycast_visibility(const KScene &sc, f3 from, 
 
 // ------------------------------------------------------------------------------ lights
 // sample_<Light> (scenes.adb:497-549) dispatched by cumulative RUNTIME counts (scenes.adb:731-764)
-MDH_DEV f3 sample_light(const KScene &sc, int index, f3 pos, f3 &dir, float &dist)
+template <bool CUSTOM> MDH_DEV f3 sample_light(const KScene &sc, int index, f3 pos, f3 normal, f3 &dir, float &dist)
 {
    const int nl = hdr(H_NL);
 #pragma unroll 1
    for (int k = 0; k < nl; ++k) {
       const int n = hdr(H_LCOUNT + k);
       if (index < n) {
+         if (CUSTOM && hdr(H_LTYPE + k) == LK_CUSTOM) { // the generated sample_<Light> (scenes.adb:497-549) around the kind's programs
+            const int ent = (hdr(H_LSLOT + k) + hdr(H_LSTRIDE + k) * index) * 4;
+            dir = xrun<false>(hdr(H_XLPOS + k), hdr(H_XLPOSN + k), ent, pos) - pos;
+            dist = length(dir);
+            dir = dir / dist;
+            return xrun<false>(hdr(H_XLSAMPLE + k), hdr(H_XLSAMPLEN + k), ent, pos, normal, dir, dist);
+         }
          if (hdr(H_LTYPE + k) == LK_POINT) { // madarch-lights-point_lights.ads:20-22
             const int s = hdr(H_LSLOT + k) + 2 * index;
             dir = xyz(s_tab[s]) - pos;

@@ -6,7 +6,9 @@
 
 #include "mdh_device.h"
 
+#ifndef MDH_BLOCK
 #define MDH_BLOCK 256 // 4 wavefronts; every wavefront owns one 8x8 tile
+#endif
 
 #include "mdh_march.h"
 #define MDH_SHADE shade_structured
@@ -242,7 +244,7 @@ template <int PART> __global__ __launch_bounds__(MDH_BLOCK) void k_visibility(KS
    for (int l = 0; l < sc.total_lights; ++l) { // sample_lights :8-19
       f3 L;
       float L_dist;
-      f3 radiance = sample_light(sc, l, pos, L, L_dist);
+      f3 radiance = sample_light<(PART & MDH_PF_CUSTOM) != 0>(sc, l, pos, F3(1.0f, 0.0f, 0.0f), L, L_dist); // compute_frustrum_visibility.glsl:12
       float visibility = raycast_visibility<PART>(sc, pos, L, L_dist);
       f3 L_in = radiance * (exp_(-L_dist * MDH_TAU) * visibility);
       result = result + (L_in * MDH_TAU) * henvey_greenstein_phase(L, dir);

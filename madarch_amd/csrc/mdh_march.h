@@ -299,7 +299,7 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
                   for (int li = 0; li < sc.total_lights; ++li) {
                      f3 L;
                      float L_dist;
-                     f3 radiance = sample_light(sc, li, P, L, L_dist);
+                     f3 radiance = sample_light<(PART & MDH_PF_CUSTOM) != 0>(sc, li, P, N, L, L_dist);
                      float NdotL = max_(dot(N, L), 0.0f);
                      f3 kD, kS;
                      cook_torrance(N, -rd, L, NdotL, m.albedo, m.metallic, m.roughness, kD, kS);

@@ -406,6 +406,18 @@ class _Compiler:
             for i, d in enumerate(out):
                 self.emit(X_MIN if b == "min" else X_MAX, d, x[i if kx == Vector3_Kind else 0], y[i if ky == Vector3_Kind else 0])
             return done(Vector3_Kind if vec else Float_Kind, out)
+        if b == "pow" and isinstance(e.args[1], Lit) and e.args[1].v.kind in (Float_Kind, Int_Kind) \
+                and float(e.args[1].v.data) == int(e.args[1].v.data) and 2 <= int(e.args[1].v.data) <= 16:
+            # a literal integer power is repeated multiplication, squaring from the top bit
+            x = want(0, Float_Kind)
+            n = int(e.args[1].v.data)
+            d, = self.alloc()
+            self.emit(X_MOV, d, x[0])
+            for bit in bin(n)[3:]:
+                self.emit(X_MUL, d, d, d)
+                if bit == "1":
+                    self.emit(X_MUL, d, d, x[0])
+            return done(Float_Kind, [d])
         if b == "pow":
             x, y = want(0, Float_Kind), want(1, Float_Kind)
             d, = self.alloc()
@@ -430,16 +442,20 @@ def _f2i(x):
     return struct.unpack("<I", struct.pack("<f", float(np.float32(x))))[0]
 
 
-def compile_program(expr, comps, result_kind, point_name=None):
-    """The MDH_X words of `expr` for a kind with components `comps`: the point argument (if any)
-    is bound to `point_name`, the result lands in R0 (R0..R2 for a vector)."""
+def compile_program(expr, comps, result_kind, point_name=None, args=None):
+    """The MDH_X words of `expr` for a kind with components `comps`.  Arguments (MDH_X_POINT floats)
+    are bound to names: `point_name` is the vector at floats 0..2; `args` = [(name, kind, first float)]
+    for the general case (a light's Sample: pos 0, normal 3, dir 6, dist 9).  The result lands in R0
+    (R0..R2 for a vector)."""
     c = _Compiler(comps)
     env = {}
     if point_name is not None:
-        p = c.alloc(3)
-        for i, r in enumerate(p):
-            c.emit(X_POINT, r, i)
-        env[point_name] = (Vector3_Kind, p)
+        args = [(point_name, Vector3_Kind, 0)] + list(args or [])
+    for name, kind, first in args or []:
+        regs = c.alloc(3 if kind == Vector3_Kind else 1)
+        for i, r in enumerate(regs):
+            c.emit(X_POINT, r, first + i)
+        env[name] = (kind, regs)
     k, regs, owned = c.expr(expr, env)
     if result_kind == Float_Kind and k == Int_Kind:
         k, regs, owned = c.as_float(k, regs, owned)

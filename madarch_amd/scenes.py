@@ -69,8 +69,10 @@ class Scene:
                 arr[i].max_count = n
                 arr[i].n_components = len(k.comps)
                 arr[i].components = cs
-                if getattr(k, "is_user_defined", None) and k.is_user_defined() and k.distance and k.normal and k.material:
-                    # the kind's expressions as MDH_X programs (the analogue of To_GLSL, scenes.adb:1189-1266)
+                user = getattr(k, "is_user_defined", None) and k.is_user_defined()
+                if user and (getattr(k, "sample", None) and k.position if hasattr(k, "sample") else k.distance and k.normal and k.material):
+                    # the kind's expressions as MDH_X programs (the analogue of To_GLSL, scenes.adb:1189-1266);
+                    # a light's Sample and Position travel in the dist / normal fields
                     for field, words in zip(("dist", "normal", "material"), k.programs()):
                         code = (C.c_int32 * max(1, len(words)))(*words)
                         keep.append(code)

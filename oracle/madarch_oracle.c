@@ -35,7 +35,7 @@
 #define MAX_MATERIALS 20 /* glsl/materials.glsl:9 */
 
 enum { PK_SPHERE = 0, PK_PLANE = 1, PK_BOX = 2, PK_TRIANGLE = 3, PK_CUSTOM = 4 }; /* PK_CUSTOM: user-defined kind (MDH_X programs, include/madarch_hip.h) */
-enum { LK_POINT = 0, LK_SPOT = 1 };
+enum { LK_POINT = 0, LK_SPOT = 1, LK_CUSTOM = 2 };
 
 /* oracle-only options (>= 100) */
 enum { ORC_OPT_SDF_MODE = 100 /* 0 closed form, 1 Madarch.Exprs tree evaluator */, ORC_OPT_THREADS = 101 };
@@ -233,7 +233,14 @@ static void make_entity(const orc_renderer *r, const kind_t *k, int i, entity *e
 
 /* The MDH_X register programs of a user-defined kind (include/madarch_hip.h): the oracle's own
  * interpreter, a plain switch over the instruction list.  which: 0 Distance, 1 Normal, 2 Material. */
+/* args: the MDH_X_POINT floats -- 0..2 the point (pos), 3..5 normal, 6..8 dir, 9 dist (light Sample) */
+static void orc_xrun_args(const orc_renderer *r, const kind_t *k, int which, int inst, const float args[10], int ada_div, float out[3]);
 static void orc_xrun(const orc_renderer *r, const kind_t *k, int which, int inst, v3 x, int ada_div, float out[3])
+{
+   float args[10] = {x.x, x.y, x.z, 0, 0, 0, 0, 0, 0, 0};
+   orc_xrun_args(r, k, which, inst, args, ada_div, out);
+}
+static void orc_xrun_args(const orc_renderer *r, const kind_t *k, int which, int inst, const float args[10], int ada_div, float out[3])
 {
    float R[MDH_X_REGS];
    memset(R, 0, sizeof R);
@@ -248,7 +255,7 @@ static void orc_xrun(const orc_renderer *r, const kind_t *k, int which, int inst
       case MDH_X_LIT: memcpy(&res, &code[++pc], 4); break;
       case MDH_X_MOV: res = va; break;
       case MDH_X_COMP: res = ubo_f(r, base + k->x_float_off[a]); break;
-      case MDH_X_POINT: res = a == 0 ? x.x : (a == 1 ? x.y : x.z); break;
+      case MDH_X_POINT: res = args[a < 10 ? a : 9]; break;
       case MDH_X_ADD: res = va + vb; break;
       case MDH_X_SUB: res = va - vb; break;
       case MDH_X_MUL: res = va * vb; break;
@@ -608,11 +615,20 @@ static float raycast_visibility(const orc_renderer *r, v3 from, v3 dir, float ma
 /* sample_<Light> (scenes.adb:497-549) + sample_light (scenes.adb:731-764) */
 static v3 sample_light(const orc_renderer *r, int index, v3 pos, v3 normal, v3 *dir, float *dist)
 {
-   (void)normal;
    for (int k = 0; k < r->nlk; ++k) {
       const kind_t *lk = &r->lk[k];
       int n = ubo_i(r, lk->count_off); /* runtime count, scenes.adb:737-751 */
       if (index < n) {
+         if (lk->type == LK_CUSTOM) { /* the generated sample_<Light> (scenes.adb:497-549) around the kind's programs */
+            float o[3], args[10] = {pos.x, pos.y, pos.z, normal.x, normal.y, normal.z, 0, 0, 0, 0};
+            orc_xrun_args(r, lk, 1, index, args, 0, o); /* Position */
+            *dir = sub(V3(o[0], o[1], o[2]), pos);
+            *dist = length(*dir);
+            *dir = divs(*dir, *dist);
+            args[6] = dir->x; args[7] = dir->y; args[8] = dir->z; args[9] = *dist;
+            orc_xrun_args(r, lk, 0, index, args, 0, o); /* Sample */
+            return V3(o[0], o[1], o[2]);
+         }
          int b = lk->array_off + lk->stride * index;
          v3 lpos = ubo_v3(r, b + lk->f_a);
          *dir = sub(lpos, pos);
@@ -1187,8 +1203,8 @@ static int resolve_kind(kind_t *k, const mdh_kind_decl *d, int is_light)
    int n = is_light ? 2 : 4;
    for (int t = 0; t < n; ++t)
       if (strcmp(d->name, is_light ? LIGHT_NAMES[t] : PRIM_NAMES[t]) == 0) k->type = t;
-   int custom = k->type < 0 && !is_light && d->dist_code && d->normal_code && d->material_code;
-   if (custom) k->type = PK_CUSTOM;
+   int custom = k->type < 0 && d->dist_code && d->normal_code && (is_light || d->material_code);
+   if (custom) k->type = is_light ? (int)LK_CUSTOM : (int)PK_CUSTOM;
    if (k->type < 0 || d->n_components > 8 || d->n_components < 1) return 0;
    k->max_count = d->max_count;
    k->ncomp = d->n_components;
@@ -1204,7 +1220,7 @@ static int resolve_kind(kind_t *k, const mdh_kind_decl *d, int is_light)
       k->inst_floats = 0;
       for (int c = 0; c < k->ncomp; ++c)
          for (int j = 0; j < (k->comp_kind[c] == MDH_VEC3 ? 3 : 1); ++j) k->x_float_off[k->inst_floats++] = k->comp_off[c] + 4 * j;
-      for (int q = 0; q < 3; ++q) {
+      for (int q = 0; q < (is_light ? 2 : 3); ++q) {
          if (len[q] < 1 || len[q] > MDH_X_MAX_WORDS) return 0;
          for (int pc = 0; pc < len[q]; ++pc) { /* the operands this interpreter indexes with */
             const uint32_t w = (uint32_t)src[q][pc];
@@ -1299,8 +1315,8 @@ int32_t orc_destroy(orc_renderer *r)
 {
    if (!r) return MDH_OK;
    for (int i = 0; i < 4; ++i) free(r->tex[i].data);
-   for (int k = 0; k < r->npk; ++k)
-      for (int q = 0; q < 3; ++q) free(r->pk[k].x_code[q]);
+   for (int k = 0; k < MAX_KINDS; ++k)
+      for (int q = 0; q < 3; ++q) { free(r->pk[k].x_code[q]); free(r->lk[k].x_code[q]); }
    free(r->scene_ubo); free(r->part_table); free(r->fb); free(r->gb_index); free(r->gb_steps); free(r->gb_t);
    free(r);
    return MDH_OK;

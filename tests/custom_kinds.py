@@ -1,7 +1,7 @@
 """User-defined primitive kinds for the tests: the four built-in kinds restated with the reference's
 own expressions (madarch-primitives-{spheres,planes}.ads, -{boxes,triangles}.adb) under other names,
 and two kinds the reference does not have (a torus and a capsule)."""
-from madarch_amd import components, entities, exprs, primitives, values
+from madarch_amd import components, entities, exprs, lights, primitives, values
 from madarch_amd.exprs import (Construct_Vector3, Forward_Difference, If_Then_Else, Let_In, Literal, Min, Value_Identifier)
 from madarch_amd.primitives.materials import Material_Id
 
@@ -160,3 +160,43 @@ Ripple = primitives.Create(
 
 def ripple(height, amp, freq, m):
     return entities.Create([(W_Height, values.Float(height)), (W_Amp, values.Float(amp)), (W_Freq, values.Float(freq)), (Material_Id, values.Int(m))])
+
+
+# ---- lights: PointLight and SpotLight restated (point_lights.ads:20-22, spot_lights.adb:5-24), and a lamp of our own
+L_Position, L_Color = components.Create("position", V3K), components.Create("color", V3K)
+L_Direction, L_Aperture = components.Create("direction", V3K), components.Create("aperture", FK)
+_F15, _F003, _F8 = Literal(values.Float(1.5)), Literal(values.Float(0.03)), Literal(values.Float(8.0))
+
+My_Point_Light = lights.Create(
+    "MyPointLight", (L_Position, L_Color),
+    lambda L, Pos, Normal, Dir, Dist: L.Get(L_Color) / (Dist * Dist * _F003), lambda L: L.Get(L_Position))
+
+
+def _spot_sample(L, Pos, Normal, Dir, Dist):
+    attenuation = _F1 / (Dist * Dist * _F003)
+    theta = (-Dir).Dot(L.Get(L_Direction)).Max(_F0).Acos()
+    ratio = (theta / L.Get(L_Aperture)).Clamp(_F0, _F1)
+    return L.Get(L_Color) * attenuation.Min(_F15) * (_F1 - ratio ** _F8)
+
+
+My_Spot_Light = lights.Create("MySpotLight", (L_Position, L_Direction, L_Aperture, L_Color), _spot_sample, lambda L: L.Get(L_Position))
+
+
+def point_light(p, c):
+    return entities.Create([(L_Position, values.Vector3(p)), (L_Color, values.Vector3(c))])
+
+
+def spot_light(p, d, a, c):
+    return entities.Create([(L_Position, values.Vector3(p)), (L_Direction, values.Vector3(d)), (L_Aperture, values.Float(a)), (L_Color, values.Vector3(c))])
+
+
+# a lamp that hangs `drop` below its anchor, with a linear falloff and a term in the surface normal
+M_Anchor, M_Drop, M_Power = components.Create("anchor", V3K), components.Create("drop", FK), components.Create("power", V3K)
+Lamp = lights.Create(
+    "Lamp", (M_Anchor, M_Drop, M_Power),
+    lambda L, Pos, Normal, Dir, Dist: L.Get(M_Power) * (Normal.Dot(Dir).Max(Literal(values.Float(0.25))) / (_F1 + Dist)),
+    lambda L: L.Get(M_Anchor) - Construct_Vector3(_F0, L.Get(M_Drop), _F0))
+
+
+def lamp(anchor, drop, power):
+    return entities.Create([(M_Anchor, values.Vector3(anchor)), (M_Drop, values.Float(drop)), (M_Power, values.Vector3(power))])

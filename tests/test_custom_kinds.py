@@ -12,20 +12,22 @@ import custom_kinds as ck
 from helpers import SMALL_PROBES, same_bits, snapshot
 from madarch_amd import _binding as B
 from madarch_amd import exprs, materials, renderers, scenes, values, windows
-from madarch_amd.lights import point_lights
+from madarch_amd.lights import point_lights, spot_lights
 from madarch_amd.primitives import boxes, planes, spheres, triangles
 
 ROOM = (((0.0, 1.0, 0.0), 1.0), ((0.0, -1.0, 0.0), 7.0), ((1.0, 0.0, 0.0), 1.0), ((-1.0, 0.0, 0.0), 7.0), ((0.0, 0.0, 1.0), 6.0), ((0.0, 0.0, -1.0), 7.0))
 TRIS = (((1.0, 0.5, 2.5), (2.5, 0.8, 3.0), (1.6, 2.2, 2.8)), ((4.0, 3.0, 4.0), (5.0, 3.2, 3.5), (4.4, 4.1, 4.6)))
 
 
-def room(binding, custom, W=56, H=40, mode=0, partition=False, extra=()):
+def room(binding, custom, W=56, H=40, mode=0, partition=False, extra=(), custom_lights=False, lamp=False):
     """A room of planes with spheres, boxes and triangles: built-in kinds, or their restatements."""
     K = (ck.My_Sphere, ck.My_Plane, ck.My_Box, ck.My_Triangle) if custom else (spheres.Sphere, planes.Plane, boxes.Box, triangles.Triangle)
     mk = (ck.sphere, ck.plane, ck.box, ck.triangle) if custom else (spheres.Create, planes.Create, boxes.Create, triangles.Create)
     part = scenes.Partitioning_Settings(Enable=partition, Index_Count=12, Grid_Dimensions=(6, 6, 8), Grid_Spacing=(1.5, 1.5, 1.75), Grid_Offset=(-1.5, -1.5, -6.5))
     Scene = scenes.Compile(All_Primitives=[(K[0], 6), (K[1], 8), (K[2], 4), (K[3], 3)] + [(k, 3) for k, _ in extra],
-                           All_Lights=[(point_lights.Point_Light, 2)], Partitioning=part)
+                           All_Lights=[(ck.My_Point_Light if custom_lights else point_lights.Point_Light, 2),
+                                       (ck.My_Spot_Light if custom_lights else spot_lights.Spot_Light, 3)] + ([(ck.Lamp, 6)] if lamp else []),
+                           Partitioning=part)
     R = renderers.Create(windows.Open(W, H, "custom"), Scene, Probes=SMALL_PROBES, Volumetrics=renderers.No_Volumetrics, Binding=binding)
     for (n, o), m in zip(ROOM, (0, 0, 1, 2, 0, 0)):
         R.Add_Primitive(K[1], mk[1](n, o, m))
@@ -42,7 +44,18 @@ def room(binding, custom, W=56, H=40, mode=0, partition=False, extra=()):
     R.Set_Material(1, materials.Create((1.0, 0.0, 0.0), 0.0, 0.6))
     R.Set_Material(2, materials.Create((0.0, 0.0, 1.0), 0.2, 0.5))
     R.Set_Material(3, materials.Create((0.1, 0.1, 0.1), 0.9, 0.1))
-    R.Set_Light(1, point_lights.Point_Light, point_lights.Create((3.0, 5.0, 1.0), (0.9, 0.9, 0.8)))
+    # Set_Light (Index, ...) sets the kind's count AND total_light_count to Index (renderers.adb:478-482), and the
+    # light loop walks the kinds by cumulative counts: the sequence below leaves point 1, point 2, spot 1, spot 3
+    # (and the lamp) reachable
+    PL, SL = (ck.My_Point_Light, ck.My_Spot_Light) if custom_lights else (point_lights.Point_Light, spot_lights.Spot_Light)
+    mkp, mks = (ck.point_light, ck.spot_light) if custom_lights else (point_lights.Create, spot_lights.Create)
+    R.Set_Light(1, PL, mkp((3.0, 5.0, 1.0), (0.9, 0.9, 0.8)))
+    R.Set_Light(2, PL, mkp((5.5, 1.0, 5.0), (0.2, 0.3, 0.6)))
+    R.Set_Light(1, SL, mks((1.0, 6.0, 3.0), (0.3, -0.9, 0.1), 0.7, (0.8, 0.6, 0.9)))
+    R.Set_Light(3, SL, mks((4.0, 6.0, 1.0), (-0.2, -0.9, 0.3), 0.5, (0.9, 0.9, 0.5)))
+    if lamp:
+        R.Set_Light(1, ck.Lamp, ck.lamp((5.0, 6.5, 4.0), 1.5, (1.2, 1.1, 0.9)))
+        R.Set_Light(6, ck.Lamp, ck.lamp((0.0, 0.0, 0.0), 0.0, (0.0, 0.0, 0.0)))
     R.Set_Camera_Position((2.0, 2.0, 0.0))
     R.Set_Option(B.OPT_SCREEN_MODE, mode)
     R.Set_Option(B.OPT_GBUFFER, 1)
@@ -111,6 +124,13 @@ def test_oracle_new_kinds_known_answers(orc):
     assert np.isfinite(img["image"]).all()
 
 
+def test_oracle_restated_lights_equal_the_built_in_lights(orc):
+    assert_same(snapshot(room(orc, False), 2), snapshot(room(orc, False, custom_lights=True), 2))
+    # and the lamp really lights the scene: its frame differs from the one without it
+    a, b = snapshot(room(orc, False), 1), snapshot(room(orc, False, lamp=True), 1)
+    assert not same_bits(a["image"], b["image"]) and np.isfinite(b["image"]).all()
+
+
 def test_invalid_programs_are_rejected(orc):
     good = ck.My_Sphere.programs
 
@@ -151,6 +171,12 @@ def test_hip_new_kinds_against_the_oracle(hip, orc, partition):
             R.Set_Option(B.OPT_ADA_EVAL_DIV, ada)
             res.append(R.Eval_Distances_To(pts, [ck.My_Triangle, ck.Torus, ck.Capsule, ck.My_Box, ck.Ripple]))
         assert same_bits(res[0][0], res[1][0]) and same_bits(res[0][1], res[1][1])
+
+
+@pytest.mark.gpu
+def test_hip_user_defined_lights(hip, orc):
+    assert_same(snapshot(room(hip, False), 2), snapshot(room(hip, False, custom_lights=True), 2))
+    assert_same(snapshot(room(hip, False, W=72, H=48, lamp=True, extra=EXTRA[:1]), 2), snapshot(room(orc, False, W=72, H=48, lamp=True, extra=EXTRA[:1]), 2))
 
 
 @pytest.mark.gpu
