@@ -463,6 +463,9 @@ MDH_DEV float prim_dist(int type, int slot, f3 x)
    }
 }
 
+#ifndef MDH_INFO_UNROLL
+#define MDH_INFO_UNROLL 1
+#endif
 #ifndef MDH_SDF_UNROLL
 #define MDH_SDF_UNROLL 2
 #endif
@@ -547,7 +550,7 @@ template <bool CUSTOM> MDH_DEV float closest_primitive_info(const KScene &sc, f3
 #pragma unroll 1
    for (int k = 0; k < nk; ++k) {
       const int n = hdr(H_KCOUNT + k), s0 = hdr(H_KSLOT + k), base = hdr(H_KBASE + k), type = hdr(H_KTYPE + k);
-#pragma unroll 1
+#pragma unroll MDH_INFO_UNROLL
       for (int i = 0; i < n; ++i) {
          float d = (CUSTOM && type == PK_CUSTOM) ? xdist<false>(k, i, x) : prim_dist(type, s0 + prim_slots(type) * i, x);
          if (d < closest) { closest = d; index = base + i; }

@@ -21,9 +21,6 @@
 #ifndef MDH_TAP_EARLY
 #define MDH_TAP_EARLY 1
 #endif
-#ifndef MDH_DEDUPE_FOLDED
-#define MDH_DEDUPE_FOLDED 0 // register ring for folded corners: measured no gain (VGPR pressure), see DESIGN.md
-#endif
 #ifndef MDH_SKIP_NULL_RAYS
 #define MDH_SKIP_NULL_RAYS 1
 #endif
@@ -356,43 +353,16 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
                   PH_ADD(pt, 2);
                   if (QVIS && ctx == 0) vis_bits = queued_visibility<PART>(sc, pr, pk, P, N, gp, folded, sd0);
                   PH_ADD(pt, 5);
-                  // Folded corners also repeat the whole irradiance term of their twin (same probe: same
-                  // direction, same visibility, same tap); only the trilinear factor differs.  When `folded`
-                  // is the same in all lanes (a tile on one wall) the twin's sqrt(irradiance) and its weight
-                  // before the trilinear factor are kept in a small ring and the corner costs a dozen
-                  // operations; the sum over i keeps its order.  fu = that common value, else 0.
-                  int fu = 0;
-#if MDH_DEDUPE_FOLDED
-                  if (ctx == 0) {
-                     const int f0 = __builtin_amdgcn_readfirstlane(folded);
-                     if (__ballot(folded != f0) == 0ull) fu = f0;
-                  }
-#endif
-                  f3 ring_s0 = F3(0.0f, 0.0f, 0.0f), ring_s1 = ring_s0, ring_s2 = ring_s0, ring_s3 = ring_s0;
-                  float ring_w0 = 0.0f, ring_w1 = 0.0f, ring_w2 = 0.0f, ring_w3 = 0.0f;
+                  // (Reusing the whole irradiance term of a folded corner's twin through a small register ring was
+                  // measured: the 16 extra VGPRs cost what the taps saved -- DESIGN.md, dropped experiments.)
 #pragma unroll 1
                   for (int i = 0; i < 8; ++i) {
                      // ctx 1: a folded corner has the weight of its twin, which is not strictly larger
                      if (ctx == 1 && (i & folded)) continue;
-                     // ring slot of the distinct corner behind i: the bits of i outside fu, packed
-                     int k = 0;
-                     {
-                        int nb = 0;
-                        for (int bit = 0; bit < 3; ++bit)
-                           if (!((fu >> bit) & 1)) { k |= ((i >> bit) & 1) << nb; ++nb; }
-                        k &= 3;
-                     }
                      f3 s_term = F3(0.0f, 0.0f, 0.0f); // sqrt(irradiance tap) of this corner's probe
                      float wpre = 0.0f;                // its weight before the trilinear factor
                      const i3 q = cage_probe(pr, gp, i);
-                     if (i & fu) { // (scalar branch)
-                        switch (k) {
-                        case 0: s_term = ring_s0; wpre = ring_w0; break;
-                        case 1: s_term = ring_s1; wpre = ring_w1; break;
-                        case 2: s_term = ring_s2; wpre = ring_w2; break;
-                        default: s_term = ring_s3; wpre = ring_w3; break;
-                        }
-                     } else {
+                     {
                      const f3 pw = grid_to_world(pr, q);
                      const f3 hvec = (ctx == 0) ? (pw - P) : (P - pw);
                      const float dist = length(hvec);
@@ -463,14 +433,6 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
                         f3 tx = atlas_sample(pr.irr, pr.fmt, pr.pcx, pr.pcy, pr.ires, pr.ishift, base.x + div_pcx(pr, rid.x), base.y + div_pcy(pr, rid.y), u8_tab);
 #endif
                         s_term = sqrt3(tx);
-                        if (fu) { // (scalar) keep it for the corners folded onto this one
-                           switch (k) {
-                           case 0: ring_s0 = s_term; ring_w0 = wpre; break;
-                           case 1: ring_s1 = s_term; ring_w1 = wpre; break;
-                           case 2: ring_s2 = s_term; ring_w2 = wpre; break;
-                           default: ring_s3 = s_term; ring_w3 = wpre; break;
-                           }
-                        }
                      } else { // render_probes.glsl:170-183; probe_to_spec = -vd
                         float weight = dot(-vd, -N);
                         weight *= vis;
