@@ -200,7 +200,14 @@ enum {
     *       stream, two framebuffers; falls back to 1 with volumetrics or the
     *       geometry buffer).
     * Sharded renderers and renderers on a caller-supplied stream run serially. */
-   MDH_OPT_FRAME_OVERLAP = 8
+   MDH_OPT_FRAME_OVERLAP = 8,
+   /* user-defined kinds: 1 (default) = the MDH_X programs are compiled into the
+    * kernels with hiprtc the first time a pass runs (about two seconds per kernel,
+    * cached per process), the analogue of the reference's runtime shader
+    * compilation; 0 = the kernels interpret the programs (no compilation, ~60x
+    * slower).  Same results bit for bit.  If hiprtc cannot build a scene the
+    * renderer falls back to 0 by itself and mdh_last_error says why. */
+   MDH_OPT_JIT = 9
 };
 
 /* passes of Renderers.Render (madarch-renderers.adb:302-321) */

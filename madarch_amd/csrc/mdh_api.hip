@@ -7,11 +7,16 @@
 // gfx950 device mdh_create fails with MDH_E_NO_DEVICE.
 #include "../../include/madarch_hip.h"
 #include "mdh_kernels.h"
+#include "mdh_jit_sources.inc" // the three device headers as string literals (Makefile), for the hiprtc build of user-defined kinds
+
+#include <hip/hiprtc.h>
 
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -179,6 +184,8 @@ struct mdh_renderer {
    void *d_rad2[2] = {nullptr, nullptr}, *d_irr2[2] = {nullptr, nullptr};
    int last = 0;
    int opt_overlap = 2;
+   int opt_jit = 1; // user-defined kinds: 1 = compile the MDH_X programs with hiprtc, 0 = interpret them (MDH_OPT_JIT)
+   std::string jit_kinds; // mdh_jit_kinds.h of this scene (generated once)
    hipStream_t probe_stream = nullptr;   // radiance + irradiance passes of pipelined frames
    hipStream_t alt_stream = nullptr;     // screen pass of every other pipelined frame
    hipEvent_t ev_screen[2] = {nullptr, nullptr}, ev_probe[2] = {nullptr, nullptr}, ev_join = nullptr, ev_join_alt = nullptr;
@@ -635,6 +642,7 @@ extern "C" int32_t mdh_set_option(mdh_renderer *r, int32_t option, int32_t value
    case MDH_OPT_WORLD: if (value < 1) return seterr(MDH_E_INVALID, "world < 1"); r->opt_world = value; break;
    case MDH_OPT_TIMING: r->opt_timing = value ? 1 : 0; break;
    case MDH_OPT_ADA_EVAL_DIV: r->opt_ada_div = value ? 1 : 0; break;
+   case MDH_OPT_JIT: r->opt_jit = value ? 1 : 0; break;
    case MDH_OPT_FRAME_OVERLAP: if (value < 0 || value > 2) return seterr(MDH_E_INVALID, "frame overlap is 0, 1 or 2"); r->opt_overlap = value; break;
    default: return seterr(MDH_E_INVALID, "unknown option");
    }
@@ -653,6 +661,7 @@ extern "C" int32_t mdh_get_option(mdh_renderer *r, int32_t option, int32_t *valu
    case MDH_OPT_TIMING: *value = r->opt_timing; break;
    case MDH_OPT_ADA_EVAL_DIV: *value = r->opt_ada_div; break;
    case MDH_OPT_FRAME_OVERLAP: *value = r->opt_overlap; break;
+   case MDH_OPT_JIT: *value = r->opt_jit; break;
    default: return seterr(MDH_E_INVALID, "unknown option");
    }
    return MDH_OK;
@@ -747,6 +756,170 @@ static size_t lds_bytes(const mdh_renderer *r) { return (size_t)r->ks.table_f4 *
 // the march kernels park MDH_PARK_DWORDS floats per thread behind the table (mdh_march.h)
 static size_t lds_bytes_march(const mdh_renderer *r) { return lds_bytes(r) + (size_t)MDH_PARK_DWORDS * MDH_BLOCK * sizeof(float); }
 
+// ------------------------------------------------------------------ hiprtc build of user-defined kinds
+// MDH_OPT_JIT: instead of interpreting the MDH_X programs, compile them.  Every program becomes a
+// straight-line function (one statement per instruction, the same operations in the same order, so
+// the results are those of the interpreter bit for bit), mdh_jit_kinds.h dispatches on the kind, and
+// the kernels of this library are compiled again around it with hiprtc -- the analogue of the
+// reference's runtime glCompileShader of its generated GLSL.  Modules are cached per process by their
+// generated source.
+static void jit_emit_program(std::string &out, const char *name, const std::vector<int32_t> &code)
+{
+   char buf[256];
+   bool used[MDH_X_REGS] = {false};
+   std::string body;
+   static const char *ARG[10] = {"x.x", "x.y", "x.z", "nrm.x", "nrm.y", "nrm.z", "dir.x", "dir.y", "dir.z", "dist"};
+   for (size_t pc = 0; pc < code.size(); ++pc) {
+      const uint32_t w = (uint32_t)code[pc];
+      const int op = w & 255, d = (w >> 8) & 63, a = (w >> 16) & 255, b = (w >> 24) & 63, ra = a & 63;
+      used[d] = true;
+      const char *fmt = nullptr;
+      switch (op) {
+      case MDH_X_LIT: snprintf(buf, sizeof buf, "   r%d = __builtin_bit_cast(float, (int)0x%08xu);\n", d, (unsigned)code[++pc]); body += buf; continue;
+      case MDH_X_COMP: snprintf(buf, sizeof buf, "   r%d = tab_float(ent + %d);\n", d, a); body += buf; continue;
+      case MDH_X_POINT: snprintf(buf, sizeof buf, "   r%d = %s;\n", d, ARG[a < 10 ? a : 9]); body += buf; continue;
+      case MDH_X_SEL: {
+         const int c = code[++pc] & 63;
+         used[ra] = used[b] = used[c] = true;
+         snprintf(buf, sizeof buf, "   r%d = r%d != 0.0f ? r%d : r%d;\n", d, ra, b, c); body += buf; continue;
+      }
+      case MDH_X_MOV: fmt = "   r%d = r%d;\n"; break;
+      case MDH_X_ADD: fmt = "   r%d = r%d + r%d;\n"; break;
+      case MDH_X_SUB: fmt = "   r%d = r%d - r%d;\n"; break;
+      case MDH_X_MUL: fmt = "   r%d = r%d * r%d;\n"; break;
+      case MDH_X_DIV: fmt = "   r%d = r%d / r%d;\n"; break;
+      case MDH_X_DIVF: fmt = "   r%d = ADA_DIV ? r%2$d + r%3$d : r%2$d / r%3$d;\n"; break;
+      case MDH_X_NEG: fmt = "   r%d = -r%d;\n"; break;
+      case MDH_X_ABS: fmt = "   r%d = __builtin_fabsf(r%d);\n"; break;
+      case MDH_X_FLOOR: fmt = "   r%d = __builtin_floorf(r%d);\n"; break;
+      case MDH_X_SIGN: fmt = "   r%d = sign_(r%d);\n"; break;
+      case MDH_X_MIN: fmt = "   r%d = min_(r%d, r%d);\n"; break;
+      case MDH_X_MAX: fmt = "   r%d = max_(r%d, r%d);\n"; break;
+      case MDH_X_SQRT: fmt = "   r%d = sqrt_(r%d);\n"; break;
+      case MDH_X_POW: fmt = "   r%d = pow_(r%d, r%d);\n"; break;
+      case MDH_X_LT: fmt = "   r%d = r%d < r%d ? 1.0f : 0.0f;\n"; break;
+      case MDH_X_GT: fmt = "   r%d = r%d > r%d ? 1.0f : 0.0f;\n"; break;
+      case MDH_X_LE: fmt = "   r%d = r%d <= r%d ? 1.0f : 0.0f;\n"; break;
+      case MDH_X_GE: fmt = "   r%d = r%d >= r%d ? 1.0f : 0.0f;\n"; break;
+      case MDH_X_ITOF: fmt = "   r%d = (float)__builtin_bit_cast(int, r%d);\n"; break;
+      case MDH_X_ACOS: fmt = "   r%d = acos_(r%d);\n"; break;
+      case MDH_X_SIN: fmt = "   r%d = sin_(r%d);\n"; break;
+      case MDH_X_COS: fmt = "   r%d = cos_(r%d);\n"; break;
+      case MDH_X_TAN: fmt = "   r%d = tan_(r%d);\n"; break;
+      case MDH_X_ASIN: fmt = "   r%d = asin_(r%d);\n"; break;
+      case MDH_X_ATAN: fmt = "   r%d = atan_(r%d);\n"; break;
+      default: fmt = "   r%d = 0.0f;\n"; break;
+      }
+      used[ra] = used[b] = true;
+      if (op == MDH_X_DIVF) snprintf(buf, sizeof buf, "   r%d = ADA_DIV ? r%d + r%d : r%d / r%d;\n", d, ra, b, ra, b);
+      else snprintf(buf, sizeof buf, fmt, d, ra, b);
+      body += buf;
+   }
+   used[0] = used[1] = used[2] = true;
+   out += "template <bool ADA_DIV> MDH_DEV f3 ";
+   out += name;
+   out += "(int ent, f3 x, f3 nrm, f3 dir, float dist)\n{\n   float";
+   bool first = true;
+   for (int i = 0; i < MDH_X_REGS; ++i)
+      if (used[i]) { snprintf(buf, sizeof buf, "%s r%d = 0.0f", first ? "" : ",", i); out += buf; first = false; }
+   out += ";\n" + body + "   return F3(r0, r1, r2);\n}\n";
+}
+// mdh_jit_kinds.h of a scene: the programs as functions and the two dispatchers mdh_device.h calls
+static std::string jit_kinds_header(const mdh_renderer *r)
+{
+   std::string s = "// generated by libmadarch_hip (mdh_api.hip: jit_kinds_header)\n", prim_cases, light_cases;
+   char name[64], buf[256];
+   for (int k = 0; k < r->npk; ++k) {
+      if (r->pk[k].type != PK_CUSTOM) continue;
+      const std::vector<int32_t> *progs[3] = {&r->pk[k].x_dist, &r->pk[k].x_nrm, &r->pk[k].x_mat};
+      for (int q = 0; q < 3; ++q) {
+         snprintf(name, sizeof name, "jit_p%d_%d", k, q);
+         jit_emit_program(s, name, *progs[q]);
+         snprintf(buf, sizeof buf, "   case %d: return %s<ADA_DIV>(ent, x, F3(0.0f, 0.0f, 0.0f), F3(0.0f, 0.0f, 0.0f), 0.0f);\n", q * 8 + k, name);
+         prim_cases += buf;
+      }
+   }
+   for (int k = 0; k < r->nlk; ++k) {
+      if (r->lk[k].type != LK_CUSTOM) continue;
+      const std::vector<int32_t> *progs[2] = {&r->lk[k].x_dist, &r->lk[k].x_nrm};
+      for (int q = 0; q < 2; ++q) {
+         snprintf(name, sizeof name, "jit_l%d_%d", k, q);
+         jit_emit_program(s, name, *progs[q]);
+         snprintf(buf, sizeof buf, "   case %d: return %s<false>(ent, pos, nrm, dir, dist);\n", q * 4 + k, name);
+         light_cases += buf;
+      }
+   }
+   s += "// which: 0 Distance, 1 Normal, 2 Material; k: the kind (wave-uniform)\n"
+        "template <bool ADA_DIV> MDH_DEV f3 jit_prim(int which, int k, int ent, f3 x)\n{\n   switch (which * 8 + k) {\n" + prim_cases +
+        "   default: break;\n   }\n   return F3(0.0f, 0.0f, 0.0f);\n}\n"
+        "// which: 0 Sample, 1 Position\n"
+        "MDH_DEV f3 jit_light(int which, int k, int ent, f3 pos, f3 nrm, f3 dir, float dist)\n{\n   switch (which * 4 + k) {\n" + light_cases +
+        "   default: break;\n   }\n   return F3(0.0f, 0.0f, 0.0f);\n}\n";
+   return s;
+}
+
+struct JitModule {
+   hipModule_t mod = nullptr;
+   std::map<std::string, hipFunction_t> fn;
+};
+static std::mutex g_jit_mutex;
+static std::map<std::string, JitModule *> g_jit_cache;
+
+// Compile the kernels named by `exprs` (template-ids) around this scene's mdh_jit_kinds.h.
+static JitModule *jit_module(mdh_renderer *r, const std::vector<std::string> &exprs)
+{
+   if (r->jit_kinds.empty()) r->jit_kinds = jit_kinds_header(r);
+   std::string key = r->jit_kinds;
+   for (auto &e : exprs) key += "|" + e;
+   std::lock_guard<std::mutex> lock(g_jit_mutex);
+   auto it = g_jit_cache.find(key);
+   if (it != g_jit_cache.end()) return it->second;
+   const char *headers[4] = {MDH_SRC_DEVICE, MDH_SRC_MARCH, MDH_SRC_KERNELS, r->jit_kinds.c_str()};
+   const char *names[4] = {"mdh_device.h", "mdh_march.h", "mdh_kernels.h", "mdh_jit_kinds.h"};
+   hiprtcProgram prog = nullptr;
+   auto fail = [&](const char *what, hiprtcResult e) -> JitModule * {
+      std::string log;
+      size_t n = 0;
+      if (prog && hiprtcGetProgramLogSize(prog, &n) == HIPRTC_SUCCESS && n > 1) { log.resize(n); hiprtcGetProgramLog(prog, &log[0]); }
+      snprintf(g_err, sizeof g_err, "hiprtc %s failed (%s): %.380s", what, hiprtcGetErrorString(e), log.c_str());
+      if (prog) hiprtcDestroyProgram(&prog);
+      return nullptr;
+   };
+   hiprtcResult e = hiprtcCreateProgram(&prog, "#define MDH_JIT 1\n#include \"mdh_kernels.h\"\n", "mdh_jit.hip", 4, headers, names);
+   if (e != HIPRTC_SUCCESS) return fail("create", e);
+   for (auto &x : exprs)
+      if ((e = hiprtcAddNameExpression(prog, x.c_str())) != HIPRTC_SUCCESS) return fail("name expression", e);
+   // the flags of the Makefile: one IEEE operation per source operation, no vectorizers
+   const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
+                         "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-gpu-flush-denormals-to-zero", "-fno-vectorize", "-fno-slp-vectorize"};
+   if ((e = hiprtcCompileProgram(prog, (int)(sizeof opts / sizeof opts[0]), opts)) != HIPRTC_SUCCESS) return fail("compile", e);
+   size_t size = 0;
+   if ((e = hiprtcGetCodeSize(prog, &size)) != HIPRTC_SUCCESS) return fail("code size", e);
+   std::vector<char> code(size);
+   if ((e = hiprtcGetCode(prog, code.data())) != HIPRTC_SUCCESS) return fail("code", e);
+   JitModule *m = new JitModule();
+   if (hipModuleLoadData(&m->mod, code.data()) != hipSuccess) { delete m; return fail("module load", HIPRTC_ERROR_INTERNAL_ERROR); }
+   for (auto &x : exprs) {
+      const char *lowered = nullptr;
+      if ((e = hiprtcGetLoweredName(prog, x.c_str(), &lowered)) != HIPRTC_SUCCESS) { delete m; return fail("lowered name", e); }
+      hipFunction_t f = nullptr;
+      if (hipModuleGetFunction(&f, m->mod, lowered) != hipSuccess) { delete m; return fail("module function", HIPRTC_ERROR_INTERNAL_ERROR); }
+      m->fn[x] = f;
+   }
+   hiprtcDestroyProgram(&prog);
+   g_jit_cache[key] = m;
+   return m;
+}
+// launch a function of a JIT module: the arguments are the kernel's by-value structs, laid out as the
+// kernarg segment lays them out (each at its natural alignment = a struct of them)
+template <typename Args> static int jit_launch(hipFunction_t f, int blocks, int block, size_t lds, hipStream_t st, Args &args)
+{
+   size_t size = sizeof(Args);
+   void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+   HIP_TRY(hipModuleLaunchKernel(f, blocks, 1, 1, block, 1, 1, (unsigned)lds, st, nullptr, extra));
+   return MDH_OK;
+}
+
 // Update_Partitioning (renderers.adb:757-775): all three methods build the table on the device
 extern "C" int32_t mdh_update_partitioning(mdh_renderer *r, int32_t method)
 {
@@ -816,6 +989,21 @@ static int run_pass(mdh_renderer *r, int pass, hipStream_t st, int src, int dst,
    pr.rad = r->d_rad2[dst];
    pr.irr = r->d_irr2[pass == MDH_PASS_RADIANCE ? src : dst];
    KCamera cam = make_camera(r);
+   // user-defined kinds compiled into the kernels (MDH_OPT_JIT); a scene hiprtc cannot build falls back to the
+   // interpreter for good (the reason stays in mdh_last_error, MDH_OPT_JIT reads 0 afterwards)
+   bool jit = has_custom && r->opt_jit;
+   char kname[64] = "";
+   JitModule *jm = nullptr;
+   if (jit) {
+      switch (pass) {
+      case MDH_PASS_RADIANCE: snprintf(kname, sizeof kname, "k_radiance<%d>", pf); break;
+      case MDH_PASS_VISIBILITY: snprintf(kname, sizeof kname, "k_visibility<%d>", pf); break;
+      case MDH_PASS_SCATTERING: snprintf(kname, sizeof kname, "k_scattering<%d>", pf); break;
+      case MDH_PASS_SCREEN: snprintf(kname, sizeof kname, "k_screen<%d, %d, %s>", pf, r->opt_mode, r->opt_gbuffer ? "true" : "false"); break;
+      default: jit = false; break;
+      }
+      if (jit && !(jm = jit_module(r, {kname}))) { r->opt_jit = 0; jit = false; }
+   }
    hipEvent_t e0 = nullptr, e1 = nullptr;
    if (r->opt_timing) {
       e0 = get_event(r);
@@ -832,7 +1020,12 @@ static int run_pass(mdh_renderer *r, int pass, hipStream_t st, int src, int dst,
       }
       if (n > 0) {
          int blocks = (int)((n + MDH_BLOCK - 1) / MDH_BLOCK);
-         MDH_LAUNCH_PF(k_radiance, dim3(blocks), dim3(MDH_BLOCK), lds_bytes_march(r), r->ks, pr);
+         if (jit) {
+            struct { KScene sc; KProbes pr; } args = {r->ks, pr};
+            int rc = jit_launch(jm->fn[kname], blocks, MDH_BLOCK, lds_bytes_march(r), st, args);
+            if (rc != MDH_OK) return rc;
+         } else
+            MDH_LAUNCH_PF(k_radiance, dim3(blocks), dim3(MDH_BLOCK), lds_bytes_march(r), r->ks, pr);
       }
       break;
    }
@@ -848,7 +1041,12 @@ static int run_pass(mdh_renderer *r, int pass, hipStream_t st, int src, int dst,
       long n = (long)vol.vw * vol.vh * vol.vz;
       if (n > 0) {
          int blocks = (int)((n + MDH_BLOCK - 1) / MDH_BLOCK);
-         MDH_LAUNCH_PF(k_visibility, dim3(blocks), dim3(MDH_BLOCK), lds_bytes(r), r->ks, vol, cam);
+         if (jit) {
+            struct { KScene sc; KVolumetrics vol; KCamera cam; } args = {r->ks, vol, cam};
+            int rc = jit_launch(jm->fn[kname], blocks, MDH_BLOCK, lds_bytes(r), st, args);
+            if (rc != MDH_OK) return rc;
+         } else
+            MDH_LAUNCH_PF(k_visibility, dim3(blocks), dim3(MDH_BLOCK), lds_bytes(r), r->ks, vol, cam);
       }
       break;
    }
@@ -857,7 +1055,12 @@ static int run_pass(mdh_renderer *r, int pass, hipStream_t st, int src, int dst,
       long n = (long)vol.sw * vol.sh;
       if (n > 0) {
          int blocks = (int)((n + MDH_BLOCK - 1) / MDH_BLOCK);
-         MDH_LAUNCH_PF(k_scattering, dim3(blocks), dim3(MDH_BLOCK), lds_bytes(r), r->ks, vol, cam);
+         if (jit) {
+            struct { KScene sc; KVolumetrics vol; KCamera cam; } args = {r->ks, vol, cam};
+            int rc = jit_launch(jm->fn[kname], blocks, MDH_BLOCK, lds_bytes(r), st, args);
+            if (rc != MDH_OK) return rc;
+         } else
+            MDH_LAUNCH_PF(k_scattering, dim3(blocks), dim3(MDH_BLOCK), lds_bytes(r), r->ks, vol, cam);
       }
       break;
    }
@@ -877,6 +1080,11 @@ static int run_pass(mdh_renderer *r, int pass, hipStream_t st, int src, int dst,
       int own_tiles = (a.n_tiles - a.rank + a.world - 1) / a.world;
       if (own_tiles > 0) {
          int blocks = (own_tiles + (MDH_BLOCK / 64) - 1) / (MDH_BLOCK / 64);
+         if (jit) {
+            struct { KScene sc; KProbes pr; KVolumetrics vol; KCamera cam; ScreenArgs a; } args = {r->ks, pr, vol, cam, a};
+            int rc = jit_launch(jm->fn[kname], blocks, MDH_BLOCK, lds_bytes_march(r), st, args);
+            if (rc != MDH_OK) return rc;
+         } else
          switch (pf) {
          case 0: launch_screen_m<0>(r, st, pr, vol, cam, a, blocks); break;
          case 1: launch_screen_m<1>(r, st, pr, vol, cam, a, blocks); break;

@@ -16,8 +16,10 @@
 // file:line citations are relative to /root/reference/madarch/.
 #pragma once
 
+#ifndef MDH_JIT // (hiprtc brings the HIP device builtins itself and has no system headers; nothing below needs more)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#endif
 
 #define MDH_DEV static __device__ __forceinline__
 // Triangle code is kept out of line: it is cold in every benchmark scene and register hungry
@@ -446,10 +448,54 @@ template <bool ADA_DIV> MDH_XRUN f3 xrun(int code, int n, int ent, f3 x, f3 nrm 
    }
    return F3(lo[0], lo[1], lo[2]);
 }
-// distance of instance i of user-defined kind k (scene order); k uniform, i per lane
+// The five entry points of user-defined kinds: kind k is wave-uniform, instance i per lane.  In the
+// library build they interpret the kind's MDH_X programs; in a JIT build (MDH_JIT, the module hiprtc
+// compiles for one scene, mdh_api.hip) mdh_jit_kinds.h holds the same programs as straight-line
+// functions, dispatched by a scalar switch on k.
+MDH_DEV int x_prim_ent(int k, int i) { return (hdr(H_KSLOT + k) + hdr(H_KSTRIDE + k) * i) * 4; }
+MDH_DEV int x_light_ent(int k, int i) { return (hdr(H_LSLOT + k) + hdr(H_LSTRIDE + k) * i) * 4; }
+#ifdef MDH_JIT
+#include "mdh_jit_kinds.h"
+#endif
 template <bool ADA_DIV> MDH_DEV float xdist(int k, int i, f3 x)
 {
-   return xrun<ADA_DIV>(hdr(H_XDIST + k), hdr(H_XDISTN + k), (hdr(H_KSLOT + k) + hdr(H_KSTRIDE + k) * i) * 4, x).x;
+#ifdef MDH_JIT
+   return jit_prim<ADA_DIV>(0, k, x_prim_ent(k, i), x).x;
+#else
+   return xrun<ADA_DIV>(hdr(H_XDIST + k), hdr(H_XDISTN + k), x_prim_ent(k, i), x).x;
+#endif
+}
+template <bool ADA_DIV> MDH_DEV f3 xnormal(int k, int i, f3 x)
+{
+#ifdef MDH_JIT
+   return jit_prim<ADA_DIV>(1, k, x_prim_ent(k, i), x);
+#else
+   return xrun<ADA_DIV>(hdr(H_XNRM + k), hdr(H_XNRMN + k), x_prim_ent(k, i), x);
+#endif
+}
+MDH_DEV int xmaterial(int k, int i)
+{
+#ifdef MDH_JIT
+   return __builtin_bit_cast(int, jit_prim<false>(2, k, x_prim_ent(k, i), F3(0.0f, 0.0f, 0.0f)).x);
+#else
+   return __builtin_bit_cast(int, xrun<false>(hdr(H_XMAT + k), hdr(H_XMATN + k), x_prim_ent(k, i), F3(0.0f, 0.0f, 0.0f)).x);
+#endif
+}
+MDH_DEV f3 xlight_position(int k, int i)
+{
+#ifdef MDH_JIT
+   return jit_light(1, k, x_light_ent(k, i), F3(0.0f, 0.0f, 0.0f), F3(0.0f, 0.0f, 0.0f), F3(0.0f, 0.0f, 0.0f), 0.0f);
+#else
+   return xrun<false>(hdr(H_XLPOS + k), hdr(H_XLPOSN + k), x_light_ent(k, i), F3(0.0f, 0.0f, 0.0f));
+#endif
+}
+MDH_DEV f3 xlight_sample(int k, int i, f3 pos, f3 normal, f3 dir, float dist)
+{
+#ifdef MDH_JIT
+   return jit_light(0, k, x_light_ent(k, i), pos, normal, dir, dist);
+#else
+   return xrun<false>(hdr(H_XLSAMPLE + k), hdr(H_XLSAMPLEN + k), x_light_ent(k, i), pos, normal, dir, dist);
+#endif
 }
 
 // dist_to_<Kind>(prims[i], x); `slot` = first float4 of the primitive (any lane value)
@@ -572,9 +618,8 @@ template <bool CUSTOM> MDH_DEV void primitive_info(const KScene &sc, int index, 
       if (index < kmax) {
          const int type = hdr(H_KTYPE + k);
          if (CUSTOM && type == PK_CUSTOM) { // the kind's Normal and Material programs on this lane's instance
-            const int ent = (hdr(H_KSLOT + k) + hdr(H_KSTRIDE + k) * index) * 4;
-            normal = xrun<false>(hdr(H_XNRM + k), hdr(H_XNRMN + k), ent, pos);
-            material_id = __builtin_bit_cast(int, xrun<false>(hdr(H_XMAT + k), hdr(H_XMATN + k), ent, pos).x);
+            normal = xnormal<false>(k, index, pos);
+            material_id = xmaterial(k, index);
             return;
          }
          const int slot = hdr(H_KSLOT + k) + prim_slots(type) * index; // per-lane LDS gather
@@ -686,11 +731,10 @@ template <bool CUSTOM> MDH_DEV f3 sample_light(const KScene &sc, int index, f3 p
       const int n = hdr(H_LCOUNT + k);
       if (index < n) {
          if (CUSTOM && hdr(H_LTYPE + k) == LK_CUSTOM) { // the generated sample_<Light> (scenes.adb:497-549) around the kind's programs
-            const int ent = (hdr(H_LSLOT + k) + hdr(H_LSTRIDE + k) * index) * 4;
-            dir = xrun<false>(hdr(H_XLPOS + k), hdr(H_XLPOSN + k), ent, pos) - pos;
+            dir = xlight_position(k, index) - pos;
             dist = length(dir);
             dir = dir / dist;
-            return xrun<false>(hdr(H_XLSAMPLE + k), hdr(H_XLSAMPLEN + k), ent, pos, normal, dir, dist);
+            return xlight_sample(k, index, pos, normal, dir, dist);
          }
          if (hdr(H_LTYPE + k) == LK_POINT) { // madarch-lights-point_lights.ads:20-22
             const int s = hdr(H_LSLOT + k) + 2 * index;

@@ -23,7 +23,12 @@
 #define MDH_RAD_PROBES_PER_WAVE 64 // 1, 4, 16 or 64 (measured on MI355X: see DESIGN.md)
 #endif
 // kernels of scenes with user-defined kinds carry the 64-register file of the MDH_X interpreter
+// (not in a hiprtc build, where the programs are plain code)
+#ifdef MDH_JIT
+#define MDH_OCC(PART) MDH_WAVES_PER_SIMD
+#else
 #define MDH_OCC(PART) (((PART) & MDH_PF_CUSTOM) ? 2 : MDH_WAVES_PER_SIMD)
+#endif
 #ifndef MDH_RAD_QVIS
 #define MDH_RAD_QVIS 1 // probe-visibility rays through the wave's ray queue (mdh_march.h: queued_visibility)
 #endif
@@ -428,7 +433,7 @@ template <bool ADA_DIV> __global__ __launch_bounds__(64) void k_eval_distance(KS
             const int slot = hdr(H_KSLOT + k) + prim_slots(type) * i;
             float4 A = s_tab[slot];
             switch (type) {
-            case PK_CUSTOM: normal = xrun<ADA_DIV>(hdr(H_XNRM + k), hdr(H_XNRMN + k), (hdr(H_KSLOT + k) + hdr(H_KSTRIDE + k) * i) * 4, p); break;
+            case PK_CUSTOM: normal = xnormal<ADA_DIV>(k, i, p); break;
             case PK_SPHERE: normal = normalize(p - xyz(A)); break;
             case PK_PLANE: normal = xyz(A); break;
             case PK_BOX: normal = nrm_box(A, s_tab[slot + 1], p); break;

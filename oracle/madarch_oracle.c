@@ -1338,6 +1338,7 @@ int32_t orc_set_option(orc_renderer *r, int32_t option, int32_t value)
    case MDH_OPT_TIMING: r->opt_timing = value; break;
    case MDH_OPT_ADA_EVAL_DIV: r->opt_ada_div = value; break;
    case MDH_OPT_FRAME_OVERLAP: break; /* scheduling only: nothing to restate */
+   case MDH_OPT_JIT: break;           /* how the kernels run the MDH_X programs: nothing to restate */
    case ORC_OPT_SDF_MODE: r->opt_sdf_mode = value; break;
    case ORC_OPT_THREADS: r->opt_threads = value; break;
    default: return seterr(MDH_E_INVALID, "unknown option");
@@ -1357,6 +1358,7 @@ int32_t orc_get_option(orc_renderer *r, int32_t option, int32_t *value)
    case MDH_OPT_TIMING: *value = r->opt_timing; break;
    case MDH_OPT_ADA_EVAL_DIV: *value = r->opt_ada_div; break;
    case MDH_OPT_FRAME_OVERLAP: *value = 0; break;
+   case MDH_OPT_JIT: *value = 0; break;
    case ORC_OPT_SDF_MODE: *value = r->opt_sdf_mode; break;
    case ORC_OPT_THREADS: *value = nthreads(r); break;
    default: return seterr(MDH_E_INVALID, "unknown option");

@@ -152,9 +152,12 @@ def test_invalid_programs_are_rejected(orc):
 
 # --------------------------------------------------------------------------------- GPU
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode,partition", [(0, False), (2, True)])
-def test_hip_restated_kinds_equal_the_built_in_kinds(hip, mode, partition):
-    assert_same(snapshot(room(hip, False, mode=mode, partition=partition), 2), snapshot(room(hip, True, mode=mode, partition=partition), 2))
+@pytest.mark.parametrize("mode,partition,jit", [(0, False, 0), (2, True, 0), (0, True, 1), (2, False, 1)])
+def test_hip_restated_kinds_equal_the_built_in_kinds(hip, mode, partition, jit):
+    R = room(hip, True, mode=mode, partition=partition)
+    R.Set_Option(B.OPT_JIT, jit)
+    assert_same(snapshot(room(hip, False, mode=mode, partition=partition), 2), snapshot(R, 2))
+    assert R.Get_Option(B.OPT_JIT) == jit  # (a failed hiprtc build would have switched it off)
 
 
 @pytest.mark.gpu
@@ -177,6 +180,18 @@ def test_hip_new_kinds_against_the_oracle(hip, orc, partition):
 def test_hip_user_defined_lights(hip, orc):
     assert_same(snapshot(room(hip, False), 2), snapshot(room(hip, False, custom_lights=True), 2))
     assert_same(snapshot(room(hip, False, W=72, H=48, lamp=True, extra=EXTRA[:1]), 2), snapshot(room(orc, False, W=72, H=48, lamp=True, extra=EXTRA[:1]), 2))
+
+
+@pytest.mark.gpu
+def test_hip_jit_equals_the_interpreter(hip):
+    """MDH_OPT_JIT: the same programs compiled into the kernels with hiprtc give the interpreter's frames bit for bit
+    (and so the built-in paths, for the restated kinds)."""
+    outs = []
+    for jit in (0, 1):
+        R = room(hip, True, W=72, H=48, custom_lights=True, lamp=True, extra=EXTRA)
+        R.Set_Option(B.OPT_JIT, jit)
+        outs.append(snapshot(R, 2))
+    assert_same(*outs)
 
 
 @pytest.mark.gpu
