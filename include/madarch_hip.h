@@ -207,7 +207,12 @@ enum {
     * compilation; 0 = the kernels interpret the programs (no compilation, ~60x
     * slower).  Same results bit for bit.  If hiprtc cannot build a scene the
     * renderer falls back to 0 by itself and mdh_last_error says why. */
-   MDH_OPT_JIT = 9
+   MDH_OPT_JIT = 9,
+   /* sharded renderers (MDH_OPT_WORLD > 1): 1 (default) = the irradiance pass updates ALL
+    * probes on every rank from the gathered radiance atlas instead of its own slice (the pass
+    * is one workgroup per probe and far from filling a GPU: the same time, and the second
+    * exchange of the frame is not needed); 0 = own slice only, to be exchanged. */
+   MDH_OPT_IRRADIANCE_ALL = 10
 };
 
 /* passes of Renderers.Render (madarch-renderers.adb:302-321) */

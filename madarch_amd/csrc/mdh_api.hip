@@ -184,6 +184,7 @@ struct mdh_renderer {
    void *d_rad2[2] = {nullptr, nullptr}, *d_irr2[2] = {nullptr, nullptr};
    int last = 0;
    int opt_overlap = 2;
+   int opt_irr_all = 1; // MDH_OPT_IRRADIANCE_ALL
    int opt_jit = 1; // user-defined kinds: 1 = compile the MDH_X programs with hiprtc, 0 = interpret them (MDH_OPT_JIT)
    std::string jit_kinds; // mdh_jit_kinds.h of this scene (generated once)
    hipStream_t probe_stream = nullptr;   // radiance + irradiance passes of pipelined frames
@@ -643,6 +644,7 @@ extern "C" int32_t mdh_set_option(mdh_renderer *r, int32_t option, int32_t value
    case MDH_OPT_TIMING: r->opt_timing = value ? 1 : 0; break;
    case MDH_OPT_ADA_EVAL_DIV: r->opt_ada_div = value ? 1 : 0; break;
    case MDH_OPT_JIT: r->opt_jit = value ? 1 : 0; break;
+   case MDH_OPT_IRRADIANCE_ALL: r->opt_irr_all = value ? 1 : 0; break;
    case MDH_OPT_FRAME_OVERLAP: if (value < 0 || value > 2) return seterr(MDH_E_INVALID, "frame overlap is 0, 1 or 2"); r->opt_overlap = value; break;
    default: return seterr(MDH_E_INVALID, "unknown option");
    }
@@ -662,6 +664,7 @@ extern "C" int32_t mdh_get_option(mdh_renderer *r, int32_t option, int32_t *valu
    case MDH_OPT_ADA_EVAL_DIV: *value = r->opt_ada_div; break;
    case MDH_OPT_FRAME_OVERLAP: *value = r->opt_overlap; break;
    case MDH_OPT_JIT: *value = r->opt_jit; break;
+   case MDH_OPT_IRRADIANCE_ALL: *value = r->opt_irr_all; break;
    default: return seterr(MDH_E_INVALID, "unknown option");
    }
    return MDH_OK;
@@ -1030,6 +1033,7 @@ static int run_pass(mdh_renderer *r, int pass, hipStream_t st, int src, int dst,
       break;
    }
    case MDH_PASS_IRRADIANCE: {
+      if (r->opt_world > 1 && r->opt_irr_all) { pr.probe_begin = 0; pr.probe_end = probe_total(r); } // every rank, every probe
       int n = pr.probe_end - pr.probe_begin; // one workgroup per probe, its taps staged in LDS
       size_t lds = (size_t)2 * pr.rres * pr.rres * sizeof(float4);
       if (lds > 64 * 1024) return seterr(MDH_E_INVALID, "radiance resolution too large for the irradiance pass (LDS)");

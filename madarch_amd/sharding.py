@@ -7,9 +7,10 @@ its passes back to back); what follows is the build's own design (DESIGN.md
   0. Frame_Begin: the library picks the atlas set of this frame (frames are kept in flight)
   1. radiance pass for the probes [r P/N, (r+1) P/N)        -- no communication
   2. all-gather of the radiance atlas slices                 -- RCCL over xGMI
-  3. irradiance pass for the same probes (needs the whole radiance atlas because
-     of the corner-sample bleed, update_probe_irradiance.glsl:26-31)
-  4. all-gather of the irradiance atlas slices
+  3. irradiance pass -- by default for ALL probes on every rank (one workgroup per probe: it
+     takes as long for 512 probes as for 64, and step 4 disappears; MDH_OPT_IRRADIANCE_ALL); it
+     needs the whole radiance atlas anyway (corner-sample bleed, update_probe_irradiance.glsl:26-31)
+  4. with MDH_OPT_IRRADIANCE_ALL = 0: own probes only in step 3, then all-gather of the irradiance slices
   5. volumetric passes, replicated (they depend on the camera only)
   6. screen pass for the 8x8 tiles t with t mod N == r       -- no communication
 
@@ -119,7 +120,9 @@ class ShardedFrame:
             if self.exchange is not None:
                 self.exchange.all_gather(R, B.TEX_RADIANCE, self.rank, self.world)
             R.Frame_Probe_Pass(B.PASS_IRRADIANCE)
-            if self.exchange is not None:
+            # by default every rank updates every probe's irradiance from the gathered radiance
+            # (MDH_OPT_IRRADIANCE_ALL): the pass takes the same time and this exchange disappears
+            if self.exchange is not None and not R.Get_Option(B.OPT_IRRADIANCE_ALL):
                 self.exchange.all_gather(R, B.TEX_IRRADIANCE, self.rank, self.world)
         R.Frame_End()
 

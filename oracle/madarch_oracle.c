@@ -125,7 +125,7 @@ struct orc_renderer {
    float *fb;
    int32_t *gb_index, *gb_steps;
    float *gb_t;
-   int opt_atlas, opt_mode, opt_ao, opt_gbuffer, opt_rank, opt_world, opt_timing, opt_ada_div;
+   int opt_atlas, opt_mode, opt_ao, opt_gbuffer, opt_rank, opt_world, opt_timing, opt_ada_div, opt_irr_all;
    int opt_sdf_mode, opt_threads;
    uint64_t sdf_evals; /* closest_primitive[_info] calls of the last pass set */
 };
@@ -1053,6 +1053,7 @@ static void pass_irradiance(orc_renderer *r)
    const tex_t *rad = &r->tex[MDH_TEX_RADIANCE];
    int pb, pe;
    own_probes(r, &pb, &pe);
+   if (r->opt_world > 1 && r->opt_irr_all) { pb = 0; pe = probe_total(r); } /* MDH_OPT_IRRADIANCE_ALL */
    int rres = r->probes.radiance_resolution;
    float pcx = (float)r->probes.probe_count[0], pcy = (float)r->probes.probe_count[1];
    v2 step = V2(1.0f / pcx / (float)rres, 1.0f / pcy / (float)rres);
@@ -1297,7 +1298,7 @@ int32_t orc_create(int32_t width, int32_t height, const mdh_scene_desc *scene, c
    r->probes = *probes;
    r->vol = *vol;
    r->cam_m[0] = r->cam_m[4] = r->cam_m[8] = 1.0f; /* renderers.adb:225-226 */
-   r->opt_ao = 3; r->opt_world = 1; r->opt_ada_div = 1;
+   r->opt_ao = 3; r->opt_world = 1; r->opt_ada_div = 1; r->opt_irr_all = 1;
    tex_alloc(&r->tex[MDH_TEX_RADIANCE], probes->radiance_resolution * probes->probe_count[0], probes->radiance_resolution * probes->probe_count[1], 3, 1);
    tex_alloc(&r->tex[MDH_TEX_IRRADIANCE], probes->irradiance_resolution * probes->probe_count[0], probes->irradiance_resolution * probes->probe_count[1], 3, 1);
    r->tex[MDH_TEX_RADIANCE].flush_nan = r->tex[MDH_TEX_IRRADIANCE].flush_nan = 1;
@@ -1339,6 +1340,7 @@ int32_t orc_set_option(orc_renderer *r, int32_t option, int32_t value)
    case MDH_OPT_ADA_EVAL_DIV: r->opt_ada_div = value; break;
    case MDH_OPT_FRAME_OVERLAP: break; /* scheduling only: nothing to restate */
    case MDH_OPT_JIT: break;           /* how the kernels run the MDH_X programs: nothing to restate */
+   case MDH_OPT_IRRADIANCE_ALL: r->opt_irr_all = value ? 1 : 0; break;
    case ORC_OPT_SDF_MODE: r->opt_sdf_mode = value; break;
    case ORC_OPT_THREADS: r->opt_threads = value; break;
    default: return seterr(MDH_E_INVALID, "unknown option");
@@ -1359,6 +1361,7 @@ int32_t orc_get_option(orc_renderer *r, int32_t option, int32_t *value)
    case MDH_OPT_ADA_EVAL_DIV: *value = r->opt_ada_div; break;
    case MDH_OPT_FRAME_OVERLAP: *value = 0; break;
    case MDH_OPT_JIT: *value = 0; break;
+   case MDH_OPT_IRRADIANCE_ALL: *value = r->opt_irr_all; break;
    case ORC_OPT_SDF_MODE: *value = r->opt_sdf_mode; break;
    case ORC_OPT_THREADS: *value = nthreads(r); break;
    default: return seterr(MDH_E_INVALID, "unknown option");

@@ -99,7 +99,8 @@ def test_sharded_frame_equals_whole_frame(hip):
     assert same_bits(Rs[1].Read_Texture(B.TEX_RADIANCE), whole["radiance"])
 
 
-def test_sharded_frames_in_flight_equal_whole_frames(hip):
+@pytest.mark.parametrize("irr_all", [1, 0])
+def test_sharded_frames_in_flight_equal_whole_frames(hip, irr_all):
     """The same two ranks through the three-step frame (Frame_Begin / Frame_Probe_Pass / Frame_End) that
     madarch_amd.sharding drives: frames stay in flight (two atlas sets, three streams per renderer) while
     the slices are exchanged inside the open frame."""
@@ -115,6 +116,7 @@ def test_sharded_frames_in_flight_equal_whole_frames(hip):
         R.Set_Option(B.OPT_GBUFFER, 0)
         R.Set_Option(B.OPT_RANK, r)
         R.Set_Option(B.OPT_WORLD, 2)
+        R.Set_Option(B.OPT_IRRADIANCE_ALL, irr_all)
     P = Rs[0].Probe_Total()
     for _ in range(frames):
         for R in Rs:
@@ -122,6 +124,8 @@ def test_sharded_frames_in_flight_equal_whole_frames(hip):
         for p, tex in ((B.PASS_RADIANCE, B.TEX_RADIANCE), (B.PASS_IRRADIANCE, B.TEX_IRRADIANCE)):
             for R in Rs:
                 R.Frame_Probe_Pass(p)
+            if tex == B.TEX_IRRADIANCE and irr_all:
+                continue  # every rank updated every probe: nothing to exchange
             lo = Rs[0].Read_Atlas_Slice(tex, 0, P // 2)
             hi = Rs[1].Read_Atlas_Slice(tex, P // 2, P - P // 2)
             Rs[0].Write_Atlas_Slice(tex, P // 2, hi)

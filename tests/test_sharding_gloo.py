@@ -10,7 +10,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, scene, out_dir):
+def _worker(rank, world, port, scene, irr_all, out_dir):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch.distributed as dist
@@ -21,6 +21,7 @@ def _worker(rank, world, port, scene, out_dir):
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     R = make(scene, 56, 40, oracle_binding(), probes=SMALL_PROBES)
     R.Set_Option(ORC_OPT_THREADS, 2)
+    R.Set_Option(B.OPT_IRRADIANCE_ALL, irr_all)  # 1: every rank updates all probes, one exchange per frame; 0: two
     frame = sharding.ShardedFrame(R, rank, world, sharding.HostExchange(dist))
     for _ in range(2):
         frame.Render()
@@ -32,12 +33,12 @@ def _worker(rank, world, port, scene, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("scene", ["global_illumination", "light_shafts"])
-def test_two_ranks_equal_one(orc, tmp_path, scene):
+@pytest.mark.parametrize("scene,irr_all", [("global_illumination", 1), ("global_illumination", 0), ("light_shafts", 1)])
+def test_two_ranks_equal_one(orc, tmp_path, scene, irr_all):
     import torch.multiprocessing as mp
     from helpers import SMALL_PROBES, make, same_bits, snapshot
     port = 29500 + (os.getpid() % 2000)
-    mp.spawn(_worker, args=(2, port, scene, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, scene, irr_all, str(tmp_path)), nprocs=2, join=True)
     want = snapshot(make(scene, 56, 40, orc, probes=SMALL_PROBES), 2)
     with np.load(os.path.join(str(tmp_path), "sharded.npz")) as got:
         for k in ("image", "radiance", "irradiance"):
