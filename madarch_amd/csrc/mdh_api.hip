@@ -195,6 +195,7 @@ struct mdh_renderer {
    // an open frame (mdh_frame_begin .. mdh_frame_end)
    bool in_frame = false, frame_pipelined = false;
    int frame_cur = 0;
+   int scr_parity = 0; // which screen stream / framebuffer the last pipelined frame drew on
    bool main_dirty = true; // work went to `stream` outside a pipelined frame since the probe stream last joined it
    float *d_vis = nullptr;
    float4 *d_scat = nullptr;
@@ -1147,20 +1148,21 @@ extern "C" int32_t mdh_frame_begin(mdh_renderer *r)
    if (r->in_frame) return seterr(MDH_E_STATE, "a frame is already open");
    int rc = ensure_committed(r);
    if (rc != MDH_OK) return rc;
-   r->frame_pipelined = r->opt_overlap && r->opt_mode == 0 && r->stream == r->own_stream;
+   r->frame_pipelined = r->opt_overlap && r->stream == r->own_stream; // (modes 1 and 2 have no probe passes: their screen passes still alternate streams)
    if (!r->frame_pipelined) {
       if ((rc = join_main(r)) != MDH_OK) return rc;
       r->main_dirty = true;
       r->frame_cur = r->last;
    } else {
-      const int cur = r->last ^ 1;
+      // modes 1 and 2 run no probe passes: the atlas sets stay as they are (their screen passes still alternate)
+      const int cur = r->opt_mode == 0 ? r->last ^ 1 : r->last;
       if (r->main_dirty) { // the other streams have to see everything that went to the main stream meanwhile
          if ((rc = join_main(r)) != MDH_OK) return rc;
          HIP_TRY(hipEventRecord(r->ev_join, r->stream));
          HIP_TRY(hipStreamWaitEvent(r->probe_stream, r->ev_join, 0));
          HIP_TRY(hipStreamWaitEvent(r->alt_stream, r->ev_join, 0));
          r->main_dirty = false;
-      } else if (r->ev_screen_valid[cur]) {
+      } else if (r->opt_mode == 0 && r->ev_screen_valid[cur]) { // the last screen pass that read atlas set cur
          HIP_TRY(hipStreamWaitEvent(r->probe_stream, r->ev_screen[cur], 0));
       }
       r->frame_cur = cur;
@@ -1193,8 +1195,11 @@ extern "C" int32_t mdh_frame_end(mdh_renderer *r)
    const bool dual = r->opt_overlap > 1 && !r->vol.enabled && !r->opt_gbuffer;
    // single-buffered targets: a screen pass on the main stream after one on the alternate stream
    if (!dual && r->alt_pending && (rc = join_main(r)) != MDH_OK) return rc;
-   hipStream_t screen_stream = (dual && cur) ? r->alt_stream : r->stream;
-   const int fbix = dual ? cur : r->fb_last;
+   // framebuffer 1 is only ever written from the alternate stream and framebuffer 0 from the main stream, so
+   // each buffer's writes are ordered by its stream; frames that cannot alternate draw on (main, 0)
+   r->scr_parity = dual ? r->scr_parity ^ 1 : 0;
+   hipStream_t screen_stream = r->scr_parity ? r->alt_stream : r->stream;
+   const int fbix = r->scr_parity;
    HIP_TRY(hipEventRecord(r->ev_probe[cur], r->probe_stream));
    HIP_TRY(hipStreamWaitEvent(screen_stream, r->ev_probe[cur], 0));
    if (r->vol.enabled) { // (never dual)
@@ -1225,7 +1230,7 @@ extern "C" int32_t mdh_probe_stream(mdh_renderer *r, void **stream)
 {
    if (!r || !stream) return seterr(MDH_E_INVALID, "bad argument");
    if (r->in_frame) *stream = (void *)frame_probe_stream(r);
-   else *stream = (void *)((r->opt_overlap && r->opt_mode == 0 && r->stream == r->own_stream) ? r->probe_stream : r->stream);
+   else *stream = (void *)((r->opt_overlap && r->stream == r->own_stream) ? r->probe_stream : r->stream);
    return MDH_OK;
 }
 extern "C" int32_t mdh_finish(mdh_renderer *r)

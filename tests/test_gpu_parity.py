@@ -178,6 +178,29 @@ def test_pipelined_frames_equal_serial_frames(hip, overlap, gbuffer, scene):
         assert same_bits(a, b), "output %d differs between the serial and the pipelined schedule" % i
 
 
+@pytest.mark.gpu
+def test_pipelined_frames_across_screen_modes(hip):
+    """Frames of modes 1 and 2 run no probe passes: pipelined, they must leave the atlas sets alone (and still
+    alternate the screen streams), so that what mode 0 reads afterwards is what the serial schedule reads."""
+    def drive(level):
+        R = make("global_illumination", 160, 96, hip, probes=SMALL_PROBES)
+        R.Set_Option(B.OPT_GBUFFER, 0)
+        R.Set_Option(B.OPT_FRAME_OVERLAP, level)
+        seen = []
+        for mode, frames in ((0, 3), (2, 3), (0, 2), (1, 1), (0, 1), (2, 2)):
+            R.Set_Option(B.OPT_SCREEN_MODE, mode)
+            for f in range(frames):
+                R.Set_Camera_Position((2.0 + 0.1 * f, 2.0, 0.05 * mode))
+                R.Render()
+            seen += [R.Read_Framebuffer(), R.Read_Texture(B.TEX_IRRADIANCE), R.Read_Texture(B.TEX_RADIANCE)]
+        return seen
+
+    serial = drive(0)
+    for level in (1, 2):
+        for i, (a, b) in enumerate(zip(serial, drive(level))):
+            assert same_bits(a, b), "output %d differs at overlap level %d" % (i, level)
+
+
 # ---------------------------------------------------------------- BASELINE.json's full size
 @pytest.fixture(scope="module")
 def full_size(hip):
