@@ -197,8 +197,10 @@ struct mdh_renderer {
    int frame_cur = 0;
    int scr_parity = 0; // which screen stream / framebuffer the last pipelined frame drew on
    bool main_dirty = true; // work went to `stream` outside a pipelined frame since the probe stream last joined it
-   float *d_vis = nullptr;
-   float4 *d_scat = nullptr;
+   // froxel and scattering textures, one per atlas set: the volumetric passes of a pipelined frame run on the
+   // probe stream into the set that frame produces
+   float *d_vis2[2] = {nullptr, nullptr};
+   float4 *d_scat2[2] = {nullptr, nullptr};
    float4 *d_fb2[2] = {nullptr, nullptr}; // two framebuffers: consecutive pipelined frames draw on two streams
    int fb_last = 0;                       // the one the most recent frame drew
    // (rank, world) whose tiles are the only non-zero pixels of a framebuffer; {0, 1}: every pixel may be set
@@ -469,14 +471,14 @@ static KCamera make_camera(const mdh_renderer *r)
    memcpy(c.m, r->cam_m, sizeof c.m);
    return c;
 }
-static KVolumetrics make_vol(const mdh_renderer *r, bool enabled)
+static KVolumetrics make_vol(const mdh_renderer *r, bool enabled, int set)
 {
    KVolumetrics v;
    v.enabled = enabled ? 1 : 0;
    v.vw = r->vol.visibility_resolution[0]; v.vh = r->vol.visibility_resolution[1]; v.vz = r->vol.visibility_resolution[2];
    v.sw = r->vol.scattering_resolution[0]; v.sh = r->vol.scattering_resolution[1];
    v.vstep = r->vstep; v.sstep = r->sstep;
-   v.vis = r->d_vis; v.scat = r->d_scat;
+   v.vis = r->d_vis2[set]; v.scat = r->d_scat2[set];
    return v;
 }
 
@@ -503,7 +505,7 @@ extern "C" int32_t mdh_destroy(mdh_renderer *r)
    if (r->probe_stream) (void)hipStreamSynchronize(r->probe_stream);
    if (r->alt_stream) (void)hipStreamSynchronize(r->alt_stream);
    if (r->stream) (void)hipStreamSynchronize(r->stream);
-   void *ptrs[] = {r->d_table, r->d_part, r->d_warn, r->d_rad2[0], r->d_irr2[0], r->d_rad2[1], r->d_irr2[1], r->d_vis, r->d_scat, r->d_fb2[0], r->d_fb2[1], r->d_gb_index, r->d_gb_steps, r->d_gb_t};
+   void *ptrs[] = {r->d_table, r->d_part, r->d_warn, r->d_rad2[0], r->d_irr2[0], r->d_rad2[1], r->d_irr2[1], r->d_vis2[0], r->d_scat2[0], r->d_vis2[1], r->d_scat2[1], r->d_fb2[0], r->d_fb2[1], r->d_gb_index, r->d_gb_steps, r->d_gb_t};
    for (void *p : ptrs)
       if (p) (void)hipFree(p);
    for (auto &p : r->pending) { (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1); }
@@ -607,10 +609,12 @@ extern "C" int32_t mdh_create(int32_t width, int32_t height, const mdh_scene_des
    TRY_OR_FAIL(hipMalloc(&r->d_warn, 4));
    size_t vis_n = (size_t)vol->visibility_resolution[0] * vol->visibility_resolution[1] * vol->visibility_resolution[2] * 3;
    size_t scat_n = (size_t)vol->scattering_resolution[0] * vol->scattering_resolution[1];
-   TRY_OR_FAIL(hipMalloc(&r->d_vis, (vis_n ? vis_n : 1) * 4));
-   TRY_OR_FAIL(hipMemsetAsync(r->d_vis, 0, (vis_n ? vis_n : 1) * 4, r->stream));
-   TRY_OR_FAIL(hipMalloc(&r->d_scat, (scat_n ? scat_n : 1) * sizeof(float4)));
-   TRY_OR_FAIL(hipMemsetAsync(r->d_scat, 0, (scat_n ? scat_n : 1) * sizeof(float4), r->stream));
+   for (int s = 0; s < 2; ++s) {
+      TRY_OR_FAIL(hipMalloc(&r->d_vis2[s], (vis_n ? vis_n : 1) * 4));
+      TRY_OR_FAIL(hipMemsetAsync(r->d_vis2[s], 0, (vis_n ? vis_n : 1) * 4, r->stream));
+      TRY_OR_FAIL(hipMalloc(&r->d_scat2[s], (scat_n ? scat_n : 1) * sizeof(float4)));
+      TRY_OR_FAIL(hipMemsetAsync(r->d_scat2[s], 0, (scat_n ? scat_n : 1) * sizeof(float4), r->stream));
+   }
    if (r->part.enable) {
       size_t n = (size_t)r->part_cells * (r->npk + r->part.index_count);
       TRY_OR_FAIL(hipMalloc(&r->d_part, n * 4));
@@ -1042,7 +1046,7 @@ static int run_pass(mdh_renderer *r, int pass, hipStream_t st, int src, int dst,
       break;
    }
    case MDH_PASS_VISIBILITY: {
-      KVolumetrics vol = make_vol(r, true);
+      KVolumetrics vol = make_vol(r, true, dst);
       long n = (long)vol.vw * vol.vh * vol.vz;
       if (n > 0) {
          int blocks = (int)((n + MDH_BLOCK - 1) / MDH_BLOCK);
@@ -1056,7 +1060,7 @@ static int run_pass(mdh_renderer *r, int pass, hipStream_t st, int src, int dst,
       break;
    }
    case MDH_PASS_SCATTERING: {
-      KVolumetrics vol = make_vol(r, true);
+      KVolumetrics vol = make_vol(r, true, dst);
       long n = (long)vol.sw * vol.sh;
       if (n > 0) {
          int blocks = (int)((n + MDH_BLOCK - 1) / MDH_BLOCK);
@@ -1070,7 +1074,7 @@ static int run_pass(mdh_renderer *r, int pass, hipStream_t st, int src, int dst,
       break;
    }
    case MDH_PASS_SCREEN: {
-      KVolumetrics vol = make_vol(r, r->vol.enabled != 0 && r->opt_mode == 0);
+      KVolumetrics vol = make_vol(r, r->vol.enabled != 0 && r->opt_mode == 0, dst);
       ScreenArgs a;
       a.W = r->W; a.H = r->H;
       a.tiles_x = (r->W + 7) / 8;
@@ -1192,7 +1196,7 @@ extern "C" int32_t mdh_frame_end(mdh_renderer *r)
       }
       return run_pass(r, MDH_PASS_SCREEN, r->stream, cur, cur);
    }
-   const bool dual = r->opt_overlap > 1 && !r->vol.enabled && !r->opt_gbuffer;
+   const bool dual = r->opt_overlap > 1 && !r->opt_gbuffer;
    // single-buffered targets: a screen pass on the main stream after one on the alternate stream
    if (!dual && r->alt_pending && (rc = join_main(r)) != MDH_OK) return rc;
    // framebuffer 1 is only ever written from the alternate stream and framebuffer 0 from the main stream, so
@@ -1200,12 +1204,12 @@ extern "C" int32_t mdh_frame_end(mdh_renderer *r)
    r->scr_parity = dual ? r->scr_parity ^ 1 : 0;
    hipStream_t screen_stream = r->scr_parity ? r->alt_stream : r->stream;
    const int fbix = r->scr_parity;
+   if (r->opt_mode == 0 && r->vol.enabled) { // camera-only passes into this frame's set, beside the previous screen pass
+      if ((rc = run_pass(r, MDH_PASS_VISIBILITY, r->probe_stream, cur, cur)) != MDH_OK) return rc;
+      if ((rc = run_pass(r, MDH_PASS_SCATTERING, r->probe_stream, cur, cur)) != MDH_OK) return rc;
+   }
    HIP_TRY(hipEventRecord(r->ev_probe[cur], r->probe_stream));
    HIP_TRY(hipStreamWaitEvent(screen_stream, r->ev_probe[cur], 0));
-   if (r->vol.enabled) { // (never dual)
-      if ((rc = run_pass(r, MDH_PASS_VISIBILITY, screen_stream, cur, cur)) != MDH_OK) return rc;
-      if ((rc = run_pass(r, MDH_PASS_SCATTERING, screen_stream, cur, cur)) != MDH_OK) return rc;
-   }
    if ((rc = run_pass(r, MDH_PASS_SCREEN, screen_stream, cur, cur, fbix)) != MDH_OK) return rc;
    HIP_TRY(hipEventRecord(r->ev_screen[cur], screen_stream));
    r->ev_screen_valid[cur] = true;
@@ -1353,10 +1357,10 @@ extern "C" int32_t mdh_read_texture(mdh_renderer *r, int32_t tex, float *out, in
       }
    } else if (tex == MDH_TEX_VISIBILITY) {
       W = r->vol.visibility_resolution[0]; H = r->vol.visibility_resolution[1] * r->vol.visibility_resolution[2]; C = 3;
-      if (out) { HIP_TRY(hipMemcpyAsync(out, r->d_vis, (size_t)W * H * 12, hipMemcpyDeviceToHost, r->stream)); HIP_TRY(hipStreamSynchronize(r->stream)); }
+      if (out) { HIP_TRY(hipMemcpyAsync(out, r->d_vis2[atlas_set(r)], (size_t)W * H * 12, hipMemcpyDeviceToHost, r->stream)); HIP_TRY(hipStreamSynchronize(r->stream)); }
    } else {
       W = r->vol.scattering_resolution[0]; H = r->vol.scattering_resolution[1]; C = 4;
-      if (out) { HIP_TRY(hipMemcpyAsync(out, r->d_scat, (size_t)W * H * 16, hipMemcpyDeviceToHost, r->stream)); HIP_TRY(hipStreamSynchronize(r->stream)); }
+      if (out) { HIP_TRY(hipMemcpyAsync(out, r->d_scat2[atlas_set(r)], (size_t)W * H * 16, hipMemcpyDeviceToHost, r->stream)); HIP_TRY(hipStreamSynchronize(r->stream)); }
    }
    if (w) *w = W;
    if (h) *h = H;
@@ -1385,7 +1389,7 @@ extern "C" int32_t mdh_write_texture(mdh_renderer *r, int32_t tex, const float *
          }
       return atlas_from_host(r, tex, 0, (size_t)W * H, rgb.data());
    }
-   void *dst = tex == MDH_TEX_VISIBILITY ? (void *)r->d_vis : (void *)r->d_scat;
+   void *dst = tex == MDH_TEX_VISIBILITY ? (void *)r->d_vis2[atlas_set(r)] : (void *)r->d_scat2[atlas_set(r)];
    HIP_TRY(hipMemcpyAsync(dst, in, (size_t)W * H * C * 4, hipMemcpyHostToDevice, r->stream));
    HIP_TRY(hipStreamSynchronize(r->stream));
    return MDH_OK;
