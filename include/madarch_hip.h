@@ -197,7 +197,7 @@ enum {
     *   1 = the probe passes of a frame overlap the screen pass of the frame before
     *       it (second HIP stream, two atlas sets);
     *   2 (default) = also the screen passes of consecutive frames overlap (third
-    *       stream, two framebuffers; falls back to 1 while the geometry buffer is on).
+    *       stream, two framebuffers).
     * Sharded renderers and renderers on a caller-supplied stream run serially. */
    MDH_OPT_FRAME_OVERLAP = 8,
    /* user-defined kinds: 1 (default) = the MDH_X programs are compiled into the

@@ -205,8 +205,8 @@ struct mdh_renderer {
    int fb_last = 0;                       // the one the most recent frame drew
    // (rank, world) whose tiles are the only non-zero pixels of a framebuffer; {0, 1}: every pixel may be set
    int fb_owner[2][2] = {{-1, -1}, {-1, -1}};
-   int *d_gb_index = nullptr, *d_gb_steps = nullptr;
-   float *d_gb_t = nullptr;
+   // geometry buffer: [which framebuffer] x {index, t, steps} (int32 / float / int32 per pixel)
+   void *d_gb2[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
    KScene ks{};
    // timing: event pairs recorded around every pass, resolved lazily (no host sync per pass)
    struct Pending { int pass; hipEvent_t e0, e1; };
@@ -505,7 +505,7 @@ extern "C" int32_t mdh_destroy(mdh_renderer *r)
    if (r->probe_stream) (void)hipStreamSynchronize(r->probe_stream);
    if (r->alt_stream) (void)hipStreamSynchronize(r->alt_stream);
    if (r->stream) (void)hipStreamSynchronize(r->stream);
-   void *ptrs[] = {r->d_table, r->d_part, r->d_warn, r->d_rad2[0], r->d_irr2[0], r->d_rad2[1], r->d_irr2[1], r->d_vis2[0], r->d_scat2[0], r->d_vis2[1], r->d_scat2[1], r->d_fb2[0], r->d_fb2[1], r->d_gb_index, r->d_gb_steps, r->d_gb_t};
+   void *ptrs[] = {r->d_table, r->d_part, r->d_warn, r->d_rad2[0], r->d_irr2[0], r->d_rad2[1], r->d_irr2[1], r->d_vis2[0], r->d_scat2[0], r->d_vis2[1], r->d_scat2[1], r->d_fb2[0], r->d_fb2[1], r->d_gb2[0][0], r->d_gb2[0][1], r->d_gb2[0][2], r->d_gb2[1][0], r->d_gb2[1][1], r->d_gb2[1][2]};
    for (void *p : ptrs)
       if (p) (void)hipFree(p);
    for (auto &p : r->pending) { (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1); }
@@ -603,9 +603,8 @@ extern "C" int32_t mdh_create(int32_t width, int32_t height, const mdh_scene_des
       TRY_OR_FAIL(hipMalloc(&r->d_fb2[s], px * sizeof(float4)));
       TRY_OR_FAIL(hipMemsetAsync(r->d_fb2[s], 0, px * sizeof(float4), r->stream));
    }
-   TRY_OR_FAIL(hipMalloc(&r->d_gb_index, px * 4));
-   TRY_OR_FAIL(hipMalloc(&r->d_gb_steps, px * 4));
-   TRY_OR_FAIL(hipMalloc(&r->d_gb_t, px * 4));
+   for (int s = 0; s < 2; ++s)
+      for (int q = 0; q < 3; ++q) TRY_OR_FAIL(hipMalloc(&r->d_gb2[s][q], px * 4));
    TRY_OR_FAIL(hipMalloc(&r->d_warn, 4));
    size_t vis_n = (size_t)vol->visibility_resolution[0] * vol->visibility_resolution[1] * vol->visibility_resolution[2] * 3;
    size_t scat_n = (size_t)vol->scattering_resolution[0] * vol->scattering_resolution[1];
@@ -1081,7 +1080,7 @@ static int run_pass(mdh_renderer *r, int pass, hipStream_t st, int src, int dst,
       a.n_tiles = a.tiles_x * ((r->H + 7) / 8);
       a.rank = r->opt_rank; a.world = r->opt_world;
       a.ao_steps = r->opt_ao;
-      a.fb = r->d_fb2[fbix]; a.gb_index = r->d_gb_index; a.gb_t = r->d_gb_t; a.gb_steps = r->d_gb_steps;
+      a.fb = r->d_fb2[fbix]; a.gb_index = (int *)r->d_gb2[fbix][0]; a.gb_t = (float *)r->d_gb2[fbix][1]; a.gb_steps = (int *)r->d_gb2[fbix][2];
       // other ranks' tiles read 0: cleared when the buffer last held another rank's (or a whole) frame, not every frame
       if (a.world > 1 && (r->fb_owner[fbix][0] != a.rank || r->fb_owner[fbix][1] != a.world))
          HIP_TRY(hipMemsetAsync(r->d_fb2[fbix], 0, (size_t)r->W * r->H * sizeof(float4), st));
@@ -1196,8 +1195,8 @@ extern "C" int32_t mdh_frame_end(mdh_renderer *r)
       }
       return run_pass(r, MDH_PASS_SCREEN, r->stream, cur, cur);
    }
-   const bool dual = r->opt_overlap > 1 && !r->opt_gbuffer;
-   // single-buffered targets: a screen pass on the main stream after one on the alternate stream
+   const bool dual = r->opt_overlap > 1;
+   // (level 1: all screen passes on the main stream, after whatever the alternate stream still holds)
    if (!dual && r->alt_pending && (rc = join_main(r)) != MDH_OK) return rc;
    // framebuffer 1 is only ever written from the alternate stream and framebuffer 0 from the main stream, so
    // each buffer's writes are ordered by its stream; frames that cannot alternate draw on (main, 0)
@@ -1264,9 +1263,9 @@ extern "C" int32_t mdh_read_gbuffer(mdh_renderer *r, int32_t *index_out, float *
    HIP_TRY(hipSetDevice(r->device));
    size_t n = (size_t)r->W * r->H * 4;
    { int jr = join_main(r); if (jr != MDH_OK) return jr; }
-   if (index_out) HIP_TRY(hipMemcpyAsync(index_out, r->d_gb_index, n, hipMemcpyDeviceToHost, r->stream));
-   if (t_out) HIP_TRY(hipMemcpyAsync(t_out, r->d_gb_t, n, hipMemcpyDeviceToHost, r->stream));
-   if (steps_out) HIP_TRY(hipMemcpyAsync(steps_out, r->d_gb_steps, n, hipMemcpyDeviceToHost, r->stream));
+   if (index_out) HIP_TRY(hipMemcpyAsync(index_out, r->d_gb2[r->fb_last][0], n, hipMemcpyDeviceToHost, r->stream));
+   if (t_out) HIP_TRY(hipMemcpyAsync(t_out, r->d_gb2[r->fb_last][1], n, hipMemcpyDeviceToHost, r->stream));
+   if (steps_out) HIP_TRY(hipMemcpyAsync(steps_out, r->d_gb2[r->fb_last][2], n, hipMemcpyDeviceToHost, r->stream));
    HIP_TRY(hipStreamSynchronize(r->stream));
    return MDH_OK;
 }
