@@ -38,6 +38,9 @@
 #ifndef MDH_SCAT_BATCH
 #define MDH_SCAT_BATCH 8 // scattering steps whose froxel taps are in flight together
 #endif
+#ifndef MDH_RELOAD_ARGS
+#define MDH_RELOAD_ARGS 1
+#endif
 #ifndef MDH_WAVES_PER_SIMD
 #define MDH_WAVES_PER_SIMD 5 // register budget of the march kernels (measured, pipelined frames: 5 > 6 > 4 waves/SIMD)
 #endif
@@ -82,6 +85,18 @@ __global__ __launch_bounds__(MDH_BLOCK, MDH_OCC(PART)) void k_screen(KScene sc, 
    if (!valid) { PH_KERNEL_END(); return; }
 #endif
    if (!valid) return;
+#if MDH_RELOAD_ARGS
+   // The arguments only the epilogue needs (volumetrics, the framebuffer) are read again from the kernel
+   // argument segment here, through a pointer the compiler cannot trace back: it then does not keep ~20
+   // scalar registers of them alive (or spilled to vector lanes) across the whole pixel program.
+   struct KArgs { KScene sc; KProbes pr; KVolumetrics vol; KCamera cam; ScreenArgs a; };
+   const KArgs *ka = (const KArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+   asm volatile("" : "+s"(ka));
+   const KVolumetrics vol2 = ka->vol;
+   const ScreenArgs a2 = ka->a;
+#define vol vol2
+#define a a2
+#endif
    if (MODE == 0 && vol.enabled) c = render_volumetrics(sc, vol, c, origin, pos, hit, F2(u, v));
    if (MODE != 1) // draw_screen.glsl:29
       c = F3(pow_(c.x / (c.x + 1.0f), 0.4545f), pow_(c.y / (c.y + 1.0f), 0.4545f), pow_(c.z / (c.z + 1.0f), 0.4545f));
@@ -92,6 +107,10 @@ __global__ __launch_bounds__(MDH_BLOCK, MDH_OCC(PART)) void k_screen(KScene sc, 
       a.gb_t[px] = ph.t;
       a.gb_steps[px] = ph.steps;
    }
+#if MDH_RELOAD_ARGS
+#undef vol
+#undef a
+#endif
    PH_KERNEL_END();
 }
 
