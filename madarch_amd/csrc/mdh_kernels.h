@@ -90,10 +90,20 @@ __global__ __launch_bounds__(MDH_BLOCK, MDH_OCC(PART)) void k_screen(KScene sc, 
    // argument segment here, through a pointer the compiler cannot trace back: it then does not keep ~20
    // scalar registers of them alive (or spilled to vector lanes) across the whole pixel program.
    struct KArgs { KScene sc; KProbes pr; KVolumetrics vol; KCamera cam; ScreenArgs a; };
-   const KArgs *ka = (const KArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+   typedef const KArgs __attribute__((address_space(4))) *KArgsPtr; // constant address space: scalar loads
+   KArgsPtr ka = (KArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
    asm volatile("" : "+s"(ka));
-   const KVolumetrics vol2 = ka->vol;
-   const ScreenArgs a2 = ka->a;
+   KVolumetrics vol2;
+   ScreenArgs a2;
+   {
+      typedef const int __attribute__((address_space(4))) *IntPtr;
+      IntPtr pv = (IntPtr)&ka->vol, pa = (IntPtr)&ka->a;
+      int *dv = (int *)&vol2, *da = (int *)&a2;
+#pragma unroll
+      for (int q = 0; q < (int)(sizeof(KVolumetrics) / 4); ++q) dv[q] = pv[q];
+#pragma unroll
+      for (int q = 0; q < (int)(sizeof(ScreenArgs) / 4); ++q) da[q] = pa[q];
+   }
 #define vol vol2
 #define a a2
 #endif
