@@ -9,7 +9,8 @@
 #include "mdh_kernels.h"
 #include "mdh_jit_sources.inc" // the three device headers as string literals (Makefile), for the hiprtc build of user-defined kinds
 
-#include <hip/hiprtc.h>
+#include <dlfcn.h>
+#include <hip/hiprtc.h> // types only: the library is opened on first use (no link-time dependency)
 
 #include <cmath>
 #include <cstdio>
@@ -865,6 +866,42 @@ static std::string jit_kinds_header(const mdh_renderer *r)
    return s;
 }
 
+// hiprtc is loaded when the first user-defined kind is compiled; a box without it falls back to the interpreter
+struct HiprtcApi {
+   decltype(&hiprtcCreateProgram) CreateProgram = nullptr;
+   decltype(&hiprtcDestroyProgram) DestroyProgram = nullptr;
+   decltype(&hiprtcAddNameExpression) AddNameExpression = nullptr;
+   decltype(&hiprtcCompileProgram) CompileProgram = nullptr;
+   decltype(&hiprtcGetCodeSize) GetCodeSize = nullptr;
+   decltype(&hiprtcGetCode) GetCode = nullptr;
+   decltype(&hiprtcGetLoweredName) GetLoweredName = nullptr;
+   decltype(&hiprtcGetProgramLogSize) GetProgramLogSize = nullptr;
+   decltype(&hiprtcGetProgramLog) GetProgramLog = nullptr;
+   decltype(&hiprtcGetErrorString) GetErrorString = nullptr;
+   bool ok = false;
+};
+static const HiprtcApi &hiprtc_api()
+{
+   static HiprtcApi api;
+   static bool tried = false;
+   if (tried) return api;
+   tried = true;
+   void *h = nullptr;
+   for (const char *name : {"libhiprtc.so", "libhiprtc.so.7", "/opt/rocm/lib/libhiprtc.so"})
+      if ((h = dlopen(name, RTLD_NOW | RTLD_LOCAL))) break;
+   if (!h) return api;
+#define MDH_RTC_SYM(field, sym) api.field = (decltype(api.field))dlsym(h, #sym)
+   MDH_RTC_SYM(CreateProgram, hiprtcCreateProgram); MDH_RTC_SYM(DestroyProgram, hiprtcDestroyProgram);
+   MDH_RTC_SYM(AddNameExpression, hiprtcAddNameExpression); MDH_RTC_SYM(CompileProgram, hiprtcCompileProgram);
+   MDH_RTC_SYM(GetCodeSize, hiprtcGetCodeSize); MDH_RTC_SYM(GetCode, hiprtcGetCode); MDH_RTC_SYM(GetLoweredName, hiprtcGetLoweredName);
+   MDH_RTC_SYM(GetProgramLogSize, hiprtcGetProgramLogSize); MDH_RTC_SYM(GetProgramLog, hiprtcGetProgramLog);
+   MDH_RTC_SYM(GetErrorString, hiprtcGetErrorString);
+#undef MDH_RTC_SYM
+   api.ok = api.CreateProgram && api.DestroyProgram && api.AddNameExpression && api.CompileProgram && api.GetCodeSize && api.GetCode &&
+            api.GetLoweredName && api.GetProgramLogSize && api.GetProgramLog && api.GetErrorString;
+   return api;
+}
+
 struct JitModule {
    hipModule_t mod = nullptr;
    std::map<std::string, hipFunction_t> fn;
@@ -875,6 +912,8 @@ static std::map<std::string, JitModule *> g_jit_cache;
 // Compile the kernels named by `exprs` (template-ids) around this scene's mdh_jit_kinds.h.
 static JitModule *jit_module(mdh_renderer *r, const std::vector<std::string> &exprs)
 {
+   const HiprtcApi &rtc = hiprtc_api();
+   if (!rtc.ok) { seterr(MDH_E_DEVICE, "libhiprtc.so cannot be loaded: user-defined kinds are interpreted"); return nullptr; }
    if (r->jit_kinds.empty()) r->jit_kinds = jit_kinds_header(r);
    std::string key = r->jit_kinds;
    for (auto &e : exprs) key += "|" + e;
@@ -887,33 +926,33 @@ static JitModule *jit_module(mdh_renderer *r, const std::vector<std::string> &ex
    auto fail = [&](const char *what, hiprtcResult e) -> JitModule * {
       std::string log;
       size_t n = 0;
-      if (prog && hiprtcGetProgramLogSize(prog, &n) == HIPRTC_SUCCESS && n > 1) { log.resize(n); hiprtcGetProgramLog(prog, &log[0]); }
-      snprintf(g_err, sizeof g_err, "hiprtc %s failed (%s): %.380s", what, hiprtcGetErrorString(e), log.c_str());
-      if (prog) hiprtcDestroyProgram(&prog);
+      if (prog && rtc.GetProgramLogSize(prog, &n) == HIPRTC_SUCCESS && n > 1) { log.resize(n); rtc.GetProgramLog(prog, &log[0]); }
+      snprintf(g_err, sizeof g_err, "hiprtc %s failed (%s): %.380s", what, rtc.GetErrorString(e), log.c_str());
+      if (prog) rtc.DestroyProgram(&prog);
       return nullptr;
    };
-   hiprtcResult e = hiprtcCreateProgram(&prog, "#define MDH_JIT 1\n#include \"mdh_kernels.h\"\n", "mdh_jit.hip", 4, headers, names);
+   hiprtcResult e = rtc.CreateProgram(&prog, "#define MDH_JIT 1\n#include \"mdh_kernels.h\"\n", "mdh_jit.hip", 4, headers, names);
    if (e != HIPRTC_SUCCESS) return fail("create", e);
    for (auto &x : exprs)
-      if ((e = hiprtcAddNameExpression(prog, x.c_str())) != HIPRTC_SUCCESS) return fail("name expression", e);
+      if ((e = rtc.AddNameExpression(prog, x.c_str())) != HIPRTC_SUCCESS) return fail("name expression", e);
    // the flags of the Makefile: one IEEE operation per source operation, no vectorizers
    const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
                          "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-gpu-flush-denormals-to-zero", "-fno-vectorize", "-fno-slp-vectorize"};
-   if ((e = hiprtcCompileProgram(prog, (int)(sizeof opts / sizeof opts[0]), opts)) != HIPRTC_SUCCESS) return fail("compile", e);
+   if ((e = rtc.CompileProgram(prog, (int)(sizeof opts / sizeof opts[0]), opts)) != HIPRTC_SUCCESS) return fail("compile", e);
    size_t size = 0;
-   if ((e = hiprtcGetCodeSize(prog, &size)) != HIPRTC_SUCCESS) return fail("code size", e);
+   if ((e = rtc.GetCodeSize(prog, &size)) != HIPRTC_SUCCESS) return fail("code size", e);
    std::vector<char> code(size);
-   if ((e = hiprtcGetCode(prog, code.data())) != HIPRTC_SUCCESS) return fail("code", e);
+   if ((e = rtc.GetCode(prog, code.data())) != HIPRTC_SUCCESS) return fail("code", e);
    JitModule *m = new JitModule();
    if (hipModuleLoadData(&m->mod, code.data()) != hipSuccess) { delete m; return fail("module load", HIPRTC_ERROR_INTERNAL_ERROR); }
    for (auto &x : exprs) {
       const char *lowered = nullptr;
-      if ((e = hiprtcGetLoweredName(prog, x.c_str(), &lowered)) != HIPRTC_SUCCESS) { delete m; return fail("lowered name", e); }
+      if ((e = rtc.GetLoweredName(prog, x.c_str(), &lowered)) != HIPRTC_SUCCESS) { delete m; return fail("lowered name", e); }
       hipFunction_t f = nullptr;
       if (hipModuleGetFunction(&f, m->mod, lowered) != hipSuccess) { delete m; return fail("module function", HIPRTC_ERROR_INTERNAL_ERROR); }
       m->fn[x] = f;
    }
-   hiprtcDestroyProgram(&prog);
+   rtc.DestroyProgram(&prog);
    g_jit_cache[key] = m;
    return m;
 }
