@@ -179,6 +179,8 @@ struct mdh_renderer {
    size_t table_cap = 0;
    bool table_dirty = true;
    int *d_part = nullptr, *d_warn = nullptr;
+   float *d_query = nullptr; // Eval_Distance_To: points, normals, distances of the largest batch so far
+   size_t query_cap = 0;
    // Two sets of probe atlases.  `last` is the set the most recent frame wrote: every read, write and
    // single pass works on it in place.  A pipelined mdh_render (frame overlap, see mdh_render) writes the
    // other set while the previous frame's screen pass still reads this one, then flips.
@@ -506,7 +508,7 @@ extern "C" int32_t mdh_destroy(mdh_renderer *r)
    if (r->probe_stream) (void)hipStreamSynchronize(r->probe_stream);
    if (r->alt_stream) (void)hipStreamSynchronize(r->alt_stream);
    if (r->stream) (void)hipStreamSynchronize(r->stream);
-   void *ptrs[] = {r->d_table, r->d_part, r->d_warn, r->d_rad2[0], r->d_irr2[0], r->d_rad2[1], r->d_irr2[1], r->d_vis2[0], r->d_scat2[0], r->d_vis2[1], r->d_scat2[1], r->d_fb2[0], r->d_fb2[1], r->d_gb2[0][0], r->d_gb2[0][1], r->d_gb2[0][2], r->d_gb2[1][0], r->d_gb2[1][1], r->d_gb2[1][2]};
+   void *ptrs[] = {r->d_table, r->d_part, r->d_warn, r->d_query, r->d_rad2[0], r->d_irr2[0], r->d_rad2[1], r->d_irr2[1], r->d_vis2[0], r->d_scat2[0], r->d_vis2[1], r->d_scat2[1], r->d_fb2[0], r->d_fb2[1], r->d_gb2[0][0], r->d_gb2[0][1], r->d_gb2[0][2], r->d_gb2[1][0], r->d_gb2[1][1], r->d_gb2[1][2]};
    for (void *p : ptrs)
       if (p) (void)hipFree(p);
    for (auto &p : r->pending) { (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1); }
@@ -1501,10 +1503,12 @@ extern "C" int32_t mdh_eval_distance_to(mdh_renderer *r, int32_t n, const float 
    if (n == 0) return MDH_OK;
    int rc = ensure_committed(r);
    if (rc != MDH_OK) return rc;
-   float *d_pts = nullptr, *d_n = nullptr, *d_d = nullptr;
-   HIP_TRY(hipMalloc(&d_pts, (size_t)n * 12));
-   HIP_TRY(hipMalloc(&d_n, (size_t)n * 12));
-   HIP_TRY(hipMalloc(&d_d, (size_t)n * 4));
+   if ((size_t)n > r->query_cap) { // 7 floats per query: point, normal, distance
+      if (r->d_query) { HIP_TRY(hipStreamSynchronize(r->stream)); HIP_TRY(hipFree(r->d_query)); r->d_query = nullptr; }
+      r->query_cap = (size_t)n < 256 ? 256 : (size_t)n;
+      HIP_TRY(hipMalloc(&r->d_query, r->query_cap * 7 * sizeof(float)));
+   }
+   float *d_pts = r->d_query, *d_n = d_pts + 3 * r->query_cap, *d_d = d_n + 3 * r->query_cap;
    HIP_TRY(hipMemcpyAsync(d_pts, pts, (size_t)n * 12, hipMemcpyHostToDevice, r->stream));
    EvalArgs a;
    a.n = n; a.n_kinds = n_kinds;
@@ -1516,7 +1520,6 @@ extern "C" int32_t mdh_eval_distance_to(mdh_renderer *r, int32_t n, const float 
    HIP_TRY(hipMemcpyAsync(dist_out, d_d, (size_t)n * 4, hipMemcpyDeviceToHost, r->stream));
    if (normals_out) HIP_TRY(hipMemcpyAsync(normals_out, d_n, (size_t)n * 12, hipMemcpyDeviceToHost, r->stream));
    HIP_TRY(hipStreamSynchronize(r->stream));
-   (void)hipFree(d_pts); (void)hipFree(d_n); (void)hipFree(d_d);
    return MDH_OK;
 }
 

@@ -201,6 +201,28 @@ def test_pipelined_frames_across_screen_modes(hip):
             assert same_bits(a, b), "output %d differs at overlap level %d" % (i, level)
 
 
+@pytest.mark.gpu
+def test_ball_game_frames(hip, orc):
+    """examples/ball_game: per frame a physics step (Eval_Distance_To against planes and boxes, Set_Primitive per
+    ball), a partition rebuild and a frame.  Ball states and frames must be those of the oracle bit for bit."""
+    runs = []
+    for b in (hip, orc):
+        G = examples.ball_game(96, 64, Probes=SMALL_PROBES, Binding=b)
+        G.R.Set_Option(B.OPT_GBUFFER, 1)
+        for f in range(45):
+            if f in (0, 6, 11):
+                G.Throw_Ball()
+                G.Move_Camera((0.3, 0.1, 0.0))
+            G.Frame()
+        runs.append((G, snapshot(G.R, 1)))
+    (Gh, sh), (Go, so) = runs
+    for bh, bo in zip(Gh.Ball_Bodies, Go.Ball_Bodies):
+        assert bh[0] == bo[0] and same_bits(bh[1], bo[1]) and same_bits(bh[2], bo[2])
+    assert any(body[2][1] > 0.0 for body in Go.Ball_Bodies)  # a ball has bounced off the box
+    assert_parity(sh, so)
+    assert same_bits(np.asarray(Gh.R.Read_Partitioning()), np.asarray(Go.R.Read_Partitioning()))
+
+
 # ---------------------------------------------------------------- BASELINE.json's full size
 @pytest.fixture(scope="module")
 def full_size(hip):

@@ -79,3 +79,19 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".h", ".hip", ".cpp")) or f == "Makefile":
                 for line in open(os.path.join(dirpath, f), errors="replace"):
                     assert not pat.search(line), (f, line)
+
+
+def test_ball_game_on_the_oracle(orc):
+    """examples/ball_game (madarch_amd.examples.Ball_Game): a ball thrown along +z meets the top of the box at
+    (3, 0, 4) and bounces (its vertical velocity flips), the partition is rebuilt every frame without overflow."""
+    from helpers import SMALL_PROBES
+    from madarch_amd import examples
+    G = examples.ball_game(40, 24, Probes=SMALL_PROBES, Binding=orc)
+    G.Throw_Ball()
+    vy = []
+    for _ in range(40):
+        G.Frame()
+        vy.append(float(G.Ball_Bodies[0][2][1]))
+    assert min(vy) < -1.0 and vy[-1] > 0.0
+    assert G.Ball_Bodies[0][0] == 2 and abs(float(G.Ball_Bodies[0][2][2]) - 10.0) < 1e-6
+    assert np.isfinite(G.R.Read_Framebuffer()).mean() > 0.99
