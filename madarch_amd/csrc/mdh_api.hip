@@ -446,6 +446,14 @@ static int commit_scene(mdh_renderer *r)
    s.part_index_count = r->part.index_count;
    s.part_cells = r->part_cells;
    for (int a = 0; a < 3; ++a) { s.part_dims[a] = r->part.grid_dimensions[a]; s.part_sp[a] = r->pg_spacing[a]; s.part_off[a] = r->pg_offset[a]; }
+   s.part_sp_pow2 = 1;
+   for (int a = 0; a < 3; ++a) {
+      int e = 0;
+      const float mant = frexpf(r->pg_spacing[a], &e);
+      const bool pow2 = mant == 0.5f && e > -100 && e < 100; // 2^(e-1), well inside the normal range
+      s.part_inv_sp[a] = pow2 ? 1.0f / r->pg_spacing[a] : 0.0f;
+      if (!pow2) s.part_sp_pow2 = 0;
+   }
    s.part_table = r->d_part;
    r->table_dirty = false;
    return MDH_OK;

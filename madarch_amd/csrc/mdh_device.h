@@ -58,6 +58,8 @@ struct KScene {
    int part_enable, part_border, part_index_count, part_cells;
    int part_dims[3];
    float part_sp[3], part_off[3];
+   int part_sp_pow2; // all three spacings are powers of two: part_inv_sp holds their exact reciprocals (x / 2^k == x * 2^-k)
+   float part_inv_sp[3];
    const float4 *table;   // HBM image of the table (staged to LDS by every workgroup)
    const int *part_table; // [cell][nk + index_count]
 };
@@ -642,7 +644,8 @@ template <bool CUSTOM> MDH_DEV void primitive_info(const KScene &sc, int index, 
 // past the table reads an empty cell
 MDH_DEV int partition_cell(const KScene &sc, f3 x, bool &fallback)
 {
-   f3 fx = floor3((x - F3(sc.part_off[0], sc.part_off[1], sc.part_off[2])) / F3(sc.part_sp[0], sc.part_sp[1], sc.part_sp[2]));
+   const f3 rel = x - F3(sc.part_off[0], sc.part_off[1], sc.part_off[2]);
+   f3 fx = floor3(sc.part_sp_pow2 ? rel * F3(sc.part_inv_sp[0], sc.part_inv_sp[1], sc.part_inv_sp[2]) : rel / F3(sc.part_sp[0], sc.part_sp[1], sc.part_sp[2]));
    f3 cfx = F3(clamp_(fx.x, 0.0f, (float)sc.part_dims[0]), clamp_(fx.y, 0.0f, (float)sc.part_dims[1]), clamp_(fx.z, 0.0f, (float)sc.part_dims[2]));
    fallback = false;
    if (sc.part_border == 0) fx = cfx;
