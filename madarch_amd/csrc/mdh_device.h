@@ -514,6 +514,9 @@ MDH_DEV float prim_dist(int type, int slot, f3 x)
 #ifndef MDH_INFO_UNROLL
 #define MDH_INFO_UNROLL 1
 #endif
+#ifndef MDH_PART_PREFETCH
+#define MDH_PART_PREFETCH 1
+#endif
 #ifndef MDH_SDF_UNROLL
 #define MDH_SDF_UNROLL 2
 #endif
@@ -664,6 +667,26 @@ template <bool INFO, bool CUSTOM> MDH_DEV float partitioning_lookup(const KScene
    if (cell < 0 || cell >= sc.part_cells) return closest;
    const int nk = hdr(H_NK);
    const int *rec = sc.part_table + (size_t)cell * (nk + sc.part_index_count);
+#if MDH_PART_PREFETCH
+   // every record word is asked for one step before it is needed (the count of the next kind, the next candidate
+   // index): the L2 round trips of a cell overlap with the distance evaluations instead of adding up
+   int i = 0, cnt = rec[0], pi_next = rec[nk];
+#pragma unroll 1
+   for (int k = 0; k < nk; ++k) {
+      const int cnt_next = rec[k + 1 < nk ? k + 1 : k];
+      const int size = i + cnt, type = hdr(H_KTYPE + k), s0 = hdr(H_KSLOT + k), base = hdr(H_KBASE + k);
+      const int stop = min(size, sc.part_index_count);
+      for (; i < stop; ++i) {
+         const int pi = pi_next;
+         pi_next = rec[nk + (i + 1 < sc.part_index_count ? i + 1 : i)]; // (inside the record; unused past the last candidate)
+         float d = (CUSTOM && type == PK_CUSTOM) ? xdist<false>(k, pi, x) : prim_dist(type, s0 + prim_slots(type) * pi, x);
+         if (INFO) { if (d < closest) { closest = d; index = base + pi; } }
+         else closest = min_(closest, d);
+      }
+      i = size;
+      cnt = cnt_next;
+   }
+#else
    int i = 0;
 #pragma unroll 1
    for (int k = 0; k < nk; ++k) {
@@ -677,6 +700,7 @@ template <bool INFO, bool CUSTOM> MDH_DEV float partitioning_lookup(const KScene
       }
       i = size;
    }
+#endif
    return closest;
 }
 // PART is a set of flags: bit 0 = the space partition is on, bit 1 = the scene has user-defined kinds
