@@ -66,6 +66,7 @@ class DeviceExchange:
         self.device = device
         self._streams = {}
         self._views = {}
+        self._stage = {}
 
     def _stream(self, renderer):
         # asked per call: the library runs the probe passes on its probe stream when frames are kept in
@@ -95,7 +96,14 @@ class DeviceExchange:
         if own * world != total:
             raise ValueError("probe count %d is not divisible by the world size %d" % (renderer.Probe_Total(), world))
         with self.torch.cuda.stream(self._stream(renderer)):
-            self.dist.all_gather_into_tensor(full, full[off:off + own], group=self.group)
+            # the rank's slice goes through a small staging tensor: the gather then never reads and writes the same
+            # bytes, whatever the backend makes of aliased buffers (a device copy of at most a few hundred KiB)
+            key = (tex, own)
+            if key not in self._stage:
+                self._stage[key] = self.torch.empty(own, dtype=full.dtype, device=self.device)
+            mine = self._stage[key]
+            mine.copy_(full[off:off + own], non_blocking=True)
+            self.dist.all_gather_into_tensor(full, mine, group=self.group)
 
 
 class ShardedFrame:
