@@ -140,6 +140,7 @@ def main():
     ap.add_argument("--serial", action="store_true", help="MDH_OPT_FRAME_OVERLAP = 0: one pass after the other (per-kernel timing runs)")
     ap.add_argument("--overlap", type=int, default=None, help="MDH_OPT_FRAME_OVERLAP value (default: the library's)")
     ap.add_argument("--no-serial-segment", action="store_true", help="skip the untimed serial frames that give clean per-kernel durations")
+    ap.add_argument("--animate-light", action="store_true", help="set the light anew before every frame, as the example's main loop does (global_illumination/main.adb:219-232)")
     ap.add_argument("--rehearse-rccl", action="store_true", help="one rank, but through the RCCL exchange path of the sharded frame (rehearsal of the N > 1 code path on one GPU)")
     args = ap.parse_args()
 
@@ -182,6 +183,15 @@ def main():
         if world > 1:
             dist.barrier()
 
+    animate = None
+    if args.animate_light and WORKLOADS[args.workload][0] == "global_illumination":
+        import math
+        from madarch_amd.lights import spot_lights
+        clock = [0.0]
+
+        def animate():
+            clock[0] += 0.01
+            R.Set_Light(1, spot_lights.Spot_Light, spot_lights.Create((3.5, 5.0, 2.0), (math.cos(clock[0]), math.sin(clock[0]), 0.0), 3.1415 / 4.0, (0.9, 0.9, 0.8)))
     for _ in range(args.warmup):
         frame.Render()
     sync()
@@ -190,6 +200,8 @@ def main():
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
+        if animate:
+            animate()
         frame.Render()
     R.Finish()
     torch.cuda.synchronize()
@@ -242,7 +254,7 @@ def main():
             "config": {"workload": args.workload, "scene": scene, "width": W, "height": H,
                        "probe_grid": "8x8x8" if probes == "gi8" else "4x3x3", "atlas": args.atlas,
                        "screen_mode": mode, "parallelism": "tiles+probes/%d" % world + (" (RCCL rehearsal)" if args.rehearse_rccl else ""),
-                       "frame_overlap": overlap},
+                       "frame_overlap": overlap, "animated_light": bool(animate)},
             "roofline": {"bound": "hbm", "kernel": "k_screen", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": int(alg_bytes), "bytes_per_pixel": per_px,

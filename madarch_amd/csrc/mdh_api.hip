@@ -175,7 +175,19 @@ struct mdh_renderer {
    int opt_atlas = 0, opt_mode = 0, opt_ao = 3, opt_gbuffer = 0, opt_rank = 0, opt_world = 1, opt_timing = 0, opt_ada_div = 1;
    // device state
    std::vector<float4> table_host;
-   float4 *d_table = nullptr;
+   // The scene table lives in a ring of buffers: an edit (Set_Light every frame in the reference's examples) is
+   // packed into the NEXT buffer and uploaded asynchronously from pinned memory while the frames in flight keep
+   // reading theirs -- a scene edit does not drain the frame pipeline.  A buffer is rewritten only after the last
+   // kernels that were launched with it have finished (tab_done, per stream).
+   static const int TAB_RING = 4;
+   float4 *d_table_ring[TAB_RING] = {nullptr, nullptr, nullptr, nullptr};
+   float4 *h_table_ring[TAB_RING] = {nullptr, nullptr, nullptr, nullptr}; // pinned
+   int tab_slot = 0;
+   hipEvent_t tab_done[TAB_RING][3] = {{nullptr}};
+   bool tab_used[TAB_RING][3] = {{false}};
+   hipEvent_t ev_table = nullptr;       // recorded after the last upload, on table_stream
+   hipStream_t table_stream = nullptr;
+   unsigned long long table_version = 0, tab_seen[3] = {0, 0, 0}; // per stream (main, probe, alternate): has it waited for ev_table
    size_t table_cap = 0;
    bool table_dirty = true;
    int *d_part = nullptr, *d_warn = nullptr;
@@ -277,7 +289,27 @@ static float i_as_f(int i) { float f; memcpy(&f, &i, 4); return f; }
 
 // Repack the std140 images into the float4 table the kernels stage into LDS
 // (layout in mdh_device.h) and refresh the SGPR header.
-static int commit_scene(mdh_renderer *r)
+static int stream_index(const mdh_renderer *r, hipStream_t st) { return st == r->probe_stream ? 1 : (st == r->alt_stream ? 2 : 0); }
+// before a kernel that stages the table is launched on `st`: order `st` after the table's upload
+static int table_acquire(mdh_renderer *r, hipStream_t st)
+{
+   const int si = stream_index(r, st);
+   if (r->tab_seen[si] != r->table_version) {
+      if (st != r->table_stream) HIP_TRY(hipStreamWaitEvent(st, r->ev_table, 0));
+      r->tab_seen[si] = r->table_version;
+   }
+   return MDH_OK;
+}
+// after it: the table buffer is in use on `st` until this point of the stream
+static int table_release(mdh_renderer *r, hipStream_t st)
+{
+   const int si = stream_index(r, st);
+   HIP_TRY(hipEventRecord(r->tab_done[r->tab_slot][si], st));
+   r->tab_used[r->tab_slot][si] = true;
+   return MDH_OK;
+}
+
+static int commit_scene(mdh_renderer *r, hipStream_t up)
 {
    KScene &s = r->ks;
    s.max_dist = r->max_dist;
@@ -432,15 +464,28 @@ static int commit_scene(mdh_renderer *r)
    memcpy(t.data(), H, sizeof H);
    s.table_f4 = (int)t.size();
    if ((size_t)s.table_f4 * 16 > 64 * 1024) return seterr(MDH_E_INVALID, "scene tables exceed the 64 KiB LDS budget of a workgroup");
-   if (t.size() > r->table_cap) {
-      if (r->d_table) HIP_TRY(hipFree(r->d_table));
-      r->table_cap = t.size() + 64;
-      HIP_TRY(hipMalloc(&r->d_table, r->table_cap * sizeof(float4)));
+   if (t.size() > r->table_cap) { // grow the whole ring (rare: the table only grows with the primitive counts)
+      HIP_TRY(hipDeviceSynchronize());
+      r->table_cap = t.size() + 256;
+      for (int q = 0; q < mdh_renderer::TAB_RING; ++q) {
+         if (r->d_table_ring[q]) HIP_TRY(hipFree(r->d_table_ring[q]));
+         if (r->h_table_ring[q]) HIP_TRY(hipHostFree(r->h_table_ring[q]));
+         HIP_TRY(hipMalloc(&r->d_table_ring[q], r->table_cap * sizeof(float4)));
+         HIP_TRY(hipHostMalloc((void **)&r->h_table_ring[q], r->table_cap * sizeof(float4), hipHostMallocDefault));
+         for (int si = 0; si < 3; ++si) r->tab_used[q][si] = false;
+      }
    }
-   // the copy is enqueued on the renderer's stream, ahead of the kernels that stage it
-   HIP_TRY(hipMemcpyAsync(r->d_table, t.data(), t.size() * sizeof(float4), hipMemcpyHostToDevice, r->stream));
-   HIP_TRY(hipStreamSynchronize(r->stream)); // table_host may be rebuilt by the next call
-   s.table = r->d_table;
+   const int ns = (r->tab_slot + 1) % mdh_renderer::TAB_RING;
+   for (int si = 0; si < 3; ++si)
+      if (r->tab_used[ns][si]) { HIP_TRY(hipEventSynchronize(r->tab_done[ns][si])); r->tab_used[ns][si] = false; }
+   memcpy(r->h_table_ring[ns], t.data(), t.size() * sizeof(float4));
+   HIP_TRY(hipMemcpyAsync(r->d_table_ring[ns], r->h_table_ring[ns], t.size() * sizeof(float4), hipMemcpyHostToDevice, up));
+   HIP_TRY(hipEventRecord(r->ev_table, up));
+   r->table_stream = up;
+   ++r->table_version;
+   r->tab_seen[stream_index(r, up)] = r->table_version;
+   r->tab_slot = ns;
+   s.table = r->d_table_ring[ns];
    s.part_enable = r->part.enable;
    s.part_border = r->part.border_behavior;
    s.part_index_count = r->part.index_count;
@@ -516,13 +561,18 @@ extern "C" int32_t mdh_destroy(mdh_renderer *r)
    if (r->probe_stream) (void)hipStreamSynchronize(r->probe_stream);
    if (r->alt_stream) (void)hipStreamSynchronize(r->alt_stream);
    if (r->stream) (void)hipStreamSynchronize(r->stream);
-   void *ptrs[] = {r->d_table, r->d_part, r->d_warn, r->d_query, r->d_rad2[0], r->d_irr2[0], r->d_rad2[1], r->d_irr2[1], r->d_vis2[0], r->d_scat2[0], r->d_vis2[1], r->d_scat2[1], r->d_fb2[0], r->d_fb2[1], r->d_gb2[0][0], r->d_gb2[0][1], r->d_gb2[0][2], r->d_gb2[1][0], r->d_gb2[1][1], r->d_gb2[1][2]};
+   void *ptrs[] = {r->d_table_ring[0], r->d_table_ring[1], r->d_table_ring[2], r->d_table_ring[3], r->d_part, r->d_warn, r->d_query, r->d_rad2[0], r->d_irr2[0], r->d_rad2[1], r->d_irr2[1], r->d_vis2[0], r->d_scat2[0], r->d_vis2[1], r->d_scat2[1], r->d_fb2[0], r->d_fb2[1], r->d_gb2[0][0], r->d_gb2[0][1], r->d_gb2[0][2], r->d_gb2[1][0], r->d_gb2[1][1], r->d_gb2[1][2]};
    for (void *p : ptrs)
       if (p) (void)hipFree(p);
    for (auto &p : r->pending) { (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1); }
    for (auto e : r->free_events) (void)hipEventDestroy(e);
-   for (hipEvent_t e : {r->ev_screen[0], r->ev_screen[1], r->ev_probe[0], r->ev_probe[1], r->ev_join, r->ev_join_alt})
+   for (hipEvent_t e : {r->ev_screen[0], r->ev_screen[1], r->ev_probe[0], r->ev_probe[1], r->ev_join, r->ev_join_alt, r->ev_table})
       if (e) (void)hipEventDestroy(e);
+   for (int q = 0; q < mdh_renderer::TAB_RING; ++q) {
+      if (r->h_table_ring[q]) (void)hipHostFree(r->h_table_ring[q]);
+      for (int si = 0; si < 3; ++si)
+         if (r->tab_done[q][si]) (void)hipEventDestroy(r->tab_done[q][si]);
+   }
    if (r->probe_stream) (void)hipStreamDestroy(r->probe_stream);
    if (r->alt_stream) (void)hipStreamDestroy(r->alt_stream);
    if (r->own_stream) (void)hipStreamDestroy(r->own_stream);
@@ -606,7 +656,9 @@ extern "C" int32_t mdh_create(int32_t width, int32_t height, const mdh_scene_des
       prio = prio < 0 ? hi : (prio > 0 ? lo : 0);
       TRY_OR_FAIL(hipStreamCreateWithPriority(&r->probe_stream, hipStreamNonBlocking, prio));
       TRY_OR_FAIL(hipStreamCreateWithFlags(&r->alt_stream, hipStreamNonBlocking));
-      for (hipEvent_t *e : {&r->ev_screen[0], &r->ev_screen[1], &r->ev_probe[0], &r->ev_probe[1], &r->ev_join, &r->ev_join_alt}) TRY_OR_FAIL(hipEventCreateWithFlags(e, hipEventDisableTiming));
+      for (hipEvent_t *e : {&r->ev_screen[0], &r->ev_screen[1], &r->ev_probe[0], &r->ev_probe[1], &r->ev_join, &r->ev_join_alt, &r->ev_table}) TRY_OR_FAIL(hipEventCreateWithFlags(e, hipEventDisableTiming));
+      for (int q = 0; q < mdh_renderer::TAB_RING; ++q)
+         for (int si = 0; si < 3; ++si) TRY_OR_FAIL(hipEventCreateWithFlags(&r->tab_done[q][si], hipEventDisableTiming));
    }
    if ((rc = alloc_atlases(r)) != MDH_OK) return fail(rc);
    size_t px = (size_t)width * height;
@@ -760,14 +812,11 @@ extern "C" int32_t mdh_set_camera_orientation(mdh_renderer *r, const float m[9])
    return MDH_OK;
 }
 
-static int ensure_committed(mdh_renderer *r)
+// `up`: the stream the new table is uploaded on (the one that uses it first); nullptr = the main stream
+static int ensure_committed(mdh_renderer *r, hipStream_t up = nullptr)
 {
    HIP_TRY(hipSetDevice(r->device));
-   if (r->table_dirty) {
-      int jr = join_main(r); // commit_scene drains `stream`: order it after the other streams first
-      if (jr != MDH_OK) return jr;
-      return commit_scene(r);
-   }
+   if (r->table_dirty) return commit_scene(r, up ? up : r->stream);
    return MDH_OK;
 }
 static size_t lds_bytes(const mdh_renderer *r) { return (size_t)r->ks.table_f4 * sizeof(float4); }
@@ -1002,8 +1051,10 @@ extern "C" int32_t mdh_update_partitioning(mdh_renderer *r, int32_t method)
    HIP_TRY(hipMemsetAsync(r->d_warn, 0, 4, r->stream));
    int cells = a.gx * a.gy * a.gz;
    if (cells > 0) {
+      if ((rc = table_acquire(r, r->stream)) != MDH_OK) return rc;
       hipLaunchKernelGGL(k_partition_build, dim3((cells + 63) / 64), dim3(64), lds_bytes(r), r->stream, r->ks, a);
       HIP_TRY(hipGetLastError());
+      if ((rc = table_release(r, r->stream)) != MDH_OK) return rc;
    }
    HIP_TRY(hipMemcpyAsync(&r->part_warnings, r->d_warn, 4, hipMemcpyDeviceToHost, r->stream));
    HIP_TRY(hipStreamSynchronize(r->stream));
@@ -1047,6 +1098,10 @@ static int run_pass(mdh_renderer *r, int pass, hipStream_t st, int src, int dst,
    KCamera cam = make_camera(r);
    // user-defined kinds compiled into the kernels (MDH_OPT_JIT); a scene hiprtc cannot build falls back to the
    // interpreter for good (the reason stays in mdh_last_error, MDH_OPT_JIT reads 0 afterwards)
+   if (pass != MDH_PASS_IRRADIANCE) { // (the irradiance pass does not stage the scene table)
+      int trc = table_acquire(r, st);
+      if (trc != MDH_OK) return trc;
+   }
    bool jit = has_custom && r->opt_jit;
    char kname[64] = "";
    JitModule *jm = nullptr;
@@ -1154,6 +1209,10 @@ static int run_pass(mdh_renderer *r, int pass, hipStream_t st, int src, int dst,
    default: return seterr(MDH_E_INVALID, "bad pass");
    }
    HIP_TRY(hipGetLastError());
+   if (pass != MDH_PASS_IRRADIANCE) {
+      int trc = table_release(r, st);
+      if (trc != MDH_OK) return trc;
+   }
    if (r->opt_timing) {
       HIP_TRY(hipEventRecord(e1, st));
       r->pending.push_back({pass, e0, e1});
@@ -1198,9 +1257,10 @@ extern "C" int32_t mdh_frame_begin(mdh_renderer *r)
 {
    if (!r) return seterr(MDH_E_INVALID, "null renderer");
    if (r->in_frame) return seterr(MDH_E_STATE, "a frame is already open");
-   int rc = ensure_committed(r);
-   if (rc != MDH_OK) return rc;
    r->frame_pipelined = r->opt_overlap && r->stream == r->own_stream; // (modes 1 and 2 have no probe passes: their screen passes still alternate streams)
+   // an edited scene goes up on the stream that uses it first; frames in flight keep the table buffers they were launched with
+   int rc = ensure_committed(r, r->frame_pipelined && r->opt_mode == 0 ? r->probe_stream : nullptr);
+   if (rc != MDH_OK) return rc;
    if (!r->frame_pipelined) {
       if ((rc = join_main(r)) != MDH_OK) return rc;
       r->main_dirty = true;
@@ -1497,7 +1557,11 @@ extern "C" int32_t mdh_set_stream(mdh_renderer *r, void *stream)
    HIP_TRY(hipStreamSynchronize(r->stream));
    int rc = resolve_timing(r);
    if (rc != MDH_OK) return rc;
+   if (r->probe_stream) HIP_TRY(hipStreamSynchronize(r->probe_stream));
+   if (r->alt_stream) HIP_TRY(hipStreamSynchronize(r->alt_stream));
    r->stream = stream ? (hipStream_t)stream : r->own_stream;
+   // the new main stream has not waited for anything: uploads and earlier work are complete (synchronised above)
+   for (int si = 0; si < 3; ++si) r->tab_seen[si] = r->table_version;
    return MDH_OK;
 }
 
@@ -1522,9 +1586,11 @@ extern "C" int32_t mdh_eval_distance_to(mdh_renderer *r, int32_t n, const float 
    a.n = n; a.n_kinds = n_kinds;
    for (int i = 0; i < MDH_MAX_KINDS; ++i) { a.kinds[i] = i < n_kinds ? kind_ixs[i] : 0; a.host_count[i] = r->host_count[i]; }
    a.pts = d_pts; a.normals = d_n; a.dist = d_d;
+   if ((rc = table_acquire(r, r->stream)) != MDH_OK) return rc;
    if (r->opt_ada_div) hipLaunchKernelGGL(k_eval_distance<true>, dim3((n + 63) / 64), dim3(64), lds_bytes(r), r->stream, r->ks, a);
    else hipLaunchKernelGGL(k_eval_distance<false>, dim3((n + 63) / 64), dim3(64), lds_bytes(r), r->stream, r->ks, a);
    HIP_TRY(hipGetLastError());
+   if ((rc = table_release(r, r->stream)) != MDH_OK) return rc;
    HIP_TRY(hipMemcpyAsync(dist_out, d_d, (size_t)n * 4, hipMemcpyDeviceToHost, r->stream));
    if (normals_out) HIP_TRY(hipMemcpyAsync(normals_out, d_n, (size_t)n * 12, hipMemcpyDeviceToHost, r->stream));
    HIP_TRY(hipStreamSynchronize(r->stream));

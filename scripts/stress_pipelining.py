@@ -28,8 +28,15 @@ def drive(seed, overlap):
                 R.Render()
         elif op < 70:
             R.Set_Camera_Position(tuple(rng.uniform(0.5, 5.0, 3)))
-        elif op < 76:
+        elif op < 74:
             R.Set_Primitive(spheres.Sphere, 1, spheres.Create(tuple(rng.uniform(1.0, 5.0, 3)), float(rng.uniform(0.4, 1.2)), 3))
+        elif op < 76:  # a burst of edits, each committed by a query or a frame: wraps the ring of table buffers
+            for _ in range(int(rng.integers(3, 9))):
+                R.Set_Primitive(spheres.Sphere, 1, spheres.Create(tuple(rng.uniform(1.0, 5.0, 3)), float(rng.uniform(0.4, 1.2)), 3))
+                if rng.integers(0, 2):
+                    out.append(R.Eval_Distances_To(rng.uniform(0.0, 6.0, (17, 3)).astype(np.float32), [spheres.Sphere])[0])
+                else:
+                    R.Render()
         elif op < 82:
             R.Render_Pass(int(rng.choice([B.PASS_RADIANCE, B.PASS_IRRADIANCE, B.PASS_SCREEN])))
         elif op < 88:
