@@ -359,7 +359,8 @@ static int commit_scene(mdh_renderer *r, hipStream_t up)
    // for closest_primitive (the per-kind copy above stays complete for the arg-min / normals)
    {
       const float inf = INFINITY;
-      for (int g = 0; g < 6; ++g) s.axis_off[g] = inf;
+      for (int g = 0; g < 6; ++g) { s.axis_off[g] = inf; H[H_AXIS_IDX + g] = -1; }
+      int per_dir[6] = {0, 0, 0, 0, 0, 0};
       s.n_axis = 0;
       s.gplane_slot = (int)t.size();
       s.gplane_count = 0;
@@ -375,13 +376,24 @@ static int commit_scene(mdh_renderer *r, hipStream_t up)
                if (n[c] != 0.0f) { ++nz; axis = c; }
             if (nz == 1 && (n[axis] == 1.0f || n[axis] == -1.0f) && o == o) {
                int g = 2 * axis + (n[axis] < 0.0f ? 1 : 0);
-               if (o < s.axis_off[g]) s.axis_off[g] = o;
+               if (o < s.axis_off[g]) { s.axis_off[g] = o; H[H_AXIS_IDX + g] = r->prim_base[k] + i; }
+               ++per_dir[g];
                ++s.n_axis;
             } else {
                t.push_back(mk4(n[0], n[1], n[2], o));
                ++s.gplane_count;
             }
          }
+      }
+      // the typed arg-min of closest_primitive_info needs every plane to be one of the six folded ones
+      // (two planes of one direction can tie after rounding, and the tie goes to the lower index)
+      H[H_FASTINFO] = s.gplane_count == 0;
+      for (int g = 0; g < 6; ++g)
+         if (per_dir[g] > 1) H[H_FASTINFO] = 0;
+      for (int ty = 0; ty < 4; ++ty) H[H_TBASE + ty] = 0;
+      for (int k = 0; k < r->npk; ++k) {
+         if (r->pk[k].type == PK_CUSTOM) H[H_FASTINFO] = 0;
+         else H[H_TBASE + r->pk[k].type] = r->prim_base[k];
       }
    }
    // material ids (int32), 4 per float4

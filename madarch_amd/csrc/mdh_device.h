@@ -83,7 +83,10 @@ enum {
    H_LSTRIDE = 124, // [4] float4 per instance
    // user-defined light kinds: Sample and Position programs
    H_XLSAMPLE = 128, H_XLSAMPLEN = 132, H_XLPOS = 136, H_XLPOSN = 140,
-   H_INTS = 144    // 36 float4
+   // the typed arg-min (closest_primitive_info): flat index of the plane behind each folded axis offset (-1: none),
+   // flat index base of each built-in TYPE, and whether the scene allows it
+   H_AXIS_IDX = 144, H_TBASE = 150, H_FASTINFO = 154,
+   H_INTS = 156    // 39 float4
 };
 
 struct KProbes {
@@ -517,6 +520,9 @@ MDH_DEV float prim_dist(int type, int slot, f3 x)
 #ifndef MDH_PART_PREFETCH
 #define MDH_PART_PREFETCH 1
 #endif
+#ifndef MDH_FAST_INFO
+#define MDH_FAST_INFO 1
+#endif
 #ifndef MDH_SDF_UNROLL
 #define MDH_SDF_UNROLL 2
 #endif
@@ -597,6 +603,47 @@ template <bool CUSTOM> MDH_DEV float closest_primitive(const KScene &sc, f3 x)
 template <bool CUSTOM> MDH_DEV float closest_primitive_info(const KScene &sc, f3 x, int &index)
 {
    float closest = sc.max_dist;
+#if MDH_FAST_INFO
+   // The same arg-min by TYPE, with the six folded axis planes and without the per-kind dispatch: a candidate wins
+   // when it is closer, or as close with a lower flat index -- what the scan in scene order keeps (the first of
+   // equal distances).  Only for scenes whose planes are all folded, one per direction (H_FASTINFO).
+   if (!CUSTOM && hdr(H_FASTINFO)) {
+      int best = -1;
+#define MDH_CAND(dist_, idx_)                                                                      \
+      do {                                                                                         \
+         const float d_ = (dist_);                                                                 \
+         const int i_ = (idx_);                                                                    \
+         if (d_ < closest || (d_ == closest && best >= 0 && i_ < best)) { closest = d_; best = i_; } \
+      } while (0)
+      if (sc.n_axis > 0) {
+         const float c[6] = {x.x, -x.x, x.y, -x.y, x.z, -x.z};
+#pragma unroll
+         for (int g = 0; g < 6; ++g) {
+            const int pi = hdr(H_AXIS_IDX + g);
+            if (pi >= 0) MDH_CAND(c[g] + sc.axis_off[g], pi);
+         }
+      }
+      {
+         const int n = sc.tcount[PK_SPHERE], s0 = sc.tslot[PK_SPHERE], base = hdr(H_TBASE + PK_SPHERE);
+#pragma unroll 1
+         for (int i = 0; i < n; ++i) MDH_CAND(sd_sphere(s_tab[s0 + i], x), base + i);
+      }
+      {
+         const int n = sc.tcount[PK_BOX], s0 = sc.tslot[PK_BOX], base = hdr(H_TBASE + PK_BOX);
+#pragma unroll 1
+         for (int i = 0; i < n; ++i) MDH_CAND(sd_box(s_tab[s0 + 2 * i], s_tab[s0 + 2 * i + 1], x), base + i);
+      }
+      {
+         const int n = sc.tcount[PK_TRIANGLE], s0 = sc.tslot[PK_TRIANGLE], base = hdr(H_TBASE + PK_TRIANGLE);
+#pragma unroll 1
+         for (int i = 0; i < n; ++i)
+            MDH_CAND(sd_triangle<false>(xyz(s_tab[s0 + 3 * i]), xyz(s_tab[s0 + 3 * i + 1]), xyz(s_tab[s0 + 3 * i + 2]), x), base + i);
+      }
+#undef MDH_CAND
+      if (best >= 0) index = best;
+      return closest;
+   }
+#endif
    const int nk = hdr(H_NK);
 #pragma unroll 1
    for (int k = 0; k < nk; ++k) {
