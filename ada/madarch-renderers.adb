@@ -101,7 +101,9 @@ package body Madarch.Renderers is
    procedure Render (Self : Renderer) is
    begin
       Check (HIP.Render (Self.Handle));
-      Check (HIP.Finish (Self.Handle));
+      --  renderers.adb:320: the frame's RGBA8 pixels travel to pinned host memory behind it; no host
+      --  wait here, frames stay in flight (HIP.Front_Buffer waits for the last swap and returns them)
+      Check (HIP.Swap_Buffers (Self.Handle));
    end Render;
 
    --  madarch-renderers.adb:349-367

@@ -131,6 +131,14 @@ package Madarch_HIP is
    function Read_Framebuffer (R : Handle; RGB_Out : System.Address) return Status
      with Import, Convention => C, External_Name => "mdh_read_framebuffer";
 
+   --  the window's RGBA8 pixels (Swap_Buffers, madarch-renderers.adb:320): enqueue, then fetch
+   function Swap_Buffers (R : Handle) return Status
+     with Import, Convention => C, External_Name => "mdh_swap_buffers";
+
+   function Front_Buffer
+     (R : Handle; RGBA : access System.Address; Swap_Count : access Interfaces.C.long) return Status
+     with Import, Convention => C, External_Name => "mdh_front_buffer";
+
    function Eval_Distance_To
      (R : Handle; N : int; Points : System.Address; Kind_Ixs : System.Address;
       N_Kinds : int; Normals_Out, Dist_Out : System.Address) return Status

@@ -140,6 +140,7 @@ def main():
     ap.add_argument("--serial", action="store_true", help="MDH_OPT_FRAME_OVERLAP = 0: one pass after the other (per-kernel timing runs)")
     ap.add_argument("--overlap", type=int, default=None, help="MDH_OPT_FRAME_OVERLAP value (default: the library's)")
     ap.add_argument("--no-serial-segment", action="store_true", help="skip the untimed serial frames that give clean per-kernel durations")
+    ap.add_argument("--swap-buffers", action="store_true", help="Swap_Buffers after every frame and fetch the window's RGBA8 pixels of the frame before (the PCIe-inclusive rate; never the default)")
     ap.add_argument("--animate-light", action="store_true", help="set the light anew before every frame, as the example's main loop does (global_illumination/main.adb:219-232)")
     ap.add_argument("--rehearse-rccl", action="store_true", help="one rank, but through the RCCL exchange path of the sharded frame (rehearsal of the N > 1 code path on one GPU)")
     args = ap.parse_args()
@@ -192,6 +193,8 @@ def main():
         def animate():
             clock[0] += 0.01
             R.Set_Light(1, spot_lights.Spot_Light, spot_lights.Create((3.5, 5.0, 2.0), (math.cos(clock[0]), math.sin(clock[0]), 0.0), 3.1415 / 4.0, (0.9, 0.9, 0.8)))
+    if args.swap_buffers:
+        R.Set_Option(B.OPT_WINDOW, 1)
     for _ in range(args.warmup):
         frame.Render()
     sync()
@@ -203,6 +206,12 @@ def main():
         if animate:
             animate()
         frame.Render()
+        if args.swap_buffers:  # pixels of the frame before reach the host while this one is drawn
+            if _:
+                R.Front_Buffer(copy=False)
+            R.Swap_Buffers()
+    if args.swap_buffers:
+        R.Front_Buffer(copy=False)
     R.Finish()
     torch.cuda.synchronize()
     if world > 1:
@@ -254,7 +263,7 @@ def main():
             "config": {"workload": args.workload, "scene": scene, "width": W, "height": H,
                        "probe_grid": "8x8x8" if probes == "gi8" else "4x3x3", "atlas": args.atlas,
                        "screen_mode": mode, "parallelism": "tiles+probes/%d" % world + (" (RCCL rehearsal)" if args.rehearse_rccl else ""),
-                       "frame_overlap": overlap, "animated_light": bool(animate)},
+                       "frame_overlap": overlap, "animated_light": bool(animate), "swap_buffers": bool(args.swap_buffers)},
             "roofline": {"bound": "hbm", "kernel": "k_screen", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": int(alg_bytes), "bytes_per_pixel": per_px,

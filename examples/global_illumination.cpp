@@ -1,6 +1,6 @@
 // examples/global_illumination.cpp -- the reference program examples/global_illumination/main.adb
 // (lines 29-74 and 149-161) restated with the C++ mirror of Madarch's packages: same scene data,
-// same call order, minus the window loop.  Usage: global_illumination W H FRAMES out.f32
+// same call order, minus the window loop.  Usage: global_illumination W H FRAMES [out.f32 [out.ppm]]
 #include "madarch.hpp"
 
 #include <cstdio>
@@ -34,12 +34,23 @@ int main(int argc, char **argv)
       Renderer.Set_Camera_Position({2.0f, 2.0f, 0.0f});
       Renderer.Set_Light(1, Lights::Spot_Lights::Spot_Light, Spot_Light_Instance);
 
-      for (int f = 0; f < frames; ++f) Renderer.Render();
+      for (int f = 0; f < frames; ++f) {
+         Renderer.Render();
+         Renderer.Swap_Buffers(); // renderers.adb:320, here into pinned host memory; no wait
+      }
       std::vector<float> image = Renderer.Read_Framebuffer();
       if (argc > 4) {
          FILE *out = fopen(argv[4], "wb");
          if (!out) return 2;
          fwrite(image.data(), sizeof(float), image.size(), out);
+         fclose(out);
+      }
+      if (argc > 5) { // the window's pixels of the last frame as a binary PPM
+         const uint8_t *px = Renderer.Front_Buffer();
+         FILE *out = fopen(argv[5], "wb");
+         if (!out) return 2;
+         fprintf(out, "P6\n%d %d\n255\n", W, H);
+         for (size_t i = 0; i < (size_t)W * H; ++i) fwrite(px + 4 * i, 1, 3, out);
          fclose(out);
       }
       double sum = 0;

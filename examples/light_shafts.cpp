@@ -1,5 +1,5 @@
 // examples/light_shafts.cpp -- the reference program examples/light_shafts/main.adb:29-59,140-155
-// restated with the C++ mirror (volumetrics on, default settings).  Usage: light_shafts W H FRAMES out.f32
+// restated with the C++ mirror (volumetrics on, default settings).  Usage: light_shafts W H FRAMES [out.f32 [out.ppm]]
 #include "madarch.hpp"
 
 #include <cstdio>
@@ -29,12 +29,23 @@ int main(int argc, char **argv)
       Renderer.Set_Camera_Position({2.0f, 2.0f, 0.0f});
       Renderer.Set_Light(1, Lights::Point_Lights::Point_Light, Point_Light_Instance);
 
-      for (int f = 0; f < frames; ++f) Renderer.Render();
+      for (int f = 0; f < frames; ++f) {
+         Renderer.Render();
+         Renderer.Swap_Buffers(); // renderers.adb:320, here into pinned host memory; no wait
+      }
       std::vector<float> image = Renderer.Read_Framebuffer();
       if (argc > 4) {
          FILE *out = fopen(argv[4], "wb");
          if (!out) return 2;
          fwrite(image.data(), sizeof(float), image.size(), out);
+         fclose(out);
+      }
+      if (argc > 5) { // the window's pixels of the last frame as a binary PPM
+         const uint8_t *px = Renderer.Front_Buffer();
+         FILE *out = fopen(argv[5], "wb");
+         if (!out) return 2;
+         fprintf(out, "P6\n%d %d\n255\n", W, H);
+         for (size_t i = 0; i < (size_t)W * H; ++i) fwrite(px + 4 * i, 1, 3, out);
          fclose(out);
       }
       double sum = 0;

@@ -1,6 +1,6 @@
 // examples/simple_scene.cpp -- the reference program examples/simple_scene/main.adb:28-122
 // restated with the C++ mirror (20 spheres, 6 planes, 14 boxes, one point light, the 10x10x20
-// space partition built with CPU_Best).  Usage: simple_scene W H FRAMES out.f32
+// space partition built with CPU_Best).  Usage: simple_scene W H FRAMES [out.f32 [out.ppm]]
 #include "madarch.hpp"
 
 #include <cstdio>
@@ -38,12 +38,23 @@ int main(int argc, char **argv)
       Renderer.Set_Camera_Position({2.0f, 2.0f, 0.0f});
       Renderer.Update_Partitioning(Renderers::CPU_Best);
 
-      for (int f = 0; f < frames; ++f) Renderer.Render();
+      for (int f = 0; f < frames; ++f) {
+         Renderer.Render();
+         Renderer.Swap_Buffers(); // renderers.adb:320, here into pinned host memory; no wait
+      }
       std::vector<float> image = Renderer.Read_Framebuffer();
       if (argc > 4) {
          FILE *out = fopen(argv[4], "wb");
          if (!out) return 2;
          fwrite(image.data(), sizeof(float), image.size(), out);
+         fclose(out);
+      }
+      if (argc > 5) { // the window's pixels of the last frame as a binary PPM
+         const uint8_t *px = Renderer.Front_Buffer();
+         FILE *out = fopen(argv[5], "wb");
+         if (!out) return 2;
+         fprintf(out, "P6\n%d %d\n255\n", W, H);
+         for (size_t i = 0; i < (size_t)W * H; ++i) fwrite(px + 4 * i, 1, 3, out);
          fclose(out);
       }
       double sum = 0;

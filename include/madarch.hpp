@@ -343,6 +343,15 @@ class Renderer {
       Check(mdh_read_framebuffer(h_.get(), out.data()));
       return out;
    }
+   // Swap_Buffers itself (renderers.adb:320): the window's RGBA8 pixels, enqueued behind the frame without a host wait ...
+   void Swap_Buffers() const { Check(mdh_swap_buffers(h_.get())); }
+   // ... and fetched: H*W*4 bytes owned by the renderer (valid until the second next Swap_Buffers); waits for the last swap only
+   const uint8_t *Front_Buffer() const
+   {
+      const uint8_t *p = nullptr;
+      Check(mdh_front_buffer(h_.get(), &p, nullptr));
+      return p;
+   }
    void Set_Option(int32_t Option, int32_t Value) const { Check(mdh_set_option(h_.get(), Option, Value)); }
    mdh_renderer *Handle() const { return h_.get(); }
    const Windows::Window &Window() const { return window_; }

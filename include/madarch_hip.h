@@ -211,7 +211,11 @@ enum {
     * probes on every rank from the gathered radiance atlas instead of its own slice (the pass
     * is one workgroup per probe and far from filling a GPU: the same time, and the second
     * exchange of the frame is not needed); 0 = own slice only, to be exchanged. */
-   MDH_OPT_IRRADIANCE_ALL = 10
+   MDH_OPT_IRRADIANCE_ALL = 10,
+   /* 1 = every screen pass also stores the window's RGBA8 pixels (mdh_swap_buffers) straight into
+    * pinned host memory, over PCIe, beside its float store: mdh_swap_buffers then has nothing to
+    * convert or copy.  0 (default) = mdh_swap_buffers converts and copies the framebuffer itself. */
+   MDH_OPT_WINDOW = 11
 };
 
 /* passes of Renderers.Render (madarch-renderers.adb:302-321) */
@@ -289,6 +293,19 @@ int32_t mdh_finish(mdh_renderer *r);
 /* replaces Swap_Buffers (renderers.adb:320): linear RGB floats, H*W*3, row 0 = top.
  * In a sharded run only this rank's tiles are written, the rest is 0. */
 int32_t mdh_read_framebuffer(mdh_renderer *r, float *rgb_out);
+/* Swap_Buffers itself (renderers.adb:320): what the reference's window shows.  The default framebuffer of
+ * that window is RGBA8 without sRGB encoding, so the last frame's colours are clamped to [0, 1] and
+ * converted to the nearest of 256 levels per channel (OpenGL 4.3 core 2.3.5.1; ties to even, NaN -> 0,
+ * alpha = 255), on the device.  mdh_swap_buffers enqueues that conversion and the copy into a pinned host
+ * buffer behind the frame and returns without waiting: frames stay in flight (MDH_OPT_FRAME_OVERLAP)
+ * and the copy of one frame runs beside the passes of the next.  mdh_front_buffer waits for the most
+ * recent swap only and returns its pixels: H*W*4 bytes, R G B A, row 0 = top, owned by the renderer
+ * and valid until the second next mdh_swap_buffers (with MDH_OPT_WINDOW also: until three more
+ * screen passes have been started); *swap_count (may be NULL) is the number of swaps so far.
+ * With MDH_OPT_WINDOW = 1 the screen pass has stored the pixels in host memory already and the swap
+ * only marks them.  In a sharded run only this rank's tiles are written, the rest is 0. */
+int32_t mdh_swap_buffers(mdh_renderer *r);
+int32_t mdh_front_buffer(mdh_renderer *r, const uint8_t **rgba, int64_t *swap_count);
 /* primary-ray geometry buffer (needs MDH_OPT_GBUFFER): per pixel the flat
  * primitive index of closest_primitive_info (-1 = miss), the march length t
  * and the number of SDF evaluations of the primary march */

@@ -20,7 +20,7 @@ MDH_E_INDEX, MDH_E_DEVICE, MDH_E_NO_DEVICE, MDH_E_STATE = 4, 5, 6, 7
 MDH_VEC3, MDH_FLOAT, MDH_INT = 0, 1, 2
 
 OPT_ATLAS_FORMAT, OPT_SCREEN_MODE, OPT_AO_STEPS, OPT_GBUFFER = 0, 1, 2, 3
-OPT_RANK, OPT_WORLD, OPT_TIMING, OPT_ADA_EVAL_DIV, OPT_FRAME_OVERLAP, OPT_JIT, OPT_IRRADIANCE_ALL = 4, 5, 6, 7, 8, 9, 10
+OPT_RANK, OPT_WORLD, OPT_TIMING, OPT_ADA_EVAL_DIV, OPT_FRAME_OVERLAP, OPT_JIT, OPT_IRRADIANCE_ALL, OPT_WINDOW = 4, 5, 6, 7, 8, 9, 10, 11
 
 PASS_RADIANCE, PASS_IRRADIANCE, PASS_VISIBILITY, PASS_SCATTERING, PASS_SCREEN = range(5)
 PASS_NAMES = ("radiance", "irradiance", "visibility", "scattering", "screen")
@@ -100,6 +100,8 @@ ABI = {
     "frame_end": (_I, [_P]),
     "finish": (_I, [_P]),
     "read_framebuffer": (_I, [_P, _P]),
+    "swap_buffers": (_I, [_P]),
+    "front_buffer": (_I, [_P, C.POINTER(_P), C.POINTER(C.c_int64)]),
     "read_gbuffer": (_I, [_P, _P, _P, _P]),
     "read_texture": (_I, [_P, _I, _P, _PI, _PI, _PI]),
     "write_texture": (_I, [_P, _I, _P, _I, _I, _I]),

@@ -218,6 +218,27 @@ struct mdh_renderer {
    float4 *d_scat2[2] = {nullptr, nullptr};
    float4 *d_fb2[2] = {nullptr, nullptr}; // two framebuffers: consecutive pipelined frames draw on two streams
    int fb_last = 0;                       // the one the most recent frame drew
+   // mdh_swap_buffers: a ring of RGBA8 copies of a framebuffer, each a device buffer (written on the stream that
+   // drew the frame) and a pinned host buffer (filled on a stream of its own, so no screen pass queues behind a copy)
+   static constexpr int FRONT_RING = 3;
+   unsigned *d_front[FRONT_RING] = {nullptr, nullptr, nullptr};
+   unsigned char *h_front[FRONT_RING] = {nullptr, nullptr, nullptr};
+   hipEvent_t ev_front[FRONT_RING] = {nullptr, nullptr, nullptr}; // slot's host copy done
+   hipEvent_t ev_packed = nullptr;
+   hipStream_t copy_stream = nullptr;
+   // MDH_OPT_WINDOW: the screen pass itself stores the RGBA8 pixels into a ring of pinned host buffers (over PCIe,
+   // no copy and no extra kernel); a swap then only marks the last one with an event
+   static constexpr int WIN_RING = 4;
+   int opt_window = 0;
+   unsigned *h_win[WIN_RING] = {nullptr, nullptr, nullptr, nullptr};
+   hipEvent_t ev_win[WIN_RING] = {nullptr, nullptr, nullptr, nullptr};
+   long long win_passes = 0; // screen passes that wrote a window slot; the last one wrote slot (win_passes - 1) % WIN_RING
+   bool win_valid = false;   // the last screen pass wrote a window slot
+   int win_owner[2] = {0, 1};
+   // what mdh_front_buffer returns: set by mdh_swap_buffers
+   const unsigned char *front_ptr = nullptr;
+   hipEvent_t front_ev = nullptr;
+   long long swaps = 0; // mdh_swap_buffers calls so far; the last one went to slot (swaps - 1) % FRONT_RING
    // (rank, world) whose tiles are the only non-zero pixels of a framebuffer; {0, 1}: every pixel may be set
    int fb_owner[2][2] = {{-1, -1}, {-1, -1}};
    // geometry buffer: [which framebuffer] x {index, t, steps} (int32 / float / int32 per pixel)
@@ -585,6 +606,17 @@ extern "C" int32_t mdh_destroy(mdh_renderer *r)
       for (int si = 0; si < 3; ++si)
          if (r->tab_done[q][si]) (void)hipEventDestroy(r->tab_done[q][si]);
    }
+   for (int q = 0; q < mdh_renderer::WIN_RING; ++q) {
+      if (r->h_win[q]) (void)hipHostFree(r->h_win[q]);
+      if (r->ev_win[q]) (void)hipEventDestroy(r->ev_win[q]);
+   }
+   if (r->copy_stream) { (void)hipStreamSynchronize(r->copy_stream); (void)hipStreamDestroy(r->copy_stream); }
+   if (r->ev_packed) (void)hipEventDestroy(r->ev_packed);
+   for (int q = 0; q < mdh_renderer::FRONT_RING; ++q) {
+      if (r->d_front[q]) (void)hipFree(r->d_front[q]);
+      if (r->h_front[q]) (void)hipHostFree(r->h_front[q]);
+      if (r->ev_front[q]) (void)hipEventDestroy(r->ev_front[q]);
+   }
    if (r->probe_stream) (void)hipStreamDestroy(r->probe_stream);
    if (r->alt_stream) (void)hipStreamDestroy(r->alt_stream);
    if (r->own_stream) (void)hipStreamDestroy(r->own_stream);
@@ -724,6 +756,7 @@ extern "C" int32_t mdh_set_option(mdh_renderer *r, int32_t option, int32_t value
    case MDH_OPT_ADA_EVAL_DIV: r->opt_ada_div = value ? 1 : 0; break;
    case MDH_OPT_JIT: r->opt_jit = value ? 1 : 0; break;
    case MDH_OPT_IRRADIANCE_ALL: r->opt_irr_all = value ? 1 : 0; break;
+   case MDH_OPT_WINDOW: r->opt_window = value ? 1 : 0; r->win_valid = false; break;
    case MDH_OPT_FRAME_OVERLAP: if (value < 0 || value > 2) return seterr(MDH_E_INVALID, "frame overlap is 0, 1 or 2"); r->opt_overlap = value; break;
    default: return seterr(MDH_E_INVALID, "unknown option");
    }
@@ -744,6 +777,7 @@ extern "C" int32_t mdh_get_option(mdh_renderer *r, int32_t option, int32_t *valu
    case MDH_OPT_FRAME_OVERLAP: *value = r->opt_overlap; break;
    case MDH_OPT_JIT: *value = r->opt_jit; break;
    case MDH_OPT_IRRADIANCE_ALL: *value = r->opt_irr_all; break;
+   case MDH_OPT_WINDOW: *value = r->opt_window; break;
    default: return seterr(MDH_E_INVALID, "unknown option");
    }
    return MDH_OK;
@@ -1085,6 +1119,31 @@ template <int PART> static void launch_screen_m(mdh_renderer *r, hipStream_t st,
    else launch_screen_g<PART, 2>(r, st, pr, vol, cam, a, blocks);
 }
 
+// MDH_OPT_WINDOW: the pinned host buffer the next screen pass stores the window's pixels in.  A ring: the pixels
+// of a frame stay untouched until WIN_RING - 1 further screen passes have been enqueued.
+static int window_slot(mdh_renderer *r, int rank, int world, unsigned **out)
+{
+   const size_t bytes = (size_t)r->W * r->H * 4;
+   const bool owner_changed = r->win_owner[0] != rank || r->win_owner[1] != world;
+   if (owner_changed) { // other ranks' tiles read 0, as in the framebuffer: clear every slot once nothing writes them any more
+      if (r->probe_stream) HIP_TRY(hipStreamSynchronize(r->probe_stream));
+      if (r->alt_stream) HIP_TRY(hipStreamSynchronize(r->alt_stream));
+      HIP_TRY(hipStreamSynchronize(r->stream));
+      for (int q = 0; q < mdh_renderer::WIN_RING; ++q)
+         if (r->h_win[q]) memset(r->h_win[q], 0, bytes);
+      r->win_owner[0] = rank; r->win_owner[1] = world;
+   }
+   const int slot = (int)(r->win_passes % mdh_renderer::WIN_RING);
+   if (!r->h_win[slot]) {
+      HIP_TRY(hipHostMalloc((void **)&r->h_win[slot], bytes, hipHostMallocDefault));
+      memset(r->h_win[slot], 0, bytes);
+   }
+   r->win_passes += 1;
+   r->win_valid = true;
+   *out = r->h_win[slot];
+   return MDH_OK;
+}
+
 // One pass on stream `st`.  The radiance pass reads the irradiance atlas of set `src` and writes the
 // radiance atlas of set `dst`; every other pass works on set `dst` (in place: src == dst == r->last).
 static int run_pass(mdh_renderer *r, int pass, hipStream_t st, int src, int dst, int fbix = -1)
@@ -1197,6 +1256,11 @@ static int run_pass(mdh_renderer *r, int pass, hipStream_t st, int src, int dst,
       a.rank = r->opt_rank; a.world = r->opt_world;
       a.ao_steps = r->opt_ao;
       a.fb = r->d_fb2[fbix]; a.gb_index = (int *)r->d_gb2[fbix][0]; a.gb_t = (float *)r->d_gb2[fbix][1]; a.gb_steps = (int *)r->d_gb2[fbix][2];
+      a.window = nullptr;
+      if (r->opt_window) { // the window's pixels straight into pinned host memory (mdh_swap_buffers)
+         int wrc = window_slot(r, a.rank, a.world, &a.window);
+         if (wrc != MDH_OK) return wrc;
+      }
       // other ranks' tiles read 0: cleared when the buffer last held another rank's (or a whole) frame, not every frame
       if (a.world > 1 && (r->fb_owner[fbix][0] != a.rank || r->fb_owner[fbix][1] != a.world))
          HIP_TRY(hipMemsetAsync(r->d_fb2[fbix], 0, (size_t)r->W * r->H * sizeof(float4), st));
@@ -1376,6 +1440,61 @@ extern "C" int32_t mdh_read_framebuffer(mdh_renderer *r, float *rgb_out)
    HIP_TRY(hipMemcpyAsync(tmp.data(), r->d_fb2[r->fb_last], px * sizeof(float4), hipMemcpyDeviceToHost, r->stream));
    HIP_TRY(hipStreamSynchronize(r->stream));
    for (size_t i = 0; i < px; ++i) { rgb_out[3 * i] = tmp[i].x; rgb_out[3 * i + 1] = tmp[i].y; rgb_out[3 * i + 2] = tmp[i].z; }
+   return MDH_OK;
+}
+// Swap_Buffers (renderers.adb:320): the last frame as the window's RGBA8 pixels in pinned host memory, without a
+// host wait, so that frames stay in flight.
+//  - MDH_OPT_WINDOW = 1: the screen pass has already stored them there itself (64 lanes x 4 bytes over PCIe beside
+//    its float4 store); the swap only records an event behind it.
+//  - otherwise: k_present converts the framebuffer on the stream that drew it and a copy stream takes the result
+//    to the host beside the passes of the next frame.
+extern "C" int32_t mdh_swap_buffers(mdh_renderer *r)
+{
+   if (!r) return seterr(MDH_E_INVALID, "null renderer");
+   if (r->in_frame) return seterr(MDH_E_STATE, "a frame is open");
+   HIP_TRY(hipSetDevice(r->device));
+   const size_t px = (size_t)r->W * r->H;
+   // framebuffer 1 is written from the alternate stream only; once the main stream has been ordered after it
+   // (join_main) the main stream holds its latest contents as well
+   const bool on_alt = r->fb_last == 1 && r->alt_pending;
+   hipStream_t st = on_alt ? r->alt_stream : r->stream;
+   if (r->opt_window && r->win_valid) {
+      const int slot = (int)((r->win_passes - 1) % mdh_renderer::WIN_RING);
+      if (!r->ev_win[slot]) HIP_TRY(hipEventCreateWithFlags(&r->ev_win[slot], hipEventDisableTiming));
+      HIP_TRY(hipEventRecord(r->ev_win[slot], st));
+      r->front_ptr = (const unsigned char *)r->h_win[slot];
+      r->front_ev = r->ev_win[slot];
+      r->swaps += 1;
+      return MDH_OK;
+   }
+   const int slot = (int)(r->swaps % mdh_renderer::FRONT_RING);
+   if (!r->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&r->copy_stream, hipStreamNonBlocking));
+   if (!r->ev_packed) HIP_TRY(hipEventCreateWithFlags(&r->ev_packed, hipEventDisableTiming));
+   if (!r->d_front[slot]) HIP_TRY(hipMalloc(&r->d_front[slot], px * 4));
+   if (!r->h_front[slot]) HIP_TRY(hipHostMalloc((void **)&r->h_front[slot], px * 4, hipHostMallocDefault));
+   if (!r->ev_front[slot]) HIP_TRY(hipEventCreateWithFlags(&r->ev_front[slot], hipEventDisableTiming));
+   else HIP_TRY(hipStreamWaitEvent(st, r->ev_front[slot], 0)); // the copy that read this slot's device buffer three swaps ago
+   hipLaunchKernelGGL(k_present, dim3((unsigned)((px + 255) / 256)), dim3(256), 0, st, r->d_fb2[r->fb_last], r->d_front[slot], (int)px);
+   HIP_TRY(hipGetLastError());
+   HIP_TRY(hipEventRecord(r->ev_packed, st));
+   HIP_TRY(hipStreamWaitEvent(r->copy_stream, r->ev_packed, 0));
+   HIP_TRY(hipMemcpyAsync(r->h_front[slot], r->d_front[slot], px * 4, hipMemcpyDeviceToHost, r->copy_stream));
+   HIP_TRY(hipEventRecord(r->ev_front[slot], r->copy_stream));
+   // framebuffer 1 read from the main stream: its next writer (the alternate stream) has to come after this
+   if (r->fb_last == 1 && !on_alt) r->main_dirty = true;
+   r->front_ptr = r->h_front[slot];
+   r->front_ev = r->ev_front[slot];
+   r->swaps += 1;
+   return MDH_OK;
+}
+extern "C" int32_t mdh_front_buffer(mdh_renderer *r, const uint8_t **rgba, int64_t *swap_count)
+{
+   if (!r || !rgba) return seterr(MDH_E_INVALID, "bad argument");
+   if (r->swaps == 0) return seterr(MDH_E_STATE, "no mdh_swap_buffers yet");
+   HIP_TRY(hipSetDevice(r->device));
+   HIP_TRY(hipEventSynchronize(r->front_ev));
+   *rgba = r->front_ptr;
+   if (swap_count) *swap_count = r->swaps;
    return MDH_OK;
 }
 extern "C" int32_t mdh_read_gbuffer(mdh_renderer *r, int32_t *index_out, float *t_out, int32_t *steps_out)

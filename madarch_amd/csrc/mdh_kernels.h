@@ -46,6 +46,9 @@
 #endif
 
 // ------------------------------------------------------------------------ screen pass
+// a colour as the RGBA8 default framebuffer of the reference's window holds it (see k_present below;
+// unorm8 is the atlas store's conversion, mdh_device.h)
+__device__ __forceinline__ unsigned pack_rgba8(float4 c) { return (unsigned)unorm8(c.x) | ((unsigned)unorm8(c.y) << 8) | ((unsigned)unorm8(c.z) << 16) | ((unsigned)unorm8(c.w) << 24); }
 struct ScreenArgs {
    int W, H;
    int tiles_x, n_tiles; // 8x8 tiles of the whole image
@@ -55,6 +58,7 @@ struct ScreenArgs {
    int *gb_index;
    float *gb_t;
    int *gb_steps;
+   unsigned *window; // MDH_OPT_WINDOW: the window's RGBA8 pixels (pinned host memory, written over PCIe), or null
 };
 
 // draw_screen.glsl:20-30.  One wavefront per 8x8 pixel tile: lane = (y & 7) * 8 + (x & 7);
@@ -112,6 +116,7 @@ __global__ __launch_bounds__(MDH_BLOCK, MDH_OCC(PART)) void k_screen(KScene sc, 
       c = F3(pow_(c.x / (c.x + 1.0f), 0.4545f), pow_(c.y / (c.y + 1.0f), 0.4545f), pow_(c.z / (c.z + 1.0f), 0.4545f));
    const size_t px = (size_t)j * a.W + i;
    a.fb[px] = make_float4(c.x, c.y, c.z, 1.0f);
+   if (a.window) a.window[px] = pack_rgba8(make_float4(c.x, c.y, c.z, 1.0f));
    if (GBUF) {
       a.gb_index[px] = ph.index;
       a.gb_t[px] = ph.t;
@@ -474,3 +479,16 @@ template <bool ADA_DIV> __global__ __launch_bounds__(64) void k_eval_distance(KS
    a.dist[q] = closest;
    if (a.normals) { a.normals[3 * q] = normal.x; a.normals[3 * q + 1] = normal.y; a.normals[3 * q + 2] = normal.z; }
 }
+
+// ---------------------------------------------------------------------- the window's pixels
+// What Swap_Buffers (renderers.adb:320) puts on screen: the screen pass writes float colours and
+// the default framebuffer of the reference's window is RGBA8 without sRGB encoding, so each
+// channel is clamped to [0, 1] and converted to the nearest of the 256 levels (OpenGL 4.3 core
+// section 2.3.5.1, round to nearest; ties to even; a NaN shows as 0).  16 bytes read and 4 written per pixel.
+#ifndef MDH_JIT
+__global__ __launch_bounds__(256) void k_present(const float4 *__restrict__ fb, unsigned *__restrict__ out, int n)
+{
+   const int q = blockIdx.x * 256 + threadIdx.x;
+   if (q < n) out[q] = pack_rgba8(fb[q]);
+}
+#endif

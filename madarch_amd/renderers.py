@@ -143,6 +143,22 @@ class Renderer:
         self._b.check(self._b.read_framebuffer(self._h, _fp(out)))
         return out
 
+    def Swap_Buffers(self):
+        """Glfw.Windows.Context.Swap_Buffers at the end of Render (madarch-renderers.adb:320): the last
+        frame becomes the window's RGBA8 pixels, converted on the device and copied to pinned host
+        memory behind the frame; returns without waiting, frames stay in flight."""
+        self._b.check(self._b.swap_buffers(self._h))
+
+    def Front_Buffer(self, copy=True):
+        """The pixels of the most recent Swap_Buffers: (H, W, 4) uint8, R G B A, row 0 = top.  Waits for
+        that swap only.  copy=False returns a view of the renderer's buffer, valid until the second
+        next Swap_Buffers."""
+        ptr, n = C.c_void_p(), C.c_int64()
+        self._b.check(self._b.front_buffer(self._h, C.byref(ptr), C.byref(n)))
+        buf = (C.c_uint8 * (self.Height * self.Width * 4)).from_address(ptr.value)
+        img = np.frombuffer(buf, dtype=np.uint8).reshape(self.Height, self.Width, 4)
+        return img.copy() if copy else img
+
     def Read_Gbuffer(self):
         idx = np.empty((self.Height, self.Width), dtype=np.int32)
         t = np.empty((self.Height, self.Width), dtype=np.float32)

@@ -123,9 +123,11 @@ struct orc_renderer {
    int part_cells, part_warnings;
    tex_t tex[4];
    float *fb;
+   uint8_t *front; /* orc_swap_buffers */
+   int64_t swaps;
    int32_t *gb_index, *gb_steps;
    float *gb_t;
-   int opt_atlas, opt_mode, opt_ao, opt_gbuffer, opt_rank, opt_world, opt_timing, opt_ada_div, opt_irr_all;
+   int opt_atlas, opt_mode, opt_ao, opt_gbuffer, opt_rank, opt_world, opt_timing, opt_ada_div, opt_irr_all, opt_window;
    int opt_sdf_mode, opt_threads;
    uint64_t sdf_evals; /* closest_primitive[_info] calls of the last pass set */
 };
@@ -817,11 +819,12 @@ static void tex_sample(const tex_t *t, float cx, float cy, float *out)
    for (int k = 0; k < t->c; ++k) out[k] = ((a[k] * w00 + b[k] * w10) + c[k] * w01) + d[k] * w11;
 }
 /* store with the texture's format: RGB8 clamps to [0,1] and rounds to 8 bits */
-static float unorm8(float x)
+static float unorm8_level(float x) /* 0 .. 255 */
 {
    if (x != x) return 0.0f;
-   return rintf(clamp_(x, 0.0f, 1.0f) * 255.0f) / 255.0f;
+   return rintf(clamp_(x, 0.0f, 1.0f) * 255.0f);
 }
+static float unorm8(float x) { return unorm8_level(x) / 255.0f; }
 static void tex_store(tex_t *t, int x, int y, const float *v)
 {
    float *p = t->data + ((size_t)y * t->w + x) * t->c;
@@ -1318,7 +1321,7 @@ int32_t orc_destroy(orc_renderer *r)
    for (int i = 0; i < 4; ++i) free(r->tex[i].data);
    for (int k = 0; k < MAX_KINDS; ++k)
       for (int q = 0; q < 3; ++q) { free(r->pk[k].x_code[q]); free(r->lk[k].x_code[q]); }
-   free(r->scene_ubo); free(r->part_table); free(r->fb); free(r->gb_index); free(r->gb_steps); free(r->gb_t);
+   free(r->scene_ubo); free(r->part_table); free(r->fb); free(r->front); free(r->gb_index); free(r->gb_steps); free(r->gb_t);
    free(r);
    return MDH_OK;
 }
@@ -1341,6 +1344,7 @@ int32_t orc_set_option(orc_renderer *r, int32_t option, int32_t value)
    case MDH_OPT_FRAME_OVERLAP: break; /* scheduling only: nothing to restate */
    case MDH_OPT_JIT: break;           /* how the kernels run the MDH_X programs: nothing to restate */
    case MDH_OPT_IRRADIANCE_ALL: r->opt_irr_all = value ? 1 : 0; break;
+   case MDH_OPT_WINDOW: r->opt_window = value ? 1 : 0; break; /* where the pixels are converted: no effect on them */
    case ORC_OPT_SDF_MODE: r->opt_sdf_mode = value; break;
    case ORC_OPT_THREADS: r->opt_threads = value; break;
    default: return seterr(MDH_E_INVALID, "unknown option");
@@ -1362,6 +1366,7 @@ int32_t orc_get_option(orc_renderer *r, int32_t option, int32_t *value)
    case MDH_OPT_FRAME_OVERLAP: *value = 0; break;
    case MDH_OPT_JIT: *value = 0; break;
    case MDH_OPT_IRRADIANCE_ALL: *value = r->opt_irr_all; break;
+   case MDH_OPT_WINDOW: *value = r->opt_window; break;
    case ORC_OPT_SDF_MODE: *value = r->opt_sdf_mode; break;
    case ORC_OPT_THREADS: *value = nthreads(r); break;
    default: return seterr(MDH_E_INVALID, "unknown option");
@@ -1507,6 +1512,31 @@ int32_t orc_read_framebuffer(orc_renderer *r, float *rgb_out)
 {
    if (!r || !rgb_out) return seterr(MDH_E_INVALID, "bad argument");
    memcpy(rgb_out, r->fb, (size_t)r->W * r->H * 3 * sizeof(float));
+   return MDH_OK;
+}
+/* Swap_Buffers (renderers.adb:320) into the RGBA8 default framebuffer of the reference's window: clamp to
+ * [0, 1], nearest of 256 levels (OpenGL 4.3 core 2.3.5.1; rintf = ties to even), NaN -> 0, alpha 255 */
+int32_t orc_swap_buffers(orc_renderer *r)
+{
+   if (!r) return seterr(MDH_E_INVALID, "null renderer");
+   size_t px = (size_t)r->W * r->H;
+   if (!r->front) r->front = (uint8_t *)malloc(px * 4);
+   if (!r->front) return seterr(MDH_E_INVALID, "out of memory");
+   for (size_t i = 0; i < px; ++i) {
+      r->front[4 * i] = (uint8_t)unorm8_level(r->fb[3 * i]); /* the conversion of the RGB8 atlas store above */
+      r->front[4 * i + 1] = (uint8_t)unorm8_level(r->fb[3 * i + 1]);
+      r->front[4 * i + 2] = (uint8_t)unorm8_level(r->fb[3 * i + 2]);
+      r->front[4 * i + 3] = 255;
+   }
+   r->swaps += 1;
+   return MDH_OK;
+}
+int32_t orc_front_buffer(orc_renderer *r, const uint8_t **rgba, int64_t *swap_count)
+{
+   if (!r || !rgba) return seterr(MDH_E_INVALID, "bad argument");
+   if (r->swaps == 0) return seterr(MDH_E_STATE, "no swap yet");
+   *rgba = r->front;
+   if (swap_count) *swap_count = r->swaps;
    return MDH_OK;
 }
 int32_t orc_read_gbuffer(orc_renderer *r, int32_t *index_out, float *t_out, int32_t *steps_out)

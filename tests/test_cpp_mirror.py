@@ -34,11 +34,16 @@ def test_cpp_example_matches_python_mirror(hip, tmp_path, name):
     from madarch_amd import examples
     build()
     W, H, frames = 72, 48, 2
-    path = str(tmp_path / (name + ".f32"))
-    out = subprocess.run([os.path.join(BIN, name), str(W), str(H), str(frames), path], capture_output=True, text=True, timeout=300)
+    path, ppm = str(tmp_path / (name + ".f32")), str(tmp_path / (name + ".ppm"))
+    out = subprocess.run([os.path.join(BIN, name), str(W), str(H), str(frames), path, ppm], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr
     got = np.fromfile(path, dtype=np.float32).reshape(H, W, 3)
     R = examples.SCENES[name](W, H, Binding=hip)
     for _ in range(frames):
         R.Render()
+        R.Swap_Buffers()
     assert same_bits(got, R.Read_Framebuffer())
+    raw = open(ppm, "rb").read()
+    head = ("P6\n%d %d\n255\n" % (W, H)).encode()
+    assert raw.startswith(head) and len(raw) == len(head) + W * H * 3
+    assert (np.frombuffer(raw[len(head):], dtype=np.uint8).reshape(H, W, 3) == R.Front_Buffer()[..., :3]).all()

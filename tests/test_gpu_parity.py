@@ -201,6 +201,94 @@ def test_pipelined_frames_across_screen_modes(hip):
             assert same_bits(a, b), "output %d differs at overlap level %d" % (i, level)
 
 
+def window_pixels(img):
+    """float framebuffer -> the RGBA8 default framebuffer of the reference's window (OpenGL 4.3 core 2.3.5.1)"""
+    with np.errstate(invalid="ignore"):
+        x = np.where(np.isnan(img), np.float32(0.0), img)
+        lv = np.rint(np.clip(x, np.float32(0.0), np.float32(1.0)) * np.float32(255.0)).astype(np.uint8)
+    return np.concatenate([lv, np.full(lv.shape[:2] + (1,), 255, np.uint8)], axis=2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("overlap,window", [(0, 0), (2, 0), (0, 1), (2, 1)])
+def test_swap_buffers_shows_each_frame(hip, orc, overlap, window):
+    """Swap_Buffers (renderers.adb:320): the RGBA8 pixels of every frame, converted on the device and copied
+    behind the frame while later frames are already in flight, are the conversion of that frame's colours bit
+    for bit -- whichever stream and framebuffer drew it -- and match the oracle's window."""
+    frames = 7
+    R = make("global_illumination", 200, 120, hip, probes=SMALL_PROBES)
+    R.Set_Option(B.OPT_GBUFFER, 0)
+    R.Set_Option(B.OPT_FRAME_OVERLAP, overlap)
+    R.Set_Option(B.OPT_WINDOW, window)  # 1: the screen pass stores the pixels in pinned host memory itself
+    S = make("global_illumination", 200, 120, hip, probes=SMALL_PROBES)  # the same frames, read one by one
+    S.Set_Option(B.OPT_GBUFFER, 0)
+    S.Set_Option(B.OPT_FRAME_OVERLAP, 0)
+    O = make("global_illumination", 200, 120, orc, probes=SMALL_PROBES)
+    views, want, late = [], [], None
+    for f in range(frames):
+        for X in (R, S, O):
+            X.Set_Camera_Position((2.0 + 0.07 * f, 2.0, 0.02 * f))
+            X.Render()
+        want.append(window_pixels(S.Read_Framebuffer()))
+        R.Swap_Buffers()
+        if f % 3 == 0:
+            views.append((f, R.Front_Buffer()))
+        elif f % 3 == 1:  # a view of the renderer's buffer stays valid until the second next swap ...
+            late = (f, R.Front_Buffer(copy=False))
+        else:             # ... so it is still this after one more frame and swap
+            views.append((late[0], late[1].copy()))
+    views.append((frames - 1, R.Front_Buffer()))
+    assert len(views) == 6
+    for f, got in views:
+        assert got.shape == (120, 200, 4) and got.dtype == np.uint8
+        assert (got == want[f]).all(), "frame %d" % f
+    # the oracle's window for the last frame
+    O.Swap_Buffers()
+    o = O.Front_Buffer()
+    assert (o == window_pixels(O.Read_Framebuffer())).all()
+    d = np.abs(o.astype(np.int16) - want[-1].astype(np.int16))
+    assert d.max() <= 1 and (d == 0).mean() > 0.999
+    # a single pass outside a frame, then a swap: ordered after everything in flight
+    R.Render()
+    R.Render()
+    R.Render_Pass(B.PASS_SCREEN)
+    R.Swap_Buffers()
+    assert (R.Front_Buffer() == window_pixels(R.Read_Framebuffer())).all()
+    # switching where the conversion happens, between frames; a swap shows the frame before it, not later ones
+    R.Set_Option(B.OPT_WINDOW, 1 - window)
+    R.Render()
+    R.Swap_Buffers()
+    shown = window_pixels(R.Read_Framebuffer())
+    R.Set_Camera_Position((2.3, 2.1, 0.0))
+    R.Render()
+    assert (R.Front_Buffer() == shown).all()
+    R.Swap_Buffers()
+    assert (R.Front_Buffer() == window_pixels(R.Read_Framebuffer())).all()
+    assert not (R.Front_Buffer() == shown).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("window", [0, 1])
+def test_swap_buffers_of_a_rank(hip, window):
+    """In a sharded run the window of a rank holds its own 8x8 tiles and zeros elsewhere, like its framebuffer,
+    also after the rank changes."""
+    R = make("global_illumination", 120, 72, hip, probes=SMALL_PROBES)
+    R.Set_Option(B.OPT_WINDOW, window)
+    R.Render()
+    R.Swap_Buffers()
+    whole = R.Front_Buffer()
+    ty, tx = np.meshgrid(np.arange(72) // 8, np.arange(120) // 8, indexing="ij")
+    for rank in (1, 2, 0):
+        R.Set_Option(B.OPT_WORLD, 3)
+        R.Set_Option(B.OPT_RANK, rank)
+        for _ in range(5):  # round the ring of host buffers
+            R.Render_Pass(B.PASS_SCREEN)
+        R.Swap_Buffers()
+        mine = (ty * 15 + tx) % 3 == rank
+        px = R.Front_Buffer()
+        assert (px[mine] == whole[mine]).all() and (px[~mine] == 0).all()
+
+
 @pytest.mark.gpu
 def test_ball_game_frames(hip, orc):
     """examples/ball_game: per frame a physics step (Eval_Distance_To against planes and boxes, Set_Primitive per

@@ -50,6 +50,17 @@ def _api_checks(binding):
     assert e.value.status == B.MDH_E_UNSUPPORTED_KIND
     # Update_Partitioning is a no-op when partitioning is disabled (renderers.adb:763-765)
     R.Update_Partitioning(renderers.CPU_Best)
+    # Swap_Buffers (renderers.adb:320): the window's RGBA8 pixels; nothing to show before the first swap
+    with pytest.raises(B.MadarchError) as e:
+        R.Front_Buffer()
+    assert e.value.status == B.MDH_E_STATE
+    R.Render()
+    R.Swap_Buffers()
+    px, img = R.Front_Buffer(), R.Read_Framebuffer()
+    assert px.shape == (img.shape[0], img.shape[1], 4) and px.dtype == np.uint8 and (px[..., 3] == 255).all()
+    with np.errstate(invalid="ignore"):
+        want = np.rint(np.clip(np.where(np.isnan(img), 0, img), 0, 1) * np.float32(255)).astype(np.uint8)
+    assert (px[..., :3] == want).all()
 
 
 def test_api_behaviour_oracle(orc):
