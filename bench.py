@@ -131,8 +131,8 @@ def cpu_baseline(workload):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="global_illumination_1080p_ddgi8x8x8", choices=sorted(WORKLOADS))
     ap.add_argument("--atlas", default="rgb8", choices=("rgb8", "f32"))
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -8,7 +8,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/profiles_$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-python3 $ROOT/bench.py --steps 40 --warmup 8 > $OUT/bench.json 2> $OUT/bench.err || exit 1
+python3 $ROOT/bench.py > $OUT/bench.json 2> $OUT/bench.err || exit 1
 B="python3 $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-serial-segment"
 # kernel durations of the default (pipelined) schedule and of the serial one
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $B > /dev/null 2>&1
