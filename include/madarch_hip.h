@@ -268,7 +268,9 @@ int32_t mdh_set_camera_position(mdh_renderer *r, const float p[3]);
 int32_t mdh_set_camera_orientation(mdh_renderer *r, const float m_colmajor[9]);
 
 /* Renderers.Update_Partitioning (madarch-renderers.adb:757-775);
- * method: 0 CPU_Best, 1 CPU_Fast, 2 GPU_Fast (renderers.ads:93) */
+ * method: 0 CPU_Best, 1 CPU_Fast, 2 GPU_Fast (renderers.ads:93).  All three builders run on
+ * the device; the call enqueues the build and returns -- frames in flight keep the table they
+ * were launched with, everything launched afterwards uses the new one. */
 int32_t mdh_update_partitioning(mdh_renderer *r, int32_t method);
 
 /* Renderers.Render (madarch-renderers.adb:302-321): enqueues all passes of one
@@ -342,7 +344,8 @@ int32_t mdh_probe_stream(mdh_renderer *r, void **stream);
 /* Renderers.Eval_Distance_To (madarch-renderers.adb:499-526), batched: for
  * each of n points the closest distance over the listed kinds (initial
  * closest 1.0e10) and the normal of the arg-min primitive.  n = 1 is the
- * reference call. */
+ * reference call.  Runs beside the frames in flight (a stream of its own) and
+ * returns when its own results are on the host. */
 int32_t mdh_eval_distance_to(mdh_renderer *r, int32_t n, const float *points_xyz,
                              const int32_t *kind_ixs, int32_t n_kinds, float *normals_xyz_out,
                              float *dist_out);
@@ -361,7 +364,8 @@ int32_t mdh_read_scene_buffer(mdh_renderer *r, void *out, int32_t nbytes);
 /* partition table as int32 [cell][n_prim_kinds counts + index_count indices] */
 int32_t mdh_read_partitioning(mdh_renderer *r, int32_t *out, int32_t n_ints);
 /* cells of the last Update_Partitioning whose candidate list overflowed Index_Count
- * (the reference prints "Warning : partition size too small", renderers.adb:593-598) */
+ * (the reference prints "Warning : partition size too small", renderers.adb:593-598);
+ * waits for that build */
 int32_t mdh_partition_warnings(mdh_renderer *r);
 
 const char *mdh_last_error(void);

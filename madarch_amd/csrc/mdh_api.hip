@@ -183,14 +183,29 @@ struct mdh_renderer {
    float4 *d_table_ring[TAB_RING] = {nullptr, nullptr, nullptr, nullptr};
    float4 *h_table_ring[TAB_RING] = {nullptr, nullptr, nullptr, nullptr}; // pinned
    int tab_slot = 0;
-   hipEvent_t tab_done[TAB_RING][3] = {{nullptr}};
-   bool tab_used[TAB_RING][3] = {{false}};
+   static const int NSTREAMS = 4; // main, probe, alternate, query (stream_index)
+   hipEvent_t tab_done[TAB_RING][NSTREAMS] = {{nullptr}};
+   bool tab_used[TAB_RING][NSTREAMS] = {{false}};
    hipEvent_t ev_table = nullptr;       // recorded after the last upload, on table_stream
    hipStream_t table_stream = nullptr;
-   unsigned long long table_version = 0, tab_seen[3] = {0, 0, 0}; // per stream (main, probe, alternate): has it waited for ev_table
+   unsigned long long table_version = 0, tab_seen[NSTREAMS] = {0, 0, 0, 0}; // per stream: has it waited for ev_table
    size_t table_cap = 0;
    bool table_dirty = true;
-   int *d_part = nullptr, *d_warn = nullptr;
+   // The space-partition table, in a ring like the scene table: Update_Partitioning builds into the next buffer
+   // on the stream that uses it first and returns; frames in flight keep the buffer they were launched with
+   // (KScene::part_table travels by value).  The builders' warning count comes back through pinned memory
+   // and is waited for only when somebody asks (mdh_partition_warnings).
+   static const int PART_RING = 4;
+   int *d_part_ring[PART_RING] = {nullptr, nullptr, nullptr, nullptr};
+   int part_slot = 0;
+   hipEvent_t part_done[PART_RING][NSTREAMS] = {{nullptr}};
+   bool part_used[PART_RING][NSTREAMS] = {{false}};
+   hipEvent_t ev_part = nullptr, ev_warn = nullptr; // the last build, the last read-back of its warning count
+   hipStream_t part_stream = nullptr;
+   unsigned long long part_version = 0, part_seen[NSTREAMS] = {0, 0, 0, 0};
+   int *d_warn = nullptr, *h_warn = nullptr;
+   bool warn_pending = false;
+   hipStream_t query_stream = nullptr; // Eval_Distance_To: beside the frames in flight, not behind them
    float *d_query = nullptr; // Eval_Distance_To: points, normals, distances of the largest batch so far
    size_t query_cap = 0;
    // Two sets of probe atlases.  `last` is the set the most recent frame wrote: every read, write and
@@ -310,7 +325,7 @@ static float i_as_f(int i) { float f; memcpy(&f, &i, 4); return f; }
 
 // Repack the std140 images into the float4 table the kernels stage into LDS
 // (layout in mdh_device.h) and refresh the SGPR header.
-static int stream_index(const mdh_renderer *r, hipStream_t st) { return st == r->probe_stream ? 1 : (st == r->alt_stream ? 2 : 0); }
+static int stream_index(const mdh_renderer *r, hipStream_t st) { return st == r->probe_stream ? 1 : (st == r->alt_stream ? 2 : (st == r->query_stream ? 3 : 0)); }
 // before a kernel that stages the table is launched on `st`: order `st` after the table's upload
 static int table_acquire(mdh_renderer *r, hipStream_t st)
 {
@@ -318,6 +333,10 @@ static int table_acquire(mdh_renderer *r, hipStream_t st)
    if (r->tab_seen[si] != r->table_version) {
       if (st != r->table_stream) HIP_TRY(hipStreamWaitEvent(st, r->ev_table, 0));
       r->tab_seen[si] = r->table_version;
+   }
+   if (r->part.enable && r->part_seen[si] != r->part_version) { // ... and after the build of the partition table
+      if (st != r->part_stream) HIP_TRY(hipStreamWaitEvent(st, r->ev_part, 0));
+      r->part_seen[si] = r->part_version;
    }
    return MDH_OK;
 }
@@ -327,6 +346,10 @@ static int table_release(mdh_renderer *r, hipStream_t st)
    const int si = stream_index(r, st);
    HIP_TRY(hipEventRecord(r->tab_done[r->tab_slot][si], st));
    r->tab_used[r->tab_slot][si] = true;
+   if (r->part.enable) {
+      HIP_TRY(hipEventRecord(r->part_done[r->part_slot][si], st));
+      r->part_used[r->part_slot][si] = true;
+   }
    return MDH_OK;
 }
 
@@ -505,11 +528,11 @@ static int commit_scene(mdh_renderer *r, hipStream_t up)
          if (r->h_table_ring[q]) HIP_TRY(hipHostFree(r->h_table_ring[q]));
          HIP_TRY(hipMalloc(&r->d_table_ring[q], r->table_cap * sizeof(float4)));
          HIP_TRY(hipHostMalloc((void **)&r->h_table_ring[q], r->table_cap * sizeof(float4), hipHostMallocDefault));
-         for (int si = 0; si < 3; ++si) r->tab_used[q][si] = false;
+         for (int si = 0; si < mdh_renderer::NSTREAMS; ++si) r->tab_used[q][si] = false;
       }
    }
    const int ns = (r->tab_slot + 1) % mdh_renderer::TAB_RING;
-   for (int si = 0; si < 3; ++si)
+   for (int si = 0; si < mdh_renderer::NSTREAMS; ++si)
       if (r->tab_used[ns][si]) { HIP_TRY(hipEventSynchronize(r->tab_done[ns][si])); r->tab_used[ns][si] = false; }
    memcpy(r->h_table_ring[ns], t.data(), t.size() * sizeof(float4));
    HIP_TRY(hipMemcpyAsync(r->d_table_ring[ns], r->h_table_ring[ns], t.size() * sizeof(float4), hipMemcpyHostToDevice, up));
@@ -532,7 +555,7 @@ static int commit_scene(mdh_renderer *r, hipStream_t up)
       s.part_inv_sp[a] = pow2 ? 1.0f / r->pg_spacing[a] : 0.0f;
       if (!pow2) s.part_sp_pow2 = 0;
    }
-   s.part_table = r->d_part;
+   s.part_table = r->d_part_ring[r->part_slot];
    r->table_dirty = false;
    return MDH_OK;
 }
@@ -594,7 +617,8 @@ extern "C" int32_t mdh_destroy(mdh_renderer *r)
    if (r->probe_stream) (void)hipStreamSynchronize(r->probe_stream);
    if (r->alt_stream) (void)hipStreamSynchronize(r->alt_stream);
    if (r->stream) (void)hipStreamSynchronize(r->stream);
-   void *ptrs[] = {r->d_table_ring[0], r->d_table_ring[1], r->d_table_ring[2], r->d_table_ring[3], r->d_part, r->d_warn, r->d_query, r->d_rad2[0], r->d_irr2[0], r->d_rad2[1], r->d_irr2[1], r->d_vis2[0], r->d_scat2[0], r->d_vis2[1], r->d_scat2[1], r->d_fb2[0], r->d_fb2[1], r->d_gb2[0][0], r->d_gb2[0][1], r->d_gb2[0][2], r->d_gb2[1][0], r->d_gb2[1][1], r->d_gb2[1][2]};
+   if (r->query_stream) (void)hipStreamSynchronize(r->query_stream);
+   void *ptrs[] = {r->d_table_ring[0], r->d_table_ring[1], r->d_table_ring[2], r->d_table_ring[3], r->d_part_ring[0], r->d_part_ring[1], r->d_part_ring[2], r->d_part_ring[3], r->d_warn, r->d_query, r->d_rad2[0], r->d_irr2[0], r->d_rad2[1], r->d_irr2[1], r->d_vis2[0], r->d_scat2[0], r->d_vis2[1], r->d_scat2[1], r->d_fb2[0], r->d_fb2[1], r->d_gb2[0][0], r->d_gb2[0][1], r->d_gb2[0][2], r->d_gb2[1][0], r->d_gb2[1][1], r->d_gb2[1][2]};
    for (void *p : ptrs)
       if (p) (void)hipFree(p);
    for (auto &p : r->pending) { (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1); }
@@ -603,9 +627,16 @@ extern "C" int32_t mdh_destroy(mdh_renderer *r)
       if (e) (void)hipEventDestroy(e);
    for (int q = 0; q < mdh_renderer::TAB_RING; ++q) {
       if (r->h_table_ring[q]) (void)hipHostFree(r->h_table_ring[q]);
-      for (int si = 0; si < 3; ++si)
+      for (int si = 0; si < mdh_renderer::NSTREAMS; ++si)
          if (r->tab_done[q][si]) (void)hipEventDestroy(r->tab_done[q][si]);
    }
+   for (int q = 0; q < mdh_renderer::PART_RING; ++q)
+      for (int si = 0; si < mdh_renderer::NSTREAMS; ++si)
+         if (r->part_done[q][si]) (void)hipEventDestroy(r->part_done[q][si]);
+   if (r->ev_part) (void)hipEventDestroy(r->ev_part);
+   if (r->ev_warn) (void)hipEventDestroy(r->ev_warn);
+   if (r->h_warn) (void)hipHostFree(r->h_warn);
+   if (r->query_stream) (void)hipStreamDestroy(r->query_stream);
    for (int q = 0; q < mdh_renderer::WIN_RING; ++q) {
       if (r->h_win[q]) (void)hipHostFree(r->h_win[q]);
       if (r->ev_win[q]) (void)hipEventDestroy(r->ev_win[q]);
@@ -701,8 +732,12 @@ extern "C" int32_t mdh_create(int32_t width, int32_t height, const mdh_scene_des
       TRY_OR_FAIL(hipStreamCreateWithPriority(&r->probe_stream, hipStreamNonBlocking, prio));
       TRY_OR_FAIL(hipStreamCreateWithFlags(&r->alt_stream, hipStreamNonBlocking));
       for (hipEvent_t *e : {&r->ev_screen[0], &r->ev_screen[1], &r->ev_probe[0], &r->ev_probe[1], &r->ev_join, &r->ev_join_alt, &r->ev_table}) TRY_OR_FAIL(hipEventCreateWithFlags(e, hipEventDisableTiming));
+      TRY_OR_FAIL(hipStreamCreateWithFlags(&r->query_stream, hipStreamNonBlocking));
+      for (hipEvent_t *e : {&r->ev_part, &r->ev_warn}) TRY_OR_FAIL(hipEventCreateWithFlags(e, hipEventDisableTiming));
       for (int q = 0; q < mdh_renderer::TAB_RING; ++q)
-         for (int si = 0; si < 3; ++si) TRY_OR_FAIL(hipEventCreateWithFlags(&r->tab_done[q][si], hipEventDisableTiming));
+         for (int si = 0; si < mdh_renderer::NSTREAMS; ++si) TRY_OR_FAIL(hipEventCreateWithFlags(&r->tab_done[q][si], hipEventDisableTiming));
+      for (int q = 0; q < mdh_renderer::PART_RING; ++q)
+         for (int si = 0; si < mdh_renderer::NSTREAMS; ++si) TRY_OR_FAIL(hipEventCreateWithFlags(&r->part_done[q][si], hipEventDisableTiming));
    }
    if ((rc = alloc_atlases(r)) != MDH_OK) return fail(rc);
    size_t px = (size_t)width * height;
@@ -713,6 +748,8 @@ extern "C" int32_t mdh_create(int32_t width, int32_t height, const mdh_scene_des
    for (int s = 0; s < 2; ++s)
       for (int q = 0; q < 3; ++q) TRY_OR_FAIL(hipMalloc(&r->d_gb2[s][q], px * 4));
    TRY_OR_FAIL(hipMalloc(&r->d_warn, 4));
+   TRY_OR_FAIL(hipHostMalloc((void **)&r->h_warn, 4, hipHostMallocDefault));
+   *r->h_warn = 0;
    size_t vis_n = (size_t)vol->visibility_resolution[0] * vol->visibility_resolution[1] * vol->visibility_resolution[2] * 3;
    size_t scat_n = (size_t)vol->scattering_resolution[0] * vol->scattering_resolution[1];
    for (int s = 0; s < 2; ++s) {
@@ -723,8 +760,10 @@ extern "C" int32_t mdh_create(int32_t width, int32_t height, const mdh_scene_des
    }
    if (r->part.enable) {
       size_t n = (size_t)r->part_cells * (r->npk + r->part.index_count);
-      TRY_OR_FAIL(hipMalloc(&r->d_part, n * 4));
-      TRY_OR_FAIL(hipMemsetAsync(r->d_part, 0, n * 4, r->stream));
+      for (int q = 0; q < mdh_renderer::PART_RING; ++q) {
+         TRY_OR_FAIL(hipMalloc(&r->d_part_ring[q], n * 4));
+         TRY_OR_FAIL(hipMemsetAsync(r->d_part_ring[q], 0, n * 4, r->stream));
+      }
    }
    TRY_OR_FAIL(hipStreamSynchronize(r->stream));
 #undef TRY_OR_FAIL
@@ -1077,10 +1116,27 @@ extern "C" int32_t mdh_update_partitioning(mdh_renderer *r, int32_t method)
    if (!r) return seterr(MDH_E_INVALID, "null renderer");
    if (!r->part.enable) return MDH_OK; // renderers.adb:763-765
    if (method < 0 || method > 2) return seterr(MDH_E_INVALID, "bad method");
-   int rc = ensure_committed(r);
+   if (r->in_frame) return seterr(MDH_E_STATE, "a frame is open");
+   // The build goes where the table is used first -- the probe stream when frames are kept in flight -- into the
+   // next buffer of the ring, and nothing waits on the host: frames in flight keep their buffer, later launches
+   // on any stream are ordered after ev_part (table_acquire).
+   const bool piped = r->opt_overlap && r->stream == r->own_stream && r->opt_mode == 0;
+   hipStream_t up = piped ? r->probe_stream : r->stream;
+   int rc = ensure_committed(r, up);
    if (rc != MDH_OK) return rc;
-   if ((rc = join_main(r)) != MDH_OK) return rc;
-   r->main_dirty = true;
+   if (!piped) {
+      if ((rc = join_main(r)) != MDH_OK) return rc;
+      r->main_dirty = true;
+   }
+   const int sup = stream_index(r, up);
+   const int ns = (r->part_slot + 1) % mdh_renderer::PART_RING;
+   for (int si = 0; si < mdh_renderer::NSTREAMS; ++si)
+      if (r->part_used[ns][si]) { // the last kernels that read that buffer (four builds ago)
+         if (si != sup) HIP_TRY(hipStreamWaitEvent(up, r->part_done[ns][si], 0));
+         r->part_used[ns][si] = false;
+      }
+   // the warning counter is shared by consecutive builds: behind the previous build and its read-back
+   if (r->part_version && r->part_stream != up) HIP_TRY(hipStreamWaitEvent(up, r->ev_warn, 0));
    PartBuildArgs a;
    a.method = method;
    const int *d = r->part.grid_dimensions;
@@ -1092,18 +1148,30 @@ extern "C" int32_t mdh_update_partitioning(mdh_renderer *r, int32_t method)
       a.off[i] = method == 2 ? r->pg_offset[i] : r->part.grid_offset[i];
    }
    a.gpu_diag = r->part_gpu_diag;
-   a.table = r->d_part;
+   a.table = r->d_part_ring[ns];
    a.warnings = r->d_warn;
-   HIP_TRY(hipMemsetAsync(r->d_warn, 0, 4, r->stream));
-   int cells = a.gx * a.gy * a.gz;
+   // The builders write a cell's counts and the candidates it found, nothing else: entries behind them and cells
+   // outside the builder's grid (GPU_Fast on odd dimensions) keep what the table held before, in the
+   // reference's single buffer.  So the next buffer starts as a copy of the current one (tens of KiB).
+   const size_t total = (size_t)r->part_cells * (r->npk + r->part.index_count);
+   const int cells = a.gx * a.gy * a.gz;
+   if ((rc = table_acquire(r, up)) != MDH_OK) return rc; // (also orders `up` after the previous build)
+   HIP_TRY(hipMemcpyAsync(r->d_part_ring[ns], r->d_part_ring[r->part_slot], total * 4, hipMemcpyDeviceToDevice, up));
+   HIP_TRY(hipMemsetAsync(r->d_warn, 0, 4, up));
    if (cells > 0) {
-      if ((rc = table_acquire(r, r->stream)) != MDH_OK) return rc;
-      hipLaunchKernelGGL(k_partition_build, dim3((cells + 63) / 64), dim3(64), lds_bytes(r), r->stream, r->ks, a);
+      hipLaunchKernelGGL(k_partition_build, dim3((cells + 63) / 64), dim3(64), lds_bytes(r), up, r->ks, a);
       HIP_TRY(hipGetLastError());
-      if ((rc = table_release(r, r->stream)) != MDH_OK) return rc;
    }
-   HIP_TRY(hipMemcpyAsync(&r->part_warnings, r->d_warn, 4, hipMemcpyDeviceToHost, r->stream));
-   HIP_TRY(hipStreamSynchronize(r->stream));
+   if ((rc = table_release(r, up)) != MDH_OK) return rc; // (the copy read the current buffer)
+   HIP_TRY(hipMemcpyAsync(r->h_warn, r->d_warn, 4, hipMemcpyDeviceToHost, up));
+   HIP_TRY(hipEventRecord(r->ev_warn, up));
+   r->warn_pending = true;
+   HIP_TRY(hipEventRecord(r->ev_part, up));
+   r->part_stream = up;
+   ++r->part_version;
+   r->part_seen[sup] = r->part_version;
+   r->part_slot = ns;
+   r->ks.part_table = r->d_part_ring[ns];
    return MDH_OK;
 }
 
@@ -1690,9 +1758,10 @@ extern "C" int32_t mdh_set_stream(mdh_renderer *r, void *stream)
    if (rc != MDH_OK) return rc;
    if (r->probe_stream) HIP_TRY(hipStreamSynchronize(r->probe_stream));
    if (r->alt_stream) HIP_TRY(hipStreamSynchronize(r->alt_stream));
+   if (r->query_stream) HIP_TRY(hipStreamSynchronize(r->query_stream));
    r->stream = stream ? (hipStream_t)stream : r->own_stream;
    // the new main stream has not waited for anything: uploads and earlier work are complete (synchronised above)
-   for (int si = 0; si < 3; ++si) r->tab_seen[si] = r->table_version;
+   for (int si = 0; si < mdh_renderer::NSTREAMS; ++si) { r->tab_seen[si] = r->table_version; r->part_seen[si] = r->part_version; }
    return MDH_OK;
 }
 
@@ -1704,27 +1773,29 @@ extern "C" int32_t mdh_eval_distance_to(mdh_renderer *r, int32_t n, const float 
    for (int i = 0; i < n_kinds; ++i)
       if (kind_ixs[i] < 0 || kind_ixs[i] >= r->npk) return seterr(MDH_E_INVALID, "bad kind index");
    if (n == 0) return MDH_OK;
-   int rc = ensure_committed(r);
+   // on a stream of its own: the query waits for the table it reads, not for the frames in flight
+   hipStream_t qs = r->query_stream;
+   int rc = ensure_committed(r, qs);
    if (rc != MDH_OK) return rc;
    if ((size_t)n > r->query_cap) { // 7 floats per query: point, normal, distance
-      if (r->d_query) { HIP_TRY(hipStreamSynchronize(r->stream)); HIP_TRY(hipFree(r->d_query)); r->d_query = nullptr; }
+      if (r->d_query) { HIP_TRY(hipStreamSynchronize(qs)); HIP_TRY(hipFree(r->d_query)); r->d_query = nullptr; }
       r->query_cap = (size_t)n < 256 ? 256 : (size_t)n;
       HIP_TRY(hipMalloc(&r->d_query, r->query_cap * 7 * sizeof(float)));
    }
    float *d_pts = r->d_query, *d_n = d_pts + 3 * r->query_cap, *d_d = d_n + 3 * r->query_cap;
-   HIP_TRY(hipMemcpyAsync(d_pts, pts, (size_t)n * 12, hipMemcpyHostToDevice, r->stream));
+   HIP_TRY(hipMemcpyAsync(d_pts, pts, (size_t)n * 12, hipMemcpyHostToDevice, qs));
    EvalArgs a;
    a.n = n; a.n_kinds = n_kinds;
    for (int i = 0; i < MDH_MAX_KINDS; ++i) { a.kinds[i] = i < n_kinds ? kind_ixs[i] : 0; a.host_count[i] = r->host_count[i]; }
    a.pts = d_pts; a.normals = d_n; a.dist = d_d;
-   if ((rc = table_acquire(r, r->stream)) != MDH_OK) return rc;
-   if (r->opt_ada_div) hipLaunchKernelGGL(k_eval_distance<true>, dim3((n + 63) / 64), dim3(64), lds_bytes(r), r->stream, r->ks, a);
-   else hipLaunchKernelGGL(k_eval_distance<false>, dim3((n + 63) / 64), dim3(64), lds_bytes(r), r->stream, r->ks, a);
+   if ((rc = table_acquire(r, qs)) != MDH_OK) return rc;
+   if (r->opt_ada_div) hipLaunchKernelGGL(k_eval_distance<true>, dim3((n + 63) / 64), dim3(64), lds_bytes(r), qs, r->ks, a);
+   else hipLaunchKernelGGL(k_eval_distance<false>, dim3((n + 63) / 64), dim3(64), lds_bytes(r), qs, r->ks, a);
    HIP_TRY(hipGetLastError());
-   if ((rc = table_release(r, r->stream)) != MDH_OK) return rc;
-   HIP_TRY(hipMemcpyAsync(dist_out, d_d, (size_t)n * 4, hipMemcpyDeviceToHost, r->stream));
-   if (normals_out) HIP_TRY(hipMemcpyAsync(normals_out, d_n, (size_t)n * 12, hipMemcpyDeviceToHost, r->stream));
-   HIP_TRY(hipStreamSynchronize(r->stream));
+   if ((rc = table_release(r, qs)) != MDH_OK) return rc;
+   HIP_TRY(hipMemcpyAsync(dist_out, d_d, (size_t)n * 4, hipMemcpyDeviceToHost, qs));
+   if (normals_out) HIP_TRY(hipMemcpyAsync(normals_out, d_n, (size_t)n * 12, hipMemcpyDeviceToHost, qs));
+   HIP_TRY(hipStreamSynchronize(qs));
    return MDH_OK;
 }
 
@@ -1779,11 +1850,22 @@ extern "C" int32_t mdh_read_partitioning(mdh_renderer *r, int32_t *out, int32_t 
    size_t total = (size_t)r->part_cells * (r->npk + r->part.index_count);
    if ((size_t)n_ints != total) return seterr(MDH_E_INVALID, "size mismatch");
    HIP_TRY(hipSetDevice(r->device));
-   HIP_TRY(hipMemcpyAsync(out, r->d_part, total * 4, hipMemcpyDeviceToHost, r->stream));
-   HIP_TRY(hipStreamSynchronize(r->stream));
+   if (r->part_version) HIP_TRY(hipEventSynchronize(r->ev_part)); // the last build
+   HIP_TRY(hipMemcpy(out, r->d_part_ring[r->part_slot], total * 4, hipMemcpyDeviceToHost));
    return MDH_OK;
 }
-extern "C" int32_t mdh_partition_warnings(mdh_renderer *r) { return r ? r->part_warnings : 0; }
+// the warnings of the last Update_Partitioning (scenes.adb:861-867 prints them): waits for that build only
+extern "C" int32_t mdh_partition_warnings(mdh_renderer *r)
+{
+   if (!r) return 0;
+   if (r->warn_pending) {
+      (void)hipSetDevice(r->device);
+      if (hipEventSynchronize(r->ev_warn) != hipSuccess) return -1;
+      r->part_warnings = *r->h_warn;
+      r->warn_pending = false;
+   }
+   return r->part_warnings;
+}
 
 #ifdef MDH_DIAG
 // debug: read and reset the lane-utilisation counters of mdh_march.h

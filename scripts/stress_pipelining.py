@@ -15,7 +15,8 @@ seeds, n_ops = int(sys.argv[1]) if len(sys.argv) > 1 else 6, int(sys.argv[2]) if
 
 def drive(seed, overlap):
     rng = np.random.default_rng(seed)
-    scene = ("global_illumination", "light_shafts")[seed % 2]
+    scene = ("global_illumination", "light_shafts", "simple_scene")[seed % 3]  # the last one with the space partition
+    part = scene == "simple_scene"
     W, H = (int(v) for v in os.environ.get("STRESS_SIZE", "256x144").split("x"))
     R = make(scene, W, H, hb, probes=SMALL_PROBES if os.environ.get("STRESS_PROBES", "small") == "small" else None)
     R.Set_Option(B.OPT_GBUFFER, int(rng.integers(0, 2)))
@@ -30,9 +31,15 @@ def drive(seed, overlap):
             R.Set_Camera_Position(tuple(rng.uniform(0.5, 5.0, 3)))
         elif op < 74:
             R.Set_Primitive(spheres.Sphere, 1, spheres.Create(tuple(rng.uniform(1.0, 5.0, 3)), float(rng.uniform(0.4, 1.2)), 3))
+            if part and rng.integers(0, 4):  # a rebuilt partition table rides along with the frames in flight
+                R.Update_Partitioning(int(rng.integers(0, 3)))
+                if rng.integers(0, 4) == 0:
+                    out.append(np.array([R.Partition_Warnings()], dtype=np.int32))
         elif op < 76:  # a burst of edits, each committed by a query or a frame: wraps the ring of table buffers
             for _ in range(int(rng.integers(3, 9))):
                 R.Set_Primitive(spheres.Sphere, 1, spheres.Create(tuple(rng.uniform(1.0, 5.0, 3)), float(rng.uniform(0.4, 1.2)), 3))
+                if part:
+                    R.Update_Partitioning(int(rng.integers(0, 3)))
                 if rng.integers(0, 2):
                     out.append(R.Eval_Distances_To(rng.uniform(0.0, 6.0, (17, 3)).astype(np.float32), [spheres.Sphere])[0])
                 else:
@@ -48,11 +55,16 @@ def drive(seed, overlap):
             R.Write_Texture(B.TEX_IRRADIANCE, t * np.float32(0.5))
         elif op < 97:
             R.Set_Option(B.OPT_GBUFFER, int(rng.integers(0, 2)))
-        elif op < 99:
+        elif op < 98:
             R.Finish()
+        elif op < 99:
+            if part:
+                out.append(R.Read_Partitioning())
         else:
             R.Set_Option(B.OPT_SCREEN_MODE, int(rng.integers(0, 3)))
     out.append(R.Read_Framebuffer()); out.append(R.Read_Texture(B.TEX_RADIANCE)); out.append(R.Read_Texture(B.TEX_IRRADIANCE))
+    if part:
+        out.append(R.Read_Partitioning())
     return out
 
 
