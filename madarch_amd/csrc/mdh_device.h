@@ -540,9 +540,19 @@ MDH_DEV float prim_dist(int type, int slot, f3 x)
 #ifndef MDH_CULL
 #define MDH_CULL 1
 #endif
+#ifndef MDH_SDF_PREFETCH
+#define MDH_SDF_PREFETCH 1
+#endif
 template <bool CUSTOM> MDH_DEV float closest_primitive(const KScene &sc, f3 x)
 {
    float closest = sc.max_dist;
+#if MDH_SDF_PREFETCH
+   // the first sphere and the first box are on their way from LDS while the planes are evaluated: a wavefront that
+   // has a SIMD to itself (the tail of every pass, and whole passes of a sharded frame) has nothing else to
+   // hide that latency behind.  (With a count of 0 the words read belong to the next kind and are not used.)
+   const float4 pf_s = s_tab[sc.tslot[PK_SPHERE]];
+   const float4 pf_b0 = s_tab[sc.tslot[PK_BOX]], pf_b1 = s_tab[sc.tslot[PK_BOX] + 1];
+#endif
    if (sc.n_axis > 0) { // six adds for all axis-aligned planes together
       closest = min_(closest, min_(x.x + sc.axis_off[0], -x.x + sc.axis_off[1]));
       closest = min_(closest, min_(x.y + sc.axis_off[2], -x.y + sc.axis_off[3]));
@@ -555,30 +565,42 @@ template <bool CUSTOM> MDH_DEV float closest_primitive(const KScene &sc, f3 x)
    }
    {
       const int n = sc.tcount[PK_SPHERE], s0 = sc.tslot[PK_SPHERE];
+#define MDH_SPHERE_STEP(a_)                                                                  \
+      do {                                                                                   \
+         const float4 a = (a_);                                                              \
+         const float d2 = dot2(xyz(a) - x); /* sd_sphere = sqrt(d2) - a.w (spheres.ads:13-14) */ \
+         const float tsum = closest + a.w;                                                   \
+         const bool need = !(tsum < 0.0f) && !(d2 > (tsum * tsum) * 1.000001f);              \
+         if (!MDH_CULL || __ballot(need) != 0ull) closest = min_(closest, sqrt_(d2) - a.w);  \
+      } while (0)
+#if MDH_SDF_PREFETCH
+      if (n > 0) MDH_SPHERE_STEP(pf_s);
 #pragma unroll 1
-      for (int i = 0; i < n; ++i) {
-         const float4 a = s_tab[s0 + i];
-         const float d2 = dot2(xyz(a) - x); // sd_sphere = sqrt(d2) - a.w (spheres.ads:13-14)
-#if MDH_CULL
-         const float tsum = closest + a.w;
-         const bool need = !(tsum < 0.0f) && !(d2 > (tsum * tsum) * 1.000001f);
-         if (__ballot(need) == 0ull) continue;
+      for (int i = 1; i < n; ++i) MDH_SPHERE_STEP(s_tab[s0 + i]);
+#else
+#pragma unroll 1
+      for (int i = 0; i < n; ++i) MDH_SPHERE_STEP(s_tab[s0 + i]);
 #endif
-         closest = min_(closest, sqrt_(d2) - a.w);
-      }
+#undef MDH_SPHERE_STEP
    }
    {
       const int n = sc.tcount[PK_BOX], s0 = sc.tslot[PK_BOX];
+#define MDH_BOX_STEP(c_, e_)                                                                 \
+      do {                                                                                   \
+         const f3 q = abs3(xyz(c_) - x) - xyz(e_); /* boxes.adb:10 */                        \
+         const float m = max_(q.x, max_(q.y, q.z));                                          \
+         const float thr = closest > 0.0f ? closest * 1.000001f : closest;                   \
+         if (!MDH_CULL || __ballot(!(m > thr)) != 0ull) closest = min_(closest, length(max3s(q, 0.0f)) + min_(m, 0.0f)); \
+      } while (0)
+#if MDH_SDF_PREFETCH
+      if (n > 0) MDH_BOX_STEP(pf_b0, pf_b1);
 #pragma unroll 1
-      for (int i = 0; i < n; ++i) {
-         const f3 q = abs3(xyz(s_tab[s0 + 2 * i]) - x) - xyz(s_tab[s0 + 2 * i + 1]); // boxes.adb:10
-         const float m = max_(q.x, max_(q.y, q.z));
-#if MDH_CULL
-         const float thr = closest > 0.0f ? closest * 1.000001f : closest;
-         if (__ballot(!(m > thr)) == 0ull) continue;
+      for (int i = 1; i < n; ++i) MDH_BOX_STEP(s_tab[s0 + 2 * i], s_tab[s0 + 2 * i + 1]);
+#else
+#pragma unroll 1
+      for (int i = 0; i < n; ++i) MDH_BOX_STEP(s_tab[s0 + 2 * i], s_tab[s0 + 2 * i + 1]);
 #endif
-         closest = min_(closest, length(max3s(q, 0.0f)) + min_(m, 0.0f));
-      }
+#undef MDH_BOX_STEP
    }
    {
       const int n = sc.tcount[PK_TRIANGLE], s0 = sc.tslot[PK_TRIANGLE];
