@@ -543,15 +543,26 @@ MDH_DEV float prim_dist(int type, int slot, f3 x)
 #ifndef MDH_SDF_PREFETCH
 #define MDH_SDF_PREFETCH 1
 #endif
-template <bool CUSTOM> MDH_DEV float closest_primitive(const KScene &sc, f3 x)
+// The first sphere and the first box of the table in registers: a march loop that evaluates the SDF many times
+// reads them from LDS once (MDH_SDF_REGS) instead of once per evaluation.  (With a count of 0 the words
+// belong to the next kind and are not used.)
+struct SdfRegs { float4 s, b0, b1; };
+MDH_DEV SdfRegs sdf_regs(const KScene &sc)
+{
+   SdfRegs r;
+   r.s = s_tab[sc.tslot[PK_SPHERE]];
+   r.b0 = s_tab[sc.tslot[PK_BOX]]; r.b1 = s_tab[sc.tslot[PK_BOX] + 1];
+   return r;
+}
+template <bool CUSTOM> MDH_DEV float closest_primitive(const KScene &sc, f3 x, const SdfRegs *regs = nullptr)
 {
    float closest = sc.max_dist;
 #if MDH_SDF_PREFETCH
    // the first sphere and the first box are on their way from LDS while the planes are evaluated: a wavefront that
    // has a SIMD to itself (the tail of every pass, and whole passes of a sharded frame) has nothing else to
-   // hide that latency behind.  (With a count of 0 the words read belong to the next kind and are not used.)
-   const float4 pf_s = s_tab[sc.tslot[PK_SPHERE]];
-   const float4 pf_b0 = s_tab[sc.tslot[PK_BOX]], pf_b1 = s_tab[sc.tslot[PK_BOX] + 1];
+   // hide that latency behind.
+   const float4 pf_s = regs ? regs->s : s_tab[sc.tslot[PK_SPHERE]];
+   const float4 pf_b0 = regs ? regs->b0 : s_tab[sc.tslot[PK_BOX]], pf_b1 = regs ? regs->b1 : s_tab[sc.tslot[PK_BOX] + 1];
 #endif
    if (sc.n_axis > 0) { // six adds for all axis-aligned planes together
       closest = min_(closest, min_(x.x + sc.axis_off[0], -x.x + sc.axis_off[1]));
@@ -780,6 +791,13 @@ template <int PART> MDH_DEV float sdf(const KScene &sc, f3 x)
    int dummy;
    if (PART & MDH_PF_PART) return partitioning_lookup<false, (PART & MDH_PF_CUSTOM) != 0>(sc, x, dummy);
    return closest_primitive<(PART & MDH_PF_CUSTOM) != 0>(sc, x);
+}
+// the same with the first sphere and box already in registers (sdf_regs)
+template <int PART> MDH_DEV float sdf(const KScene &sc, f3 x, const SdfRegs &regs)
+{
+   int dummy;
+   if (PART & MDH_PF_PART) return partitioning_lookup<false, (PART & MDH_PF_CUSTOM) != 0>(sc, x, dummy);
+   return closest_primitive<(PART & MDH_PF_CUSTOM) != 0>(sc, x, &regs);
 }
 template <int PART> MDH_DEV float sdf_info(const KScene &sc, f3 x, int &index)
 {

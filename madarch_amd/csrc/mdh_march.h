@@ -112,9 +112,12 @@ template <int PART> MDH_DEV bool march_plain(const KScene &sc, f3 o, f3 d, float
    int n = 0;
    bool h = false;
    float total = 0.0f;
+   // the first sphere and box stay in registers for the whole march (measured: +0.7 %; the same in the shadow,
+   // visibility-queue and occlusion marches ±0, in the per-corner visibility march -1 %: register pressure)
+   const SdfRegs regs = sdf_regs(sc);
    while (total < tmax) {
       MDH_DIAG_STEP(0);
-      float dist = sdf<PART>(sc, o + d * total);
+      float dist = sdf<PART>(sc, o + d * total, regs);
       ++n;
       if (dist < MDH_EPS) { h = true; break; }
       total += dist;
