@@ -162,10 +162,12 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
+        # (no device_id: a communicator bound eagerly to the device runs its collectives 70 us per frame slower
+        #  beside the renderer's streams -- measured with scripts/rccl_host_cost.py; the device is set above)
         if world > 1:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl")
         else:
-            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", rank=0, world_size=1)
 
     R = make_renderer(args.workload, B.hip_binding(), device=local_rank)
     R.Set_Option(B.OPT_ATLAS_FORMAT, 0 if args.atlas == "rgb8" else 1)
@@ -182,7 +184,7 @@ def main():
         R.Finish()
         torch.cuda.synchronize()
         if world > 1:
-            dist.barrier()
+            dist.barrier(device_ids=[local_rank])
 
     animate = None
     if args.animate_light and WORKLOADS[args.workload][0] == "global_illumination":
@@ -215,7 +217,7 @@ def main():
     R.Finish()
     torch.cuda.synchronize()
     if world > 1:
-        dist.barrier()
+        dist.barrier(device_ids=[local_rank])
     dt = time.perf_counter() - t0
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
@@ -284,7 +286,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.workload)
         print(json.dumps(out), flush=True)
     if dist is not None:
-        dist.barrier()
+        dist.barrier(device_ids=[local_rank])
         dist.destroy_process_group()
 
 

@@ -55,7 +55,8 @@ class _DevicePtr:
 
 
 class DeviceExchange:
-    """In-place RCCL all-gather on the probe-major atlases (backend "nccl" = RCCL).
+    """In-place RCCL all-gather on the probe-major atlases (backend "nccl" = RCCL):
+    output = the whole atlas, input = this rank's slice of it where it lies.
     The collective is issued with the renderer's probe stream as torch's current
     stream, so it is ordered between the probe passes of the open frame and the
     screen pass of the previous frame keeps running beside it."""
@@ -66,7 +67,7 @@ class DeviceExchange:
         self.device = device
         self._streams = {}
         self._views = {}
-        self._stage = {}
+        self._slices = {}
 
     def _stream(self, renderer):
         # asked per call: the library runs the probe passes on its probe stream when frames are kept in
@@ -95,14 +96,15 @@ class DeviceExchange:
         full, off, own, total = self._view(renderer, tex)
         if own * world != total:
             raise ValueError("probe count %d is not divisible by the world size %d" % (renderer.Probe_Total(), world))
+        # in place: the rank's slice is the input where it lies in the output (sendbuff = recvbuff + rank * count,
+        # the in-place form the collective defines) -- no staging copy, one kernel on the probe chain
+        key = (full.data_ptr(), off, own)
+        mine = self._slices.get(key)
+        if mine is None:
+            if len(self._slices) >= 16:
+                self._slices.clear()
+            mine = self._slices[key] = full[off:off + own]
         with self.torch.cuda.stream(self._stream(renderer)):
-            # the rank's slice goes through a small staging tensor: the gather then never reads and writes the same
-            # bytes, whatever the backend makes of aliased buffers (a device copy of at most a few hundred KiB)
-            key = (tex, own)
-            if key not in self._stage:
-                self._stage[key] = self.torch.empty(own, dtype=full.dtype, device=self.device)
-            mine = self._stage[key]
-            mine.copy_(full[off:off + own], non_blocking=True)
             self.dist.all_gather_into_tensor(full, mine, group=self.group)
 
 

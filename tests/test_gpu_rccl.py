@@ -23,7 +23,7 @@ from helpers import SMALL_PROBES, make, same_bits, snapshot
 from madarch_amd import _binding as B, sharding
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29611")
 torch.cuda.set_device(0)
-dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+dist.init_process_group("nccl", rank=0, world_size=1)
 hip = B.hip_binding()
 want = snapshot(make("global_illumination", 64, 40, hip, probes=SMALL_PROBES), 2)
 R = make("global_illumination", 64, 40, hip, probes=SMALL_PROBES)
