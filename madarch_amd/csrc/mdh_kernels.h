@@ -29,6 +29,17 @@
 #else
 #define MDH_OCC(PART) (((PART) & MDH_PF_CUSTOM) ? 2 : MDH_WAVES_PER_SIMD)
 #endif
+// The radiance kernel is built for more wavefronts per SIMD than the screen kernel: beside two screen passes it then
+// takes less of the register file (measured with frames in flight: 5 -> 3775, 6 -> 3800, 7 -> 3830, 8 -> 3845 Mpix/s;
+// at 8 a wavefront alone on its SIMD, as in an 8-way sharded frame, runs 5 % slower on its spills: 7).
+#ifndef MDH_RAD_WAVES_PER_SIMD
+#define MDH_RAD_WAVES_PER_SIMD 7
+#endif
+#ifdef MDH_JIT
+#define MDH_OCC_RAD(PART) MDH_RAD_WAVES_PER_SIMD
+#else
+#define MDH_OCC_RAD(PART) (((PART) & MDH_PF_CUSTOM) ? 2 : MDH_RAD_WAVES_PER_SIMD)
+#endif
 #ifndef MDH_RAD_QVIS
 #define MDH_RAD_QVIS 1 // probe-visibility rays through the wave's ray queue (mdh_march.h: queued_visibility)
 #endif
@@ -132,7 +143,7 @@ __global__ __launch_bounds__(MDH_BLOCK, MDH_OCC(PART)) void k_screen(KScene sc, 
 // ---------------------------------------------------------------------- radiance pass
 // compute_probe_radiance.glsl:16-27.  One wavefront per 8x8 texel tile of one probe's
 // octahedral map; all 64 rays of a wave leave the same probe position.
-template <int PART> __global__ __launch_bounds__(MDH_BLOCK, MDH_OCC(PART)) void k_radiance(KScene sc, KProbes pr)
+template <int PART> __global__ __launch_bounds__(MDH_BLOCK, MDH_OCC_RAD(PART)) void k_radiance(KScene sc, KProbes pr)
 {
    stage_table(sc);
    const int per_probe = pr.rres * pr.rres;
