@@ -203,10 +203,13 @@ MDH_DEV int queued_visibility(const KScene &sc, const KProbes &pr, float *pk, f3
    int head = 0, job = -1;
    float total = 0.0f, vmax = 0.0f;
    f3 o = F3(0.0f, 0.0f, 0.0f), d = F3(0.0f, 0.0f, 0.0f);
+   // only the lanes whose point was hit are here: a wave with fewer of them than the refill threshold (rays that
+   // left an open scene) must still start its queue
+   const int refill = min((int)MDH_QVIS_REFILL, (int)__popcll(__ballot(true)));
    for (;;) {
       const unsigned long long idle = __ballot(job < 0);
       const int n_idle = __popcll(idle);
-      if (head < njobs && n_idle >= MDH_QVIS_REFILL) {
+      if (head < njobs && n_idle >= refill) {
          if (job < 0) {
             const int my = head + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(idle >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)idle, 0u));
             if (my < njobs) {

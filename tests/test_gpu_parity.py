@@ -62,6 +62,79 @@ def test_empty_scene_and_sky(hip, orc):
     assert (outs[0]["gb_index"] == -1).all()
 
 
+@pytest.mark.parametrize("partitioned,method", [(False, 0), (True, 0), (True, 2)])
+@pytest.mark.parametrize("W,H", [(1, 1), (9, 3), (40, 24)])
+def test_every_kind_at_its_declared_maximum(hip, orc, partitioned, method, W, H):
+    """Every built-in kind filled to its declared count, two kinds of lights at theirs, images down to one
+    pixel: spheres, tilted and axis planes, boxes and triangles through the whole frame, with and without
+    the space partition (a small Index_Count makes cells overflow and cut their lists)."""
+    from madarch_amd import materials, scenes, windows
+    from madarch_amd.lights import point_lights, spot_lights
+    from madarch_amd.primitives import boxes, planes, spheres, triangles
+    outs = []
+    for b in (hip, orc):
+        part = scenes.Partitioning_Settings(Enable=partitioned, Index_Count=6, Grid_Dimensions=(5, 5, 7), Grid_Spacing=(2.0, 2.0, 2.0),
+                                            Grid_Offset=(-2.0, -2.0, -7.0))
+        scene = scenes.Compile([(spheres.Sphere, 5), (planes.Plane, 7), (boxes.Box, 3), (triangles.Triangle, 2)],
+                               [(point_lights.Point_Light, 2), (spot_lights.Spot_Light, 4)], Partitioning=part)
+        R = renderers.Create(windows.Open(W, H), scene, Probes=SMALL_PROBES, Volumetrics=renderers.No_Volumetrics, Binding=b)
+        for m, alb in enumerate(((0.8, 0.8, 0.8), (0.9, 0.1, 0.1), (0.1, 0.1, 0.9), (0.2, 0.2, 0.2))):
+            R.Set_Material(m, materials.Create(alb, 0.9 if m == 3 else 0.0, 0.15 if m == 3 else 0.6))
+        for n, o, m in (((0, 1, 0), 1.0, 0), ((0, -1, 0), 7.0, 0), ((1, 0, 0), 1.0, 1), ((-1, 0, 0), 7.0, 2), ((0, 0, 1), 6.0, 0),
+                        ((0, 0, -1), 7.0, 0), ((0.6, 0.8, 0.0), 0.5, 1)):  # the last one is not axis-aligned
+            R.Add_Primitive(planes.Plane, planes.Create(n, o, m))
+        for i in range(5):
+            R.Add_Primitive(spheres.Sphere, spheres.Create((1.0 + 1.1 * i, 0.5 + 0.7 * i, 3.0 + 0.5 * i), 0.45 + 0.1 * i, 3 if i % 2 else 1))
+        for i in range(3):
+            R.Add_Primitive(boxes.Box, boxes.Create((1.0 + 2.0 * i, 0.0, 5.0 - i), (0.6, 0.9 - 0.2 * i, 0.5), 2 if i else 3))
+        R.Add_Primitive(triangles.Triangle, triangles.Create((0.0, 3.0, 5.0), (2.0, 5.0, 5.5), (3.0, 3.0, 4.0), 1))
+        R.Add_Primitive(triangles.Triangle, triangles.Create((4.0, 1.0, 2.5), (5.5, 2.0, 3.0), (5.0, 0.5, 3.5), 3))
+        R.Set_Light(1, point_lights.Point_Light, point_lights.Create((1.0, 5.0, 1.0), (0.7, 0.7, 0.6)))
+        R.Set_Light(2, point_lights.Point_Light, point_lights.Create((5.0, 2.0, 0.0), (0.2, 0.3, 0.6)))
+        # Set_Light leaves the kind's count AND the total at Index (renderers.adb:478-482): four spot entries make the
+        # total 4, which the walk by cumulative counts reads as the two point lights and the first two spots
+        for i, (pos, d, ap, col) in enumerate((((3.5, 6.0, 2.0), (0.0, -1.0, 0.2), 0.9, (0.9, 0.9, 0.8)), ((0.0, 1.0, -3.0), (0.3, 0.1, 1.0), 0.5, (0.5, 0.2, 0.2)),
+                                               ((6.0, 6.0, 6.0), (-0.5, -0.7, -0.5), 0.7, (0.1, 0.5, 0.1)), ((2.0, 6.5, 5.0), (0.0, -1.0, 0.0), 0.4, (0.3, 0.3, 0.3)))):
+            R.Set_Light(i + 1, spot_lights.Spot_Light, spot_lights.Create(pos, d, ap, col))
+        R.Set_Camera_Position((2.5, 2.0, -2.0))
+        R.Set_Option(B.OPT_GBUFFER, 1)
+        if partitioned:
+            R.Update_Partitioning(method)
+        out = snapshot(R, 2)
+        if partitioned:
+            out["partition"], out["warnings"] = R.Read_Partitioning(), np.array([R.Partition_Warnings()])
+        outs.append(out)
+    assert_parity(*outs)
+    if partitioned:
+        assert same_bits(outs[0]["partition"], outs[1]["partition"]) and same_bits(outs[0]["warnings"], outs[1]["warnings"])
+        if method == 0:
+            assert outs[0]["warnings"][0] > 0  # Index_Count = 6 is too small for this room
+
+
+def test_open_scene_with_few_hits_per_wavefront(hip, orc):
+    """A floor, two spheres and the sky: most probe rays of a wavefront leave the scene and only a few lanes
+    shade a point (the radiance pass's visibility queue has to start with any number of lanes)."""
+    from madarch_amd import materials, scenes, windows
+    from madarch_amd.lights import point_lights
+    from madarch_amd.primitives import planes, spheres
+    outs = []
+    for b in (hip, orc):
+        scene = scenes.Compile([(spheres.Sphere, 4), (planes.Plane, 2)], [(point_lights.Point_Light, 2)],
+                               Partitioning=scenes.Partitioning_Settings(Enable=False))
+        R = renderers.Create(windows.Open(48, 32), scene, Probes=SMALL_PROBES, Volumetrics=renderers.No_Volumetrics, Binding=b)
+        R.Set_Material(0, materials.Create((0.7, 0.7, 0.7), 0.0, 0.6))
+        R.Set_Material(1, materials.Create((0.9, 0.2, 0.1), 0.8, 0.2))
+        R.Add_Primitive(planes.Plane, planes.Create((0, 1, 0), 1.0, 0))
+        R.Add_Primitive(spheres.Sphere, spheres.Create((2.0, 0.5, 4.0), 1.2, 1))
+        R.Add_Primitive(spheres.Sphere, spheres.Create((4.5, 2.5, 3.0), 0.6, 0))
+        R.Set_Light(1, point_lights.Point_Light, point_lights.Create((3.0, 6.0, 1.0), (0.9, 0.9, 0.8)))
+        R.Set_Camera_Position((2.5, 1.5, -1.0))
+        R.Set_Option(B.OPT_GBUFFER, 1)
+        outs.append(snapshot(R, 3))
+    assert_parity(*outs)
+    assert 0.05 < (outs[0]["gb_index"] == -1).mean() < 0.95  # sky and hits both
+
+
 def test_set_primitive_updates_device_tables(hip, orc):
     """Set_Primitive between frames (what the examples' loops do with lights) reaches the kernels."""
     from madarch_amd.primitives import spheres
