@@ -8,6 +8,10 @@ SEED = 0x4D414441  # "MADA", SURVEY.md section 8d
 
 SMALL_PROBES = renderers.Probe_Settings(Radiance_Resolution=16, Irradiance_Resolution=8, Probe_Count=(6, 6),
                                         Grid_Dimensions=(4, 3, 3), Grid_Spacing=(2.0, 3.0, 3.0))
+# nothing a power of two, more than one wavefront of probes and not a multiple of 64: the divisions by the
+# resolutions and the probe counts, the last partial wavefront of the radiance pass
+ODD_PROBES = renderers.Probe_Settings(Radiance_Resolution=12, Irradiance_Resolution=6, Probe_Count=(15, 5),
+                                      Grid_Dimensions=(5, 5, 3), Grid_Spacing=(1.6, 1.9, 2.5))
 SMALL_VOL = renderers.Volumetrics_Settings(Visibility_Resolution=(20, 20, 24), Scattering_Resolution=(24, 24))
 
 

@@ -5,7 +5,7 @@ same frame, and size-independent properties are checked on the whole frame."""
 import numpy as np
 import pytest
 
-from helpers import SMALL_PROBES, assert_parity, make, same_bits, snapshot
+from helpers import ODD_PROBES, SMALL_PROBES, assert_parity, make, same_bits, snapshot
 from madarch_amd import _binding as B
 from madarch_amd import examples, renderers, sharding
 
@@ -19,6 +19,9 @@ CASES = [  # scene, W, H, mode, atlas, frames, probes
     ("global_illumination", 61, 37, 0, 0, 2, SMALL_PROBES),  # ragged: sizes that are no multiple of 8
     ("light_shafts", 64, 48, 0, 0, 2, SMALL_PROBES),      # config 4: volumetrics
     ("simple_scene", 64, 48, 0, 0, 2, SMALL_PROBES),      # partitioned scene through the full path
+    ("global_illumination", 56, 40, 0, 0, 3, ODD_PROBES),  # 75 probes, 12 / 6 texel tiles, 15 x 5 atlas: no power of two anywhere
+    ("global_illumination", 56, 40, 0, 1, 2, ODD_PROBES),
+    ("light_shafts", 48, 40, 0, 0, 2, ODD_PROBES),
 ]
 
 
@@ -147,29 +150,40 @@ def test_set_primitive_updates_device_tables(hip, orc):
     assert_parity(*outs)
 
 
-def test_sharded_frame_equals_whole_frame(hip):
-    """Two ranks' worth of tiles and probe slices, exchanged through the host, give the whole
-    frame bit for bit (the multi-GPU path with both 'ranks' on this one GPU)."""
-    whole = snapshot(make("global_illumination", 72, 40, hip, probes=SMALL_PROBES), 2)
-    Rs = [make("global_illumination", 72, 40, hip, probes=SMALL_PROBES) for _ in range(2)]
+@pytest.mark.parametrize("probes,N,irr_all", [(SMALL_PROBES, 2, 1), (ODD_PROBES, 4, 0), (ODD_PROBES, 3, 1)])
+def test_sharded_frame_equals_whole_frame(hip, probes, N, irr_all):
+    """N ranks' worth of tiles and probe slices (uneven when N does not divide the probe count), exchanged
+    through the host, give the whole frame bit for bit (the multi-GPU path with all 'ranks' on this one GPU)."""
+    whole = snapshot(make("global_illumination", 72, 40, hip, probes=probes), 2)
+    Rs = [make("global_illumination", 72, 40, hip, probes=probes) for _ in range(N)]
     for r, R in enumerate(Rs):
         R.Set_Option(B.OPT_RANK, r)
-        R.Set_Option(B.OPT_WORLD, 2)
+        R.Set_Option(B.OPT_WORLD, N)
+        R.Set_Option(B.OPT_IRRADIANCE_ALL, irr_all)
     P = Rs[0].Probe_Total()
+    bounds = [(P * r // N, P * (r + 1) // N) for r in range(N)]
+
+    def exchange(tex):
+        parts = [R.Read_Atlas_Slice(tex, lo, hi - lo) for R, (lo, hi) in zip(Rs, bounds)]
+        for r, R in enumerate(Rs):
+            for q, (lo, hi) in enumerate(bounds):
+                if q != r:
+                    R.Write_Atlas_Slice(tex, lo, parts[q])
     for _ in range(2):
-        for p, tex in ((B.PASS_RADIANCE, B.TEX_RADIANCE), (B.PASS_IRRADIANCE, B.TEX_IRRADIANCE)):
-            for R in Rs:
-                R.Render_Pass(p)
-            lo = Rs[0].Read_Atlas_Slice(tex, 0, P // 2)
-            hi = Rs[1].Read_Atlas_Slice(tex, P // 2, P - P // 2)
-            Rs[0].Write_Atlas_Slice(tex, P // 2, hi)
-            Rs[1].Write_Atlas_Slice(tex, 0, lo)
+        for R in Rs:
+            R.Render_Pass(B.PASS_RADIANCE)
+        exchange(B.TEX_RADIANCE)
+        for R in Rs:
+            R.Render_Pass(B.PASS_IRRADIANCE)
+        if not irr_all:  # own probes only: the slices have to travel as well
+            exchange(B.TEX_IRRADIANCE)
         for R in Rs:
             R.Render_Pass(B.PASS_SCREEN)
-    img = Rs[0].Read_Framebuffer() + Rs[1].Read_Framebuffer()
+    img = sum(R.Read_Framebuffer() for R in Rs)
     assert same_bits(img, whole["image"])
-    assert same_bits(Rs[0].Read_Texture(B.TEX_IRRADIANCE), whole["irradiance"])
-    assert same_bits(Rs[1].Read_Texture(B.TEX_RADIANCE), whole["radiance"])
+    for R in Rs:
+        assert same_bits(R.Read_Texture(B.TEX_IRRADIANCE), whole["irradiance"])
+        assert same_bits(R.Read_Texture(B.TEX_RADIANCE), whole["radiance"])
 
 
 @pytest.mark.parametrize("irr_all", [1, 0])
