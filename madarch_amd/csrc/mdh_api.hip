@@ -519,7 +519,9 @@ static int commit_scene(mdh_renderer *r, hipStream_t up)
    for (int k = 0; k < 256; k += 4) t.push_back(mk4((float)k / 255.0f, (float)(k + 1) / 255.0f, (float)(k + 2) / 255.0f, (float)(k + 3) / 255.0f));
    memcpy(t.data(), H, sizeof H);
    s.table_f4 = (int)t.size();
-   if ((size_t)s.table_f4 * 16 > 64 * 1024) return seterr(MDH_E_INVALID, "scene tables exceed the 64 KiB LDS budget of a workgroup");
+   // (the march kernels park MDH_PARK_DWORDS floats per thread behind the table, lds_bytes_march)
+   if ((size_t)s.table_f4 * 16 + (size_t)MDH_PARK_DWORDS * MDH_BLOCK * sizeof(float) > 64 * 1024)
+      return seterr(MDH_E_INVALID, "scene tables exceed the 64 KiB LDS budget of a workgroup");
    if (t.size() > r->table_cap) { // grow the whole ring (rare: the table only grows with the primitive counts)
       HIP_TRY(hipDeviceSynchronize());
       r->table_cap = t.size() + 256;
@@ -1283,7 +1285,14 @@ static int run_pass(mdh_renderer *r, int pass, hipStream_t st, int src, int dst,
       if (r->opt_world > 1 && r->opt_irr_all) { pr.probe_begin = 0; pr.probe_end = probe_total(r); } // every rank, every probe
       int n = pr.probe_end - pr.probe_begin; // one workgroup per probe, its taps staged in LDS
       size_t lds = (size_t)2 * pr.rres * pr.rres * sizeof(float4);
-      if (lds > 64 * 1024) return seterr(MDH_E_INVALID, "radiance resolution too large for the irradiance pass (LDS)");
+      if (lds > 64 * 1024) { // radiance tiles beyond 45 x 45 texels: up to the whole 160 KiB of a CU (70 x 70)
+         static size_t granted = 64 * 1024;
+         if (lds > 160 * 1024) return seterr(MDH_E_INVALID, "radiance resolution too large for the irradiance pass (160 KiB of LDS: at most 70)");
+         if (lds > granted) {
+            HIP_TRY(hipFuncSetAttribute((const void *)k_irradiance, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            granted = 160 * 1024;
+         }
+      }
       if (n > 0) hipLaunchKernelGGL(k_irradiance, dim3(n), dim3(MDH_IRR_BLOCK), lds, st, pr);
       break;
    }

@@ -49,6 +49,29 @@ def test_moved_camera_and_light(hip, orc):
     assert_parity(*outs)
 
 
+def test_large_radiance_tiles(hip, orc):
+    """64 x 64 radiance tiles: the irradiance pass stages a probe's 4096 taps in 128 KiB of LDS."""
+    big = renderers.Probe_Settings(Radiance_Resolution=64, Irradiance_Resolution=8, Probe_Count=(4, 2), Grid_Dimensions=(2, 2, 2),
+                                   Grid_Spacing=(4.0, 4.0, 5.0))
+    outs = [snapshot(make("global_illumination", 40, 24, b, probes=big), 2) for b in (hip, orc)]
+    assert_parity(*outs)
+    too_big = renderers.Probe_Settings(Radiance_Resolution=80, Irradiance_Resolution=8, Probe_Count=(4, 2), Grid_Dimensions=(2, 2, 2))
+    R = make("global_illumination", 16, 8, hip, probes=too_big)
+    with pytest.raises(B.MadarchError):
+        R.Render()
+
+
+@pytest.mark.parametrize("steps", [0, 1, 8])
+def test_ambient_occlusion_steps(hip, orc, steps):
+    """M_AO_STEPS (lighting.glsl:42-49) other than the default 5, including none."""
+    outs = []
+    for b in (hip, orc):
+        R = make("global_illumination", 48, 32, b, probes=SMALL_PROBES)
+        R.Set_Option(B.OPT_AO_STEPS, steps)
+        outs.append(snapshot(R, 2))
+    assert_parity(*outs)
+
+
 def test_empty_scene_and_sky(hip, orc):
     """No primitive added: every ray misses and returns the sky (render_probes.glsl:287)."""
     from madarch_amd import scenes, windows
