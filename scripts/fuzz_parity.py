@@ -52,7 +52,8 @@ def build(seed, binding):
     for _ in range(maxc[1] - npl if rng.integers(0, 2) else 0):  # tilted planes fill the rest
         n = u(-1.0, 1.0, 3); n /= np.linalg.norm(n)
         R.Add_Primitive(planes.Plane, planes.Create(tuple(float(v) for v in n), float(u(0.5, 4.0)), mat()))
-    for _ in range(int(rng.integers(0, maxc[0] + 1))):
+    n_spheres = int(rng.integers(0, maxc[0] + 1))
+    for _ in range(n_spheres):
         R.Add_Primitive(spheres.Sphere, spheres.Create(tuple(u(0.0, 6.0, 3)), float(u(0.2, 1.3)), mat()))
     for _ in range(int(rng.integers(0, maxc[2] + 1))):
         R.Add_Primitive(boxes.Box, boxes.Create(tuple(u(0.0, 6.0, 3)), tuple(u(0.2, 1.2, 3)), mat()))
@@ -76,10 +77,29 @@ def build(seed, binding):
     R.Set_Option(B.OPT_GBUFFER, 1)
     if part_on and rng.integers(0, 5) > 0:
         R.Update_Partitioning(int(rng.integers(0, 3)))
+    R.Set_Option(B.OPT_FRAME_OVERLAP, int(rng.choice([0, 1, 2])))  # (the schedule must not show)
+    R.Set_Option(B.OPT_WINDOW, int(rng.integers(0, 2)))
     frames = int(rng.integers(1, 4))
     out = snapshot(R, frames)
     if part_on:
         out["partition"] = R.Read_Partitioning()
+    # a second act: distance queries, a scene edit, frames without a read in between, the window's pixels
+    kinds = [k for k, on in zip((spheres.Sphere, planes.Plane, boxes.Box, triangles.Triangle), rng.integers(0, 2, 4)) if on] or [planes.Plane]
+    out["eval_d"], out["eval_n"] = R.Eval_Distances_To(u(-1.0, 7.0, (int(rng.integers(1, 40)), 3)).astype(np.float32), kinds)
+    if rng.integers(0, 2) and n_spheres:
+        R.Set_Primitive(spheres.Sphere, int(rng.integers(1, n_spheres + 1)), spheres.Create(tuple(u(0.0, 6.0, 3)), float(u(0.2, 1.3)), mat()))
+        if part_on and rng.integers(0, 2):
+            R.Update_Partitioning(int(rng.integers(0, 3)))
+    if rng.integers(0, 2):
+        R.Set_Light(1, point_lights.Point_Light, point_lights.Create(tuple(u(0.0, 6.0, 3)), tuple(u(0.1, 1.0, 3))))
+    for f in range(int(rng.integers(1, 5))):
+        R.Set_Camera_Position(tuple(u(-0.5, 6.5, 3)))
+        R.Render()
+        R.Swap_Buffers()
+    act2 = snapshot(R, 0)
+    for k, v in act2.items():
+        out["act2_" + k] = v
+    out["window"] = R.Front_Buffer()
     return out
 
 
@@ -89,8 +109,12 @@ for seed in range(first, first + count):
     try:
         got, want = build(seed, hip), build(seed, orc)
         assert_parity(got, want)
-        if "partition" in want:
-            assert same_bits(got["partition"], want["partition"]), "partition"
+        assert_parity({k[5:]: v for k, v in got.items() if k.startswith("act2_")}, {k[5:]: v for k, v in want.items() if k.startswith("act2_")})
+        for k in ("partition", "eval_d", "eval_n"):
+            if k in want:
+                assert same_bits(got[k], want[k]), k
+        dw = np.abs(got["window"].astype(np.int16) - want["window"].astype(np.int16))
+        assert dw.max() <= 1 and (dw == 0).mean() > 0.99, "window"
         print("seed %d ok" % seed, flush=True)
     except Exception as e:  # noqa: BLE001
         bad.append(seed)
