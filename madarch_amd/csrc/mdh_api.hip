@@ -909,6 +909,16 @@ static int ensure_committed(mdh_renderer *r, hipStream_t up = nullptr)
 static size_t lds_bytes(const mdh_renderer *r) { return (size_t)r->ks.table_f4 * sizeof(float4); }
 // the march kernels park MDH_PARK_DWORDS floats per thread behind the table (mdh_march.h)
 static size_t lds_bytes_march(const mdh_renderer *r) { return lds_bytes(r) + (size_t)MDH_PARK_DWORDS * MDH_BLOCK * sizeof(float); }
+// the screen pass runs without the visibility queue, whose entries, first steps and result words are the park
+// slots from 15 up: 3 KiB less per workgroup, room for one more workgroup of a neighbouring pass on the CU
+#ifndef MDH_SCR_PARK_DWORDS
+#if MDH_SCR_QVIS || defined(MDH_PHASES)
+#define MDH_SCR_PARK_DWORDS MDH_PARK_DWORDS
+#else
+#define MDH_SCR_PARK_DWORDS 15
+#endif
+#endif
+static size_t lds_bytes_screen(const mdh_renderer *r) { return lds_bytes(r) + (size_t)MDH_SCR_PARK_DWORDS * MDH_BLOCK * sizeof(float); }
 
 // ------------------------------------------------------------------ hiprtc build of user-defined kinds
 // MDH_OPT_JIT: instead of interpreting the MDH_X programs, compile them.  Every program becomes a
@@ -1179,8 +1189,8 @@ extern "C" int32_t mdh_update_partitioning(mdh_renderer *r, int32_t method)
 
 template <int PART, int MODE> static void launch_screen_g(mdh_renderer *r, hipStream_t st, const KProbes &pr, const KVolumetrics &vol, const KCamera &cam, const ScreenArgs &a, int blocks)
 {
-   if (r->opt_gbuffer) hipLaunchKernelGGL((k_screen<PART, MODE, true>), dim3(blocks), dim3(MDH_BLOCK), lds_bytes_march(r), st, r->ks, pr, vol, cam, a);
-   else hipLaunchKernelGGL((k_screen<PART, MODE, false>), dim3(blocks), dim3(MDH_BLOCK), lds_bytes_march(r), st, r->ks, pr, vol, cam, a);
+   if (r->opt_gbuffer) hipLaunchKernelGGL((k_screen<PART, MODE, true>), dim3(blocks), dim3(MDH_BLOCK), lds_bytes_screen(r), st, r->ks, pr, vol, cam, a);
+   else hipLaunchKernelGGL((k_screen<PART, MODE, false>), dim3(blocks), dim3(MDH_BLOCK), lds_bytes_screen(r), st, r->ks, pr, vol, cam, a);
 }
 template <int PART> static void launch_screen_m(mdh_renderer *r, hipStream_t st, const KProbes &pr, const KVolumetrics &vol, const KCamera &cam, const ScreenArgs &a, int blocks)
 {
@@ -1347,7 +1357,7 @@ static int run_pass(mdh_renderer *r, int pass, hipStream_t st, int src, int dst,
          int blocks = (own_tiles + (MDH_BLOCK / 64) - 1) / (MDH_BLOCK / 64);
          if (jit) {
             struct { KScene sc; KProbes pr; KVolumetrics vol; KCamera cam; ScreenArgs a; } args = {r->ks, pr, vol, cam, a};
-            int rc = jit_launch(jm->fn[kname], blocks, MDH_BLOCK, lds_bytes_march(r), st, args);
+            int rc = jit_launch(jm->fn[kname], blocks, MDH_BLOCK, lds_bytes_screen(r), st, args);
             if (rc != MDH_OK) return rc;
          } else
          switch (pf) {
