@@ -198,7 +198,8 @@ enum {
     *       it (second HIP stream, two atlas sets);
     *   2 (default) = also the screen passes of consecutive frames overlap (third
     *       stream, two framebuffers).
-    * Sharded renderers and renderers on a caller-supplied stream run serially. */
+    * Sharded renderers keep frames in flight the same way (mdh_frame_begin / _probe_pass / _end);
+    * renderers on a caller-supplied stream run serially. */
    MDH_OPT_FRAME_OVERLAP = 8,
    /* user-defined kinds: 1 (default) = the MDH_X programs are compiled into the
     * kernels with hiprtc the first time a pass runs (about two seconds per kernel,
