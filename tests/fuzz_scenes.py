@@ -1,6 +1,8 @@
 """Random scenes for differential testing (scripts/fuzz_parity.py, tests/test_gpu_fuzz.py): kinds and counts, open or
 closed rooms, tilted planes, materials, lights, camera, probe / partition / volumetrics settings, screen mode, atlas
 format, then a second act of distance queries, scene edits, partition rebuilds, frames in flight and Swap_Buffers."""
+import os
+
 import numpy as np
 
 from helpers import assert_parity, same_bits, snapshot
@@ -30,7 +32,7 @@ def build(seed, binding):
     lmax = [int(rng.integers(1, 4)), int(rng.integers(1, 4))]
     scene = scenes.Compile([(spheres.Sphere, maxc[0]), (planes.Plane, maxc[1]), (boxes.Box, maxc[2]), (triangles.Triangle, maxc[3])],
                            [(point_lights.Point_Light, lmax[0]), (spot_lights.Spot_Light, lmax[1])], Partitioning=part)
-    W, H = int(rng.integers(1, 41)), int(rng.integers(1, 29))
+    W, H = int(rng.integers(1, int(os.environ.get("FUZZ_MAX_W", 40)) + 1)), int(rng.integers(1, int(os.environ.get("FUZZ_MAX_H", 28)) + 1))  # (larger for soak runs)
     vol = renderers.No_Volumetrics
     if rng.integers(0, 3) == 0:  # light shafts: froxel visibility + scattering passes
         vol = renderers.Volumetrics_Settings(Visibility_Resolution=tuple(int(v) for v in rng.integers(3, 22, 3)), Visibility_Step_Size=float(rng.choice([0.1, 0.25, 0.4])),
