@@ -1295,6 +1295,7 @@ static int run_pass(mdh_renderer *r, int pass, hipStream_t st, int src, int dst,
       if (r->opt_world > 1 && r->opt_irr_all) { pr.probe_begin = 0; pr.probe_end = probe_total(r); } // every rank, every probe
       int n = pr.probe_end - pr.probe_begin; // one workgroup per probe, its taps staged in LDS
       size_t lds = (size_t)2 * pr.rres * pr.rres * sizeof(float4);
+      if (MDH_IRR_CHUNK && pr.ires * pr.ires <= 64 && lds > (size_t)4 * MDH_IRR_CHUNK * sizeof(float4)) lds = (size_t)4 * MDH_IRR_CHUNK * sizeof(float4); // two chunk buffers
       if (lds > 64 * 1024) { // radiance tiles beyond 45 x 45 texels: up to the whole 160 KiB of a CU (70 x 70)
          static size_t granted = 64 * 1024;
          if (lds > 160 * 1024) return seterr(MDH_E_INVALID, "radiance resolution too large for the irradiance pass (160 KiB of LDS: at most 70)");

@@ -206,6 +206,9 @@ template <int PART> __global__ __launch_bounds__(MDH_BLOCK, MDH_OCC_RAD(PART)) v
 #ifndef MDH_IRR_PACKED
 #define MDH_IRR_PACKED 1
 #endif
+#ifndef MDH_IRR_CHUNK
+#define MDH_IRR_CHUNK 256 // taps per LDS buffer when one wavefront folds (0 = all taps staged at once)
+#endif
 typedef float pk2 __attribute__((ext_vector_type(2))); // two fp32 per VALU instruction (v_pk_mul_f32 / v_pk_add_f32: IEEE per component)
 __global__ __launch_bounds__(MDH_IRR_BLOCK) void k_irradiance(KProbes pr)
 {
@@ -218,14 +221,60 @@ __global__ __launch_bounds__(MDH_IRR_BLOCK) void k_irradiance(KProbes pr)
    const f2 step = F2(1.0f / pcx / (float)pr.rres, 1.0f / pcy / (float)pr.rres);
    // probe_id_to_coord of the probe the output texels belong to (probe_utils.glsl:52-56)
    const f2 rad_coord = F2((float)tx / pcx, (float)ty / pcy);
-   for (int tap = threadIdx.x; tap < ntaps; tap += MDH_IRR_BLOCK) {
-      const int yy = tap / pr.rres, xx = tap - yy * pr.rres;
-      f2 c = F2(clamp_(rad_coord.x + (float)xx * step.x, step.x, 1.0f - step.x), clamp_(rad_coord.y + (float)yy * step.y, step.y, 1.0f - step.y));
-      f3 rad = atlas_sample(pr.rad, pr.fmt, pr.pcx, pr.pcy, pr.rres, pr.rshift, c.x, c.y, -1);
-      f3 rad_dir = ray_id_to_ray_dir(F2(fract_(c.x * pcx), fract_(c.y * pcy)));
-      s_taps[2 * tap] = make_float4(rad.x, rad.y, rad.z, 1.0f);
-      s_taps[2 * tap + 1] = make_float4(rad_dir.x, rad_dir.y, rad_dir.z, 0.0f);
+   // one tap: the bilinear fetch of the radiance atlas and the ray direction of its texel
+#define MDH_IRR_STAGE(tap_, slot_)                                                                                      \
+   do {                                                                                                                 \
+      const int yy = (tap_) / pr.rres, xx = (tap_) - yy * pr.rres;                                                       \
+      f2 c = F2(clamp_(rad_coord.x + (float)xx * step.x, step.x, 1.0f - step.x), clamp_(rad_coord.y + (float)yy * step.y, step.y, 1.0f - step.y)); \
+      f3 rad = atlas_sample(pr.rad, pr.fmt, pr.pcx, pr.pcy, pr.rres, pr.rshift, c.x, c.y, -1);                          \
+      f3 rad_dir = ray_id_to_ray_dir(F2(fract_(c.x * pcx), fract_(c.y * pcy)));                                          \
+      s_taps[2 * (slot_)] = make_float4(rad.x, rad.y, rad.z, 1.0f);                                                      \
+      s_taps[2 * (slot_) + 1] = make_float4(rad_dir.x, rad_dir.y, rad_dir.z, 0.0f);                                      \
+   } while (0)
+#if MDH_IRR_CHUNK
+   if (pr.ires * pr.ires <= 64) {
+      // One wavefront folds (a lane per texel): the taps go through LDS in chunks of MDH_IRR_CHUNK, two buffers --
+      // while the first wavefront folds chunk c, the other three stage chunk c + 1.  The same taps in the same
+      // order; a quarter of the LDS (room for the march kernels' workgroups beside it) and the staging hidden.
+      constexpr int CH = MDH_IRR_CHUNK;
+      const int nchunks = (ntaps + CH - 1) / CH;
+      const int x = threadIdx.x % pr.ires, y = threadIdx.x / pr.ires; // (used by the folding lanes only)
+      const int i = tx * pr.ires + x, j = ty * pr.ires + y;
+      const f2 nc = F2((centre(i, pr.pcx * pr.ires) + 1.0f) * 0.5f, (centre(j, pr.pcy * pr.ires) + 1.0f) * 0.5f);
+      const f3 irr_dir = ray_id_to_ray_dir(F2(fract_(nc.x * pcx), fract_(nc.y * pcy)));
+      pk2 acc_xy = {0.0f, 0.0f}, acc_zw = {0.0f, 0.0f};
+      const pk2 dir_xy = {irr_dir.x, irr_dir.y};
+      for (int t = threadIdx.x; t < min(CH, ntaps); t += MDH_IRR_BLOCK) MDH_IRR_STAGE(t, t);
+      __syncthreads();
+      for (int c = 0; c < nchunks; ++c) {
+         const int base = c * CH, n_here = min(CH, ntaps - base);
+         const float4 *buf = s_taps + (size_t)(c & 1) * 2 * CH;
+         if (threadIdx.x < 64) {
+            if ((int)threadIdx.x < pr.ires * pr.ires)
+               for (int t = 0; t < n_here; ++t) {
+                  const float4 r = buf[2 * t], d = buf[2 * t + 1];
+                  const pk2 d_xy = {d.x, d.y}, r_xy = {r.x, r.y}, r_z1 = {r.z, r.w};
+                  const pk2 p = dir_xy * d_xy;
+                  const float w = max_((p.x + p.y) + irr_dir.z * d.z, 0.0f);
+                  const pk2 ww = {w, w};
+                  acc_xy = acc_xy + r_xy * ww;
+                  acc_zw = acc_zw + r_z1 * ww;
+               }
+         } else if (c + 1 < nchunks) {
+            const int nbase = base + CH, n_next = min(CH, ntaps - nbase), off = ((c + 1) & 1) * CH;
+            for (int t = (int)threadIdx.x - 64; t < n_next; t += MDH_IRR_BLOCK - 64) MDH_IRR_STAGE(nbase + t, off + t);
+         }
+         __syncthreads();
+      }
+      if ((int)threadIdx.x < pr.ires * pr.ires) {
+         const f3 irradiance = F3(acc_xy.x, acc_xy.y, acc_zw.x) / acc_zw.y;
+         atlas_store(pr.irr, pr.fmt, atlas_index(pr.pcx, pr.ires, pr.ishift, i, j), irradiance);
+      }
+      return;
    }
+#endif
+   for (int tap = threadIdx.x; tap < ntaps; tap += MDH_IRR_BLOCK) MDH_IRR_STAGE(tap, tap);
+#undef MDH_IRR_STAGE
    __syncthreads();
    for (int rem = threadIdx.x; rem < pr.ires * pr.ires; rem += MDH_IRR_BLOCK) {
       const int y = rem / pr.ires, x = rem - y * pr.ires;

@@ -49,13 +49,20 @@ def test_moved_camera_and_light(hip, orc):
     assert_parity(*outs)
 
 
-def test_large_radiance_tiles(hip, orc):
-    """64 x 64 radiance tiles: the irradiance pass stages a probe's 4096 taps in 128 KiB of LDS."""
-    big = renderers.Probe_Settings(Radiance_Resolution=64, Irradiance_Resolution=8, Probe_Count=(4, 2), Grid_Dimensions=(2, 2, 2),
+@pytest.mark.parametrize("rres,ires", [(64, 8), (80, 4), (48, 16)])
+def test_large_radiance_tiles(hip, orc, rres, ires):
+    """Large radiance tiles: with up to 64 irradiance texels per probe one wavefront folds and the taps go through
+    two small LDS buffers in chunks (any tile size); with more texels all taps are staged at once (48 x 48 x 32 B =
+    72 KiB of LDS here)."""
+    big = renderers.Probe_Settings(Radiance_Resolution=rres, Irradiance_Resolution=ires, Probe_Count=(4, 2), Grid_Dimensions=(2, 2, 2),
                                    Grid_Spacing=(4.0, 4.0, 5.0))
     outs = [snapshot(make("global_illumination", 40, 24, b, probes=big), 2) for b in (hip, orc)]
     assert_parity(*outs)
-    too_big = renderers.Probe_Settings(Radiance_Resolution=80, Irradiance_Resolution=8, Probe_Count=(4, 2), Grid_Dimensions=(2, 2, 2))
+
+
+def test_radiance_tiles_beyond_the_lds(hip):
+    """... and past 160 KiB that path refuses loudly."""
+    too_big = renderers.Probe_Settings(Radiance_Resolution=80, Irradiance_Resolution=16, Probe_Count=(4, 2), Grid_Dimensions=(2, 2, 2))
     R = make("global_illumination", 16, 8, hip, probes=too_big)
     with pytest.raises(B.MadarchError):
         R.Render()
