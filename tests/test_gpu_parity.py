@@ -318,6 +318,46 @@ def test_pipelined_frames_across_screen_modes(hip):
             assert same_bits(a, b), "output %d differs at overlap level %d" % (i, level)
 
 
+def test_caller_supplied_stream(hip):
+    """mdh_set_stream: on a stream of the caller frames run serially behind the caller's work; handing the renderer
+    back to its own streams resumes frames in flight.  Same bits throughout."""
+    import ctypes as C
+    from madarch_amd.primitives import spheres
+    rt = C.CDLL("libamdhip64.so")  # the HIP runtime the library itself is linked against
+
+    def drive(use_stream):
+        R = make("simple_scene", 96, 64, hip, probes=SMALL_PROBES)
+        R.Set_Option(B.OPT_GBUFFER, 0)
+        st = C.c_void_p()
+        if use_stream:
+            assert rt.hipStreamCreate(C.byref(st)) == 0
+        seen = []
+        for phase in range(3):
+            if use_stream:
+                hip.check(hip.set_stream(R._h, C.c_void_p(st.value if phase != 1 else 0)))  # phase 1: back on its own streams
+                if phase != 1:
+                    cur = C.c_void_p()
+                    hip.check(hip.stream(R._h, C.byref(cur)))
+                    assert cur.value == st.value
+            for f in range(4):
+                R.Set_Camera_Position((2.0 + 0.1 * f, 2.0, 0.05 * phase))
+                R.Render()
+                R.Swap_Buffers()
+            R.Set_Primitive(spheres.Sphere, 2, spheres.Create((2.0, 3.0, 2.5 + phase), 0.6, 3))
+            R.Update_Partitioning(phase)
+            seen.append(R.Eval_Distances_To(np.linspace(0.0, 5.0, 30, dtype=np.float32).reshape(10, 3), [spheres.Sphere])[0])
+            R.Render()
+            seen += [R.Read_Framebuffer(), R.Read_Texture(B.TEX_IRRADIANCE), R.Read_Partitioning(), R.Front_Buffer()]
+        if use_stream:
+            hip.check(hip.set_stream(R._h, C.c_void_p(0)))
+            R.Destroy()
+            assert rt.hipStreamDestroy(st) == 0
+        return seen
+
+    for a, b in zip(drive(False), drive(True)):
+        assert same_bits(a, b)
+
+
 def window_pixels(img):
     """float framebuffer -> the RGBA8 default framebuffer of the reference's window (OpenGL 4.3 core 2.3.5.1)"""
     with np.errstate(invalid="ignore"):
