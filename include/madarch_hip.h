@@ -213,9 +213,10 @@ enum {
     * is one workgroup per probe and far from filling a GPU: the same time, and the second
     * exchange of the frame is not needed); 0 = own slice only, to be exchanged. */
    MDH_OPT_IRRADIANCE_ALL = 10,
-   /* 1 = every screen pass also stores the window's RGBA8 pixels (mdh_swap_buffers) straight into
-    * pinned host memory, over PCIe, beside its float store: mdh_swap_buffers then has nothing to
-    * convert or copy.  0 (default) = mdh_swap_buffers converts and copies the framebuffer itself. */
+   /* where the window's RGBA8 pixels (mdh_swap_buffers) are made: 1 = every screen pass also stores them
+    * straight into pinned host memory, over PCIe, beside its float store, and mdh_swap_buffers has nothing
+    * to convert or copy; 0 = mdh_swap_buffers converts and copies the framebuffer itself; 2 (default) = 0
+    * until the first mdh_swap_buffers, 1 from then on (a renderer that never swaps pays nothing). */
    MDH_OPT_WINDOW = 11
 };
 

@@ -244,7 +244,7 @@ struct mdh_renderer {
    // MDH_OPT_WINDOW: the screen pass itself stores the RGBA8 pixels into a ring of pinned host buffers (over PCIe,
    // no copy and no extra kernel); a swap then only marks the last one with an event
    static constexpr int WIN_RING = 4;
-   int opt_window = 0;
+   int opt_window = 2; // MDH_OPT_WINDOW: 0 never, 1 always, 2 from the first mdh_swap_buffers on
    unsigned *h_win[WIN_RING] = {nullptr, nullptr, nullptr, nullptr};
    hipEvent_t ev_win[WIN_RING] = {nullptr, nullptr, nullptr, nullptr};
    long long win_passes = 0; // screen passes that wrote a window slot; the last one wrote slot (win_passes - 1) % WIN_RING
@@ -797,7 +797,10 @@ extern "C" int32_t mdh_set_option(mdh_renderer *r, int32_t option, int32_t value
    case MDH_OPT_ADA_EVAL_DIV: r->opt_ada_div = value ? 1 : 0; break;
    case MDH_OPT_JIT: r->opt_jit = value ? 1 : 0; break;
    case MDH_OPT_IRRADIANCE_ALL: r->opt_irr_all = value ? 1 : 0; break;
-   case MDH_OPT_WINDOW: r->opt_window = value ? 1 : 0; r->win_valid = false; break;
+   case MDH_OPT_WINDOW:
+      if (value < 0 || value > 2) return seterr(MDH_E_INVALID, "bad value");
+      r->opt_window = value; r->win_valid = false;
+      break;
    case MDH_OPT_FRAME_OVERLAP: if (value < 0 || value > 2) return seterr(MDH_E_INVALID, "frame overlap is 0, 1 or 2"); r->opt_overlap = value; break;
    default: return seterr(MDH_E_INVALID, "unknown option");
    }
@@ -1345,7 +1348,7 @@ static int run_pass(mdh_renderer *r, int pass, hipStream_t st, int src, int dst,
       a.ao_steps = r->opt_ao;
       a.fb = r->d_fb2[fbix]; a.gb_index = (int *)r->d_gb2[fbix][0]; a.gb_t = (float *)r->d_gb2[fbix][1]; a.gb_steps = (int *)r->d_gb2[fbix][2];
       a.window = nullptr;
-      if (r->opt_window) { // the window's pixels straight into pinned host memory (mdh_swap_buffers)
+      if (r->opt_window == 1 || (r->opt_window == 2 && r->swaps > 0)) { // the window's pixels straight into pinned host memory (mdh_swap_buffers)
          int wrc = window_slot(r, a.rank, a.world, &a.window);
          if (wrc != MDH_OK) return wrc;
       }

@@ -1301,7 +1301,7 @@ int32_t orc_create(int32_t width, int32_t height, const mdh_scene_desc *scene, c
    r->probes = *probes;
    r->vol = *vol;
    r->cam_m[0] = r->cam_m[4] = r->cam_m[8] = 1.0f; /* renderers.adb:225-226 */
-   r->opt_ao = 3; r->opt_world = 1; r->opt_ada_div = 1; r->opt_irr_all = 1;
+   r->opt_ao = 3; r->opt_world = 1; r->opt_ada_div = 1; r->opt_irr_all = 1; r->opt_window = 2;
    tex_alloc(&r->tex[MDH_TEX_RADIANCE], probes->radiance_resolution * probes->probe_count[0], probes->radiance_resolution * probes->probe_count[1], 3, 1);
    tex_alloc(&r->tex[MDH_TEX_IRRADIANCE], probes->irradiance_resolution * probes->probe_count[0], probes->irradiance_resolution * probes->probe_count[1], 3, 1);
    r->tex[MDH_TEX_RADIANCE].flush_nan = r->tex[MDH_TEX_IRRADIANCE].flush_nan = 1;
@@ -1344,7 +1344,10 @@ int32_t orc_set_option(orc_renderer *r, int32_t option, int32_t value)
    case MDH_OPT_FRAME_OVERLAP: break; /* scheduling only: nothing to restate */
    case MDH_OPT_JIT: break;           /* how the kernels run the MDH_X programs: nothing to restate */
    case MDH_OPT_IRRADIANCE_ALL: r->opt_irr_all = value ? 1 : 0; break;
-   case MDH_OPT_WINDOW: r->opt_window = value ? 1 : 0; break; /* where the pixels are converted: no effect on them */
+   case MDH_OPT_WINDOW: /* where the pixels are converted: no effect on them */
+      if (value < 0 || value > 2) return seterr(MDH_E_INVALID, "bad value");
+      r->opt_window = value;
+      break;
    case ORC_OPT_SDF_MODE: r->opt_sdf_mode = value; break;
    case ORC_OPT_THREADS: r->opt_threads = value; break;
    default: return seterr(MDH_E_INVALID, "unknown option");
