@@ -143,6 +143,21 @@ MDH_DEV float max_(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v
 MDH_DEV float min_(float a, float b) { return __builtin_fminf(a, b); } // v_min_f32: minNum
 MDH_DEV float max_(float a, float b) { return __builtin_fmaxf(a, b); }
 #endif
+// The same two operations as bare instructions, for operands that reach them across a branch: there the compiler
+// cannot see that a value is no signaling NaN (none exists on this path: every operand is an arithmetic
+// result) and quiets it with a v_max_f32 x, x first -- six or seven of the ~75 instructions of one SDF evaluation.
+#ifndef MDH_RAW_MINMAX
+#define MDH_RAW_MINMAX 1
+#endif
+#if MDH_RAW_MINMAX
+MDH_DEV float min_raw(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+MDH_DEV float max0_raw(float a) { float r; asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(a)); return r; }
+MDH_DEV float min0_raw(float a) { float r; asm("v_min_f32 %0, 0, %1" : "=v"(r) : "v"(a)); return r; }
+#else
+MDH_DEV float min_raw(float a, float b) { return min_(a, b); }
+MDH_DEV float max0_raw(float a) { return max_(a, 0.0f); }
+MDH_DEV float min0_raw(float a) { return min_(a, 0.0f); }
+#endif
 
 // Correctly rounded sqrt.  hipcc's expansion (v_sqrt_f32 + two fma residual tests) also rescales
 // inputs below 2^-96 and re-selects 0/inf with a class test on every call; MDH_FAST_EXACT_SQRT=1
@@ -572,7 +587,7 @@ template <bool CUSTOM> MDH_DEV float closest_primitive(const KScene &sc, f3 x, c
    {
       const int n = sc.gplane_count, s0 = sc.gplane_slot;
 #pragma unroll MDH_SDF_UNROLL
-      for (int i = 0; i < n; ++i) closest = min_(closest, sd_plane(s_tab[s0 + i], x));
+      for (int i = 0; i < n; ++i) closest = min_raw(closest, sd_plane(s_tab[s0 + i], x));
    }
    {
       const int n = sc.tcount[PK_SPHERE], s0 = sc.tslot[PK_SPHERE];
@@ -582,7 +597,7 @@ template <bool CUSTOM> MDH_DEV float closest_primitive(const KScene &sc, f3 x, c
          const float d2 = dot2(xyz(a) - x); /* sd_sphere = sqrt(d2) - a.w (spheres.ads:13-14) */ \
          const float tsum = closest + a.w;                                                   \
          const bool need = !(tsum < 0.0f) && !(d2 > (tsum * tsum) * 1.000001f);              \
-         if (!MDH_CULL || __ballot(need) != 0ull) closest = min_(closest, sqrt_(d2) - a.w);  \
+         if (!MDH_CULL || __ballot(need) != 0ull) closest = min_raw(closest, sqrt_(d2) - a.w); \
       } while (0)
 #if MDH_SDF_PREFETCH
       if (n > 0) MDH_SPHERE_STEP(pf_s);
@@ -601,7 +616,8 @@ template <bool CUSTOM> MDH_DEV float closest_primitive(const KScene &sc, f3 x, c
          const f3 q = abs3(xyz(c_) - x) - xyz(e_); /* boxes.adb:10 */                        \
          const float m = max_(q.x, max_(q.y, q.z));                                          \
          const float thr = closest > 0.0f ? closest * 1.000001f : closest;                   \
-         if (!MDH_CULL || __ballot(!(m > thr)) != 0ull) closest = min_(closest, length(max3s(q, 0.0f)) + min_(m, 0.0f)); \
+         if (!MDH_CULL || __ballot(!(m > thr)) != 0ull)                                      \
+            closest = min_raw(closest, length(F3(max0_raw(q.x), max0_raw(q.y), max0_raw(q.z))) + min0_raw(m)); \
       } while (0)
 #if MDH_SDF_PREFETCH
       if (n > 0) MDH_BOX_STEP(pf_b0, pf_b1);
@@ -617,7 +633,7 @@ template <bool CUSTOM> MDH_DEV float closest_primitive(const KScene &sc, f3 x, c
       const int n = sc.tcount[PK_TRIANGLE], s0 = sc.tslot[PK_TRIANGLE];
 #pragma unroll 1
       for (int i = 0; i < n; ++i)
-         closest = min_(closest, sd_triangle<false>(xyz(s_tab[s0 + 3 * i]), xyz(s_tab[s0 + 3 * i + 1]), xyz(s_tab[s0 + 3 * i + 2]), x));
+         closest = min_raw(closest, sd_triangle<false>(xyz(s_tab[s0 + 3 * i]), xyz(s_tab[s0 + 3 * i + 1]), xyz(s_tab[s0 + 3 * i + 2]), x));
    }
    if (CUSTOM) { // user-defined kinds: their Distance programs, interpreted
       const int nk = hdr(H_NK);
@@ -626,7 +642,7 @@ template <bool CUSTOM> MDH_DEV float closest_primitive(const KScene &sc, f3 x, c
          if (hdr(H_KTYPE + k) != PK_CUSTOM) continue;
          const int n = hdr(H_KCOUNT + k);
 #pragma unroll 1
-         for (int i = 0; i < n; ++i) closest = min_(closest, xdist<false>(k, i, x));
+         for (int i = 0; i < n; ++i) closest = min_raw(closest, xdist<false>(k, i, x));
       }
    }
    return closest;
@@ -761,7 +777,7 @@ template <bool INFO, bool CUSTOM> MDH_DEV float partitioning_lookup(const KScene
          pi_next = rec[nk + (i + 1 < sc.part_index_count ? i + 1 : i)]; // (inside the record; unused past the last candidate)
          float d = (CUSTOM && type == PK_CUSTOM) ? xdist<false>(k, pi, x) : prim_dist(type, s0 + prim_slots(type) * pi, x);
          if (INFO) { if (d < closest) { closest = d; index = base + pi; } }
-         else closest = min_(closest, d);
+         else closest = min_raw(closest, d);
       }
       i = size;
       cnt = cnt_next;
@@ -776,7 +792,7 @@ template <bool INFO, bool CUSTOM> MDH_DEV float partitioning_lookup(const KScene
          int pi = rec[nk + i];
          float d = (CUSTOM && type == PK_CUSTOM) ? xdist<false>(k, pi, x) : prim_dist(type, s0 + prim_slots(type) * pi, x);
          if (INFO) { if (d < closest) { closest = d; index = base + pi; } }
-         else closest = min_(closest, d);
+         else closest = min_raw(closest, d);
       }
       i = size;
    }

@@ -328,7 +328,7 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
                            if (dist < MDH_EPS) { blocked = true; break; }
                            float y = dist * dist / (2.0f * prev);
                            float d = sqrt_(dist * dist - y * y);
-                           res = min_(res, 64.0f * d / max_(0.0f, total - y));
+                           res = min_raw(res, 64.0f * d / max_(0.0f, total - y));
                            prev = dist;
                            total += dist;
                         }
