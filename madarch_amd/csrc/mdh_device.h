@@ -587,7 +587,7 @@ template <bool CUSTOM> MDH_DEV float closest_primitive(const KScene &sc, f3 x, c
    {
       const int n = sc.gplane_count, s0 = sc.gplane_slot;
 #pragma unroll MDH_SDF_UNROLL
-      for (int i = 0; i < n; ++i) closest = min_raw(closest, sd_plane(s_tab[s0 + i], x));
+      for (int i = 0; i < n; ++i) closest = min_(closest, sd_plane(s_tab[s0 + i], x)); // (unrolled in pairs: v_min3_f32)
    }
    {
       const int n = sc.tcount[PK_SPHERE], s0 = sc.tslot[PK_SPHERE];
