@@ -266,6 +266,7 @@ struct mdh_renderer {
    double pass_ms[MDH_PASS_COUNT] = {0};
    long long pass_n[MDH_PASS_COUNT] = {0};
    hipStream_t own_stream = nullptr;
+   bool irr_lds_granted = false; // k_irradiance may use up to 160 KiB of dynamic LDS on this renderer's device
 };
 
 // Order `stream` after everything pipelined frames put on the alternate screen stream (which
@@ -285,23 +286,44 @@ static hipEvent_t get_event(mdh_renderer *r)
    if (hipEventCreate(&e) != hipSuccess) return nullptr;
    return e;
 }
-// fold every finished event pair into the per-pass totals (waits for the stream)
-static int resolve_timing(mdh_renderer *r)
+// Fold event pairs into the per-pass totals.  wait = true: after every stream a pass can run on has drained, all of
+// them; wait = false (the bound on the pending list, at a frame boundary): only the pairs whose end event has already
+// completed, the rest stay pending.  Entries leave the list as they are folded, so an error half way leaves no pair behind
+// whose events were already handed back.
+static int resolve_timing(mdh_renderer *r, bool wait = true)
 {
    if (r->pending.empty()) return MDH_OK;
-   { int jr = join_main(r); if (jr != MDH_OK) return jr; }
-   HIP_TRY(hipStreamSynchronize(r->stream));
-   for (auto &p : r->pending) {
-      float ms = 0.0f;
-      HIP_TRY(hipEventElapsedTime(&ms, p.e0, p.e1));
-      r->pass_ms[p.pass] += ms;
-      r->pass_n[p.pass] += 1;
-      r->free_events.push_back(p.e0);
-      r->free_events.push_back(p.e1);
+   if (wait) {
+      { int jr = join_main(r); if (jr != MDH_OK) return jr; }
+      if (r->probe_stream) HIP_TRY(hipStreamSynchronize(r->probe_stream));
+      if (r->alt_stream) HIP_TRY(hipStreamSynchronize(r->alt_stream));
+      if (r->own_stream && r->own_stream != r->stream) HIP_TRY(hipStreamSynchronize(r->own_stream));
+      HIP_TRY(hipStreamSynchronize(r->stream));
    }
-   r->pending.clear();
-   return MDH_OK;
+   int rc = MDH_OK;
+   size_t keep = 0;
+   for (size_t i = 0; i < r->pending.size(); ++i) {
+      const mdh_renderer::Pending p = r->pending[i];
+      float ms = 0.0f;
+      hipError_t e = rc != MDH_OK ? hipErrorNotReady : ((wait || hipEventQuery(p.e1) == hipSuccess) ? hipEventElapsedTime(&ms, p.e0, p.e1) : hipErrorNotReady);
+      if (e == hipSuccess) {
+         r->pass_ms[p.pass] += ms;
+         r->pass_n[p.pass] += 1;
+         r->free_events.push_back(p.e0);
+         r->free_events.push_back(p.e1);
+         continue;
+      }
+      if (e != hipErrorNotReady || wait) {
+         if (rc == MDH_OK) { snprintf(g_err, sizeof g_err, "hipEventElapsedTime failed: %s", hipGetErrorString(e)); rc = MDH_E_DEVICE; }
+      }
+      r->pending[keep++] = p;
+   }
+   r->pending.resize(keep);
+   if (!wait) (void)hipGetLastError(); // (a hipErrorNotReady of the queries is no error of the next launch)
+   return rc;
 }
+// the bound on the pending list, applied where no frame is open
+static int bound_timing(mdh_renderer *r) { return r->pending.size() >= 4096 ? resolve_timing(r, false) : MDH_OK; }
 
 static int probe_total(const mdh_renderer *r) { return r->probes.probe_count[0] * r->probes.probe_count[1]; }
 static size_t texel_bytes(const mdh_renderer *r) { return r->opt_atlas == 0 ? 4 : 16; }
@@ -313,8 +335,9 @@ static size_t atlas_bytes(const mdh_renderer *r, int tex)
 static void own_probes(const mdh_renderer *r, int *b, int *e)
 {
    long long P = probe_total(r);
-   *b = (int)(P * r->opt_rank / r->opt_world);
-   *e = (int)(P * (r->opt_rank + 1) / r->opt_world);
+   const long long rank = r->opt_rank < r->opt_world ? r->opt_rank : r->opt_world - 1; // (rank >= world is refused where a slice is used)
+   *b = (int)(P * rank / r->opt_world);
+   *e = (int)(P * (rank + 1) / r->opt_world);
 }
 
 static float rd_f(const mdh_renderer *r, int off) { float f; memcpy(&f, r->scene_ubo.data() + off, 4); return f; }
@@ -776,6 +799,10 @@ extern "C" int32_t mdh_create(int32_t width, int32_t height, const mdh_scene_des
 extern "C" int32_t mdh_set_option(mdh_renderer *r, int32_t option, int32_t value)
 {
    if (!r) return seterr(MDH_E_INVALID, "null renderer");
+   // what an open frame has latched (its atlas set, slice, streams and screen mode) cannot change under it
+   if (r->in_frame && (option == MDH_OPT_ATLAS_FORMAT || option == MDH_OPT_RANK || option == MDH_OPT_WORLD || option == MDH_OPT_FRAME_OVERLAP ||
+                       option == MDH_OPT_SCREEN_MODE))
+      return seterr(MDH_E_STATE, "a frame is open");
    switch (option) {
    case MDH_OPT_ATLAS_FORMAT:
       if (value != 0 && value != 1) return seterr(MDH_E_INVALID, "atlas format is 0 (RGB8) or 1 (fp32)");
@@ -1074,7 +1101,7 @@ static JitModule *jit_module(mdh_renderer *r, const std::vector<std::string> &ex
    const HiprtcApi &rtc = hiprtc_api();
    if (!rtc.ok) { seterr(MDH_E_DEVICE, "libhiprtc.so cannot be loaded: user-defined kinds are interpreted"); return nullptr; }
    if (r->jit_kinds.empty()) r->jit_kinds = jit_kinds_header(r);
-   std::string key = r->jit_kinds;
+   std::string key = "device " + std::to_string(r->device) + "\n" + r->jit_kinds; // (a module and its functions belong to the device they were loaded on)
    for (auto &e : exprs) key += "|" + e;
    std::lock_guard<std::mutex> lock(g_jit_mutex);
    auto it = g_jit_cache.find(key);
@@ -1300,11 +1327,10 @@ static int run_pass(mdh_renderer *r, int pass, hipStream_t st, int src, int dst,
       size_t lds = (size_t)2 * pr.rres * pr.rres * sizeof(float4);
       if (MDH_IRR_CHUNK && pr.ires * pr.ires <= 64 && lds > (size_t)4 * MDH_IRR_CHUNK * sizeof(float4)) lds = (size_t)4 * MDH_IRR_CHUNK * sizeof(float4); // two chunk buffers
       if (lds > 64 * 1024) { // radiance tiles beyond 45 x 45 texels: up to the whole 160 KiB of a CU (70 x 70)
-         static size_t granted = 64 * 1024;
          if (lds > 160 * 1024) return seterr(MDH_E_INVALID, "radiance resolution too large for the irradiance pass (160 KiB of LDS: at most 70)");
-         if (lds > granted) {
+         if (!r->irr_lds_granted) { // (the attribute belongs to the function on THIS device: kept per renderer, not per process)
             HIP_TRY(hipFuncSetAttribute((const void *)k_irradiance, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            granted = 160 * 1024;
+            r->irr_lds_granted = true;
          }
       }
       if (n > 0) hipLaunchKernelGGL(k_irradiance, dim3(n), dim3(MDH_IRR_BLOCK), lds, st, pr);
@@ -1382,8 +1408,7 @@ static int run_pass(mdh_renderer *r, int pass, hipStream_t st, int src, int dst,
    }
    if (r->opt_timing) {
       HIP_TRY(hipEventRecord(e1, st));
-      r->pending.push_back({pass, e0, e1});
-      if (r->pending.size() >= 4096) return resolve_timing(r);
+      r->pending.push_back({pass, e0, e1}); // (folded at frame boundaries: bound_timing)
    }
    return MDH_OK;
 }
@@ -1392,11 +1417,13 @@ extern "C" int32_t mdh_render_pass(mdh_renderer *r, int32_t pass)
 {
    if (!r) return seterr(MDH_E_INVALID, "null renderer");
    if (r->in_frame) return seterr(MDH_E_STATE, "a frame is open: use mdh_frame_probe_pass / mdh_frame_end");
+   if (r->opt_rank >= r->opt_world) return seterr(MDH_E_STATE, "MDH_OPT_RANK is not below MDH_OPT_WORLD");
    int rc = ensure_committed(r);
    if (rc != MDH_OK) return rc;
    if ((rc = join_main(r)) != MDH_OK) return rc;
    r->main_dirty = true;
-   return run_pass(r, pass, r->stream, r->last, r->last);
+   if ((rc = run_pass(r, pass, r->stream, r->last, r->last)) != MDH_OK) return rc;
+   return bound_timing(r);
 }
 // Render (renderers.adb:302-321).
 //
@@ -1424,6 +1451,7 @@ extern "C" int32_t mdh_frame_begin(mdh_renderer *r)
 {
    if (!r) return seterr(MDH_E_INVALID, "null renderer");
    if (r->in_frame) return seterr(MDH_E_STATE, "a frame is already open");
+   if (r->opt_rank >= r->opt_world) return seterr(MDH_E_STATE, "MDH_OPT_RANK is not below MDH_OPT_WORLD");
    r->frame_pipelined = r->opt_overlap && r->stream == r->own_stream; // (modes 1 and 2 have no probe passes: their screen passes still alternate streams)
    // an edited scene goes up on the stream that uses it first; frames in flight keep the table buffers they were launched with
    int rc = ensure_committed(r, r->frame_pipelined && r->opt_mode == 0 ? r->probe_stream : nullptr);
@@ -1449,6 +1477,15 @@ extern "C" int32_t mdh_frame_begin(mdh_renderer *r)
    r->in_frame = true;
    return MDH_OK;
 }
+// a pass of an open frame failed: close the frame and make the next one re-join every stream (the work already
+// enqueued on the probe stream is ordered against nothing else)
+static int abandon_frame(mdh_renderer *r, int rc)
+{
+   r->in_frame = false;
+   r->main_dirty = true;
+   if (r->probe_stream) (void)hipStreamSynchronize(r->probe_stream);
+   return rc;
+}
 extern "C" int32_t mdh_frame_probe_pass(mdh_renderer *r, int32_t pass)
 {
    if (!r) return seterr(MDH_E_INVALID, "null renderer");
@@ -1457,11 +1494,17 @@ extern "C" int32_t mdh_frame_probe_pass(mdh_renderer *r, int32_t pass)
    if (r->opt_mode != 0) return MDH_OK; // modes 1 and 2 draw without probes (renderers.adb:302-321 runs them anyway; nothing reads them)
    return run_pass(r, pass, frame_probe_stream(r), r->last, r->frame_cur);
 }
+static int frame_end_passes(mdh_renderer *r);
 extern "C" int32_t mdh_frame_end(mdh_renderer *r)
 {
    if (!r) return seterr(MDH_E_INVALID, "null renderer");
    if (!r->in_frame) return seterr(MDH_E_STATE, "no open frame");
    r->in_frame = false;
+   const int rc = frame_end_passes(r);
+   return rc == MDH_OK ? bound_timing(r) : abandon_frame(r, rc);
+}
+static int frame_end_passes(mdh_renderer *r)
+{
    int rc;
    const int cur = r->frame_cur;
    if (!r->frame_pipelined) {
@@ -1498,10 +1541,7 @@ extern "C" int32_t mdh_render(mdh_renderer *r)
    if (!r) return seterr(MDH_E_INVALID, "null renderer");
    int rc;
    if ((rc = mdh_frame_begin(r)) != MDH_OK) return rc;
-   if ((rc = mdh_frame_probe_pass(r, MDH_PASS_RADIANCE)) != MDH_OK || (rc = mdh_frame_probe_pass(r, MDH_PASS_IRRADIANCE)) != MDH_OK) {
-      r->in_frame = false;
-      return rc;
-   }
+   if ((rc = mdh_frame_probe_pass(r, MDH_PASS_RADIANCE)) != MDH_OK || (rc = mdh_frame_probe_pass(r, MDH_PASS_IRRADIANCE)) != MDH_OK) return abandon_frame(r, rc);
    return mdh_frame_end(r);
 }
 // the stream the probe passes of the open frame run on (what a caller's collectives must be ordered on)
@@ -1748,6 +1788,7 @@ extern "C" int32_t mdh_write_atlas_slice(mdh_renderer *r, int32_t tex, int32_t p
 extern "C" int32_t mdh_atlas_device_ptr(mdh_renderer *r, int32_t tex, void **dptr, int64_t *total_bytes, int64_t *own_offset, int64_t *own_bytes)
 {
    if (!r || (tex != MDH_TEX_RADIANCE && tex != MDH_TEX_IRRADIANCE)) return seterr(MDH_E_INVALID, "bad argument");
+   if (r->opt_rank >= r->opt_world) return seterr(MDH_E_STATE, "MDH_OPT_RANK is not below MDH_OPT_WORLD");
    int res = tex == MDH_TEX_RADIANCE ? r->probes.radiance_resolution : r->probes.irradiance_resolution;
    int b, e;
    own_probes(r, &b, &e);

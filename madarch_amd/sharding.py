@@ -25,25 +25,51 @@ from . import _binding as B
 
 
 class HostExchange:
-    """Atlas exchange through host memory and a torch.distributed group (gloo on
-    CPU, or any backend): used by the CPU tests of the sharded path and as the
-    fall-back when P is not divisible by N."""
+    """Atlas exchange through host memory and a torch.distributed group: the CPU tests of the sharded path (gloo)
+    and, on GPUs, every probe count the world size does not divide (`device` = where the backend wants its tensors:
+    RCCL needs them on the GPU).  Slices may be uneven or empty (more ranks than probes): every rank sends
+    ceil(P / N) probes' worth, padded, and takes from rank q the first P(q+1)/N - Pq/N of them."""
 
-    def __init__(self, dist, group=None):
-        self.dist, self.group = dist, group
+    def __init__(self, dist, group=None, device=None):
+        self.dist, self.group, self.device = dist, group, device
 
     def all_gather(self, renderer, tex, rank, world):
         import torch
         P = renderer.Probe_Total()
-        bounds = [(P * r // world, P * (r + 1) // world) for r in range(world)]
+        bounds = slice_bounds(P, world)
         b, e = bounds[rank]
+        cap = max(hi - lo for lo, hi in bounds)
         mine = torch.from_numpy(renderer.Read_Atlas_Slice(tex, b, e - b))
-        res = mine.shape[1]
-        outs = [torch.empty((hi - lo, res, res, 3), dtype=torch.float32) for lo, hi in bounds]
-        self.dist.all_gather(outs, mine, group=self.group)
-        for (lo, hi), t in zip(bounds, outs):
-            if hi > lo and lo != b:
-                renderer.Write_Atlas_Slice(tex, lo, t.numpy())
+        send = torch.zeros((cap,) + tuple(mine.shape[1:]), dtype=torch.float32)
+        send[:e - b] = mine
+        if self.device is not None:
+            send = send.to(self.device)
+        outs = [torch.empty_like(send) for _ in range(world)]
+        self.dist.all_gather(outs, send, group=self.group)
+        for q, (lo, hi) in enumerate(bounds):
+            if q != rank and hi > lo:
+                renderer.Write_Atlas_Slice(tex, lo, outs[q][:hi - lo].cpu().numpy())
+
+
+def slice_bounds(P, world):
+    """probe slice [begin, end) of every rank: the split own_probes() of the library makes (mdh_api.hip)"""
+    return [(P * r // world, P * (r + 1) // world) for r in range(world)]
+
+
+def slice_bytes(P, res, texel_bytes, rank, world):
+    """(offset, size) in bytes of a rank's slice of a probe-major atlas of res x res texels per probe: what
+    mdh_atlas_device_ptr reports and the in-place all-gather of DeviceExchange relies on"""
+    lo, hi = slice_bounds(P, world)[rank]
+    per = res * res * texel_bytes
+    return per * lo, per * (hi - lo)
+
+
+def make_exchange(dist, renderer, device, world, group=None):
+    """The exchange a sharded run uses: in place on the device when every rank's slice has the same size (RCCL's
+    all-gather takes equal counts), through the host otherwise."""
+    if renderer.Probe_Total() % world == 0:
+        return DeviceExchange(dist, renderer, device, group)
+    return HostExchange(dist, group, device)
 
 
 class _DevicePtr:
@@ -94,8 +120,12 @@ class DeviceExchange:
 
     def all_gather(self, renderer, tex, rank, world):
         full, off, own, total = self._view(renderer, tex)
+        res = renderer.Probes.Radiance_Resolution if tex == B.TEX_RADIANCE else renderer.Probes.Irradiance_Resolution
+        P = renderer.Probe_Total()
+        if (off, own) != slice_bytes(P, res, total // (P * res * res), rank, world):
+            raise RuntimeError("the library's slice of rank %d / %d (%d bytes at %d) is not the one the exchange assumes" % (rank, world, own, off))
         if own * world != total:
-            raise ValueError("probe count %d is not divisible by the world size %d" % (renderer.Probe_Total(), world))
+            raise ValueError("probe count %d is not divisible by the world size %d: use make_exchange(), which picks the host exchange" % (renderer.Probe_Total(), world))
         # in place: the rank's slice is the input where it lies in the output (sendbuff = recvbuff + rank * count,
         # the in-place form the collective defines) -- no staging copy, one kernel on the probe chain
         key = (full.data_ptr(), off, own)
@@ -113,8 +143,8 @@ class ShardedFrame:
 
     def __init__(self, renderer, rank, world, exchange):
         self.R, self.rank, self.world, self.exchange = renderer, rank, world, exchange
-        renderer.Set_Option(B.OPT_RANK, rank)
         renderer.Set_Option(B.OPT_WORLD, world)
+        renderer.Set_Option(B.OPT_RANK, rank)
 
     def Render(self):
         R = self.R

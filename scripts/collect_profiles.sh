@@ -1,15 +1,16 @@
 #!/bin/bash
 # On the GPU box: the bench line, the rocprofv3 kernel stats of the same command and the PMC
 # counters of its kernels (separate passes, --kernel-trace only, as MI355X_MICROARCH.md prescribes).
-# Usage: scripts/collect_profiles.sh TAG  -> gpurun_out/profiles_TAG/{bench.json,kernel_stats.csv,
-#        kernel_stats_serial.csv,traffic.json}
+# Usage: scripts/collect_profiles.sh TAG [WORKLOAD]  -> gpurun_out/profiles_TAG/{bench.json,kernel_stats.csv,
+#        kernel_stats_serial.csv,traffic.json}   (WORKLOAD: a --workload of bench.py; default: the headline config)
 TAG=${1:-run}
+WL=${2:-global_illumination_1080p_ddgi8x8x8}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/profiles_$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-python3 $ROOT/bench.py > $OUT/bench.json 2> $OUT/bench.err || exit 1
-B="python3 $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-serial-segment"
+python3 $ROOT/bench.py --workload $WL > $OUT/bench.json 2> $OUT/bench.err || exit 1
+B="python3 $ROOT/bench.py --workload $WL --steps 20 --warmup 3 --prewarm-s 0.02 --no-cpu-baseline --no-serial-segment"
 # kernel durations of the default (pipelined) schedule and of the serial one
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $B > /dev/null 2>&1
 cp $OUT/trace/*/*kernel_stats.csv $OUT/kernel_stats.csv
