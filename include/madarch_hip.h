@@ -217,7 +217,17 @@ enum {
     * straight into pinned host memory, over PCIe, beside its float store, and mdh_swap_buffers has nothing
     * to convert or copy; 0 = mdh_swap_buffers converts and copies the framebuffer itself; 2 (default) = 0
     * until the first mdh_swap_buffers, 1 from then on (a renderer that never swaps pays nothing). */
-   MDH_OPT_WINDOW = 11
+   MDH_OPT_WINDOW = 11,
+   /* M_COMPUTE_INDIRECT_SPECULAR of the screen pass (madarch-renderers.adb:138 fixes it at 2; the macro selects
+    * among four bodies at glsl/render_probes.glsl:264-272):
+    *   0 = no indirect specular;
+    *   1 = sample_radiance_with_specular (render_probes.glsl:71-136): the reflection's hit position lit by the
+    *       radiance atlases of the eight cage probes of the SHADED point, weighted by soft shadows and trilinearly;
+    *   2 (default) = sample_radiance_no_specular (:138-209): the best-facing visible cage probe of the reflection's
+    *       hit, plus that point's direct specular (M_ADD_INDIRECT_SPECULAR = 1);
+    *   3 = compute_indirect_specular (:211-244): the reflection's hit shaded in full (direct light + irradiance).
+    * textureLod on the single-level atlases is level 0 in every mode. */
+   MDH_OPT_INDIRECT_SPECULAR = 12
 };
 
 /* passes of Renderers.Render (madarch-renderers.adb:302-321) */

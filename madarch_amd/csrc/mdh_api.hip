@@ -172,7 +172,7 @@ struct mdh_renderer {
    int last_material_index = 0;
    float cam_pos[3] = {0, 0, 0}, cam_m[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}; // renderers.adb:225-226
    // options
-   int opt_atlas = 0, opt_mode = 0, opt_ao = 3, opt_gbuffer = 0, opt_rank = 0, opt_world = 1, opt_timing = 0, opt_ada_div = 1;
+   int opt_atlas = 0, opt_mode = 0, opt_ao = 3, opt_gbuffer = 0, opt_rank = 0, opt_world = 1, opt_timing = 0, opt_ada_div = 1, opt_spec = 2;
    // device state
    std::vector<float4> table_host;
    // The scene table lives in a ring of buffers: an edit (Set_Light every frame in the reference's examples) is
@@ -599,6 +599,14 @@ static KProbes make_probes(const mdh_renderer *r)
    p.inv_pcy = log2_or_neg(p.pcy) >= 0 ? 1.0f / (float)p.pcy : 0.0f;
    p.rad = r->d_rad2[r->last]; p.irr = r->d_irr2[r->last];
    own_probes(r, &p.probe_begin, &p.probe_end);
+   // the uniform fp32 values of the atlas taps: the kernels' own expressions, evaluated here once (IEEE, one rounding each)
+   p.irr_lo = 0.5f / (float)p.ires; p.irr_hi = 1.0f - p.irr_lo;
+   p.rad_lo = 0.5f / (float)p.rres; p.rad_hi = 1.0f - p.rad_lo;
+   p.irr_w = (float)(p.pcx * p.ires); p.irr_h = (float)(p.pcy * p.ires);
+   p.rad_w = (float)(p.pcx * p.rres); p.rad_h = (float)(p.pcy * p.rres);
+   p.fpcx = (float)p.pcx; p.fpcy = (float)p.pcy;
+   p.rad_lods = 0;
+   while ((2 << p.rad_lods) <= p.rres) ++p.rad_lods;
    return p;
 }
 static KCamera make_camera(const mdh_renderer *r)
@@ -829,6 +837,7 @@ extern "C" int32_t mdh_set_option(mdh_renderer *r, int32_t option, int32_t value
       r->opt_window = value; r->win_valid = false;
       break;
    case MDH_OPT_FRAME_OVERLAP: if (value < 0 || value > 2) return seterr(MDH_E_INVALID, "frame overlap is 0, 1 or 2"); r->opt_overlap = value; break;
+   case MDH_OPT_INDIRECT_SPECULAR: if (value < 0 || value > 3) return seterr(MDH_E_INVALID, "indirect specular mode is 0 .. 3"); r->opt_spec = value; break;
    default: return seterr(MDH_E_INVALID, "unknown option");
    }
    return MDH_OK;
@@ -849,6 +858,7 @@ extern "C" int32_t mdh_get_option(mdh_renderer *r, int32_t option, int32_t *valu
    case MDH_OPT_JIT: *value = r->opt_jit; break;
    case MDH_OPT_IRRADIANCE_ALL: *value = r->opt_irr_all; break;
    case MDH_OPT_WINDOW: *value = r->opt_window; break;
+   case MDH_OPT_INDIRECT_SPECULAR: *value = r->opt_spec; break;
    default: return seterr(MDH_E_INVALID, "unknown option");
    }
    return MDH_OK;
@@ -945,7 +955,7 @@ static size_t lds_bytes_march(const mdh_renderer *r) { return lds_bytes(r) + (si
 #if MDH_SCR_QVIS || defined(MDH_PHASES)
 #define MDH_SCR_PARK_DWORDS MDH_PARK_DWORDS
 #else
-#define MDH_SCR_PARK_DWORDS 15
+#define MDH_SCR_PARK_DWORDS MDH_PARK_DWORDS
 #endif
 #endif
 static size_t lds_bytes_screen(const mdh_renderer *r) { return lds_bytes(r) + (size_t)MDH_SCR_PARK_DWORDS * MDH_BLOCK * sizeof(float); }
@@ -1222,9 +1232,18 @@ template <int PART, int MODE> static void launch_screen_g(mdh_renderer *r, hipSt
    if (r->opt_gbuffer) hipLaunchKernelGGL((k_screen<PART, MODE, true>), dim3(blocks), dim3(MDH_BLOCK), lds_bytes_screen(r), st, r->ks, pr, vol, cam, a);
    else hipLaunchKernelGGL((k_screen<PART, MODE, false>), dim3(blocks), dim3(MDH_BLOCK), lds_bytes_screen(r), st, r->ks, pr, vol, cam, a);
 }
-template <int PART> static void launch_screen_m(mdh_renderer *r, hipStream_t st, const KProbes &pr, const KVolumetrics &vol, const KCamera &cam, const ScreenArgs &a, int blocks)
+// (pow2: mode 0 with probe counts and tile resolutions that are all powers of two runs the MDH_PF_POW2 variant;
+//  built for scenes without user-defined kinds only -- those compile their own variant at run time, or interpret)
+template <int PART> static void launch_screen_m(mdh_renderer *r, hipStream_t st, const KProbes &pr, const KVolumetrics &vol, const KCamera &cam, const ScreenArgs &a, int blocks, bool pow2)
 {
-   if (r->opt_mode == 0) launch_screen_g<PART, 0>(r, st, pr, vol, cam, a, blocks);
+   if (r->opt_mode == 0) {
+      if (a.spec_mode == 1 || a.spec_mode == 3) { // the other two bodies of render_probes.glsl:264-272: a variant of their own
+         if (r->opt_gbuffer) hipLaunchKernelGGL((k_screen<PART, 0, true, true>), dim3(blocks), dim3(MDH_BLOCK), lds_bytes_screen(r), st, r->ks, pr, vol, cam, a);
+         else hipLaunchKernelGGL((k_screen<PART, 0, false, true>), dim3(blocks), dim3(MDH_BLOCK), lds_bytes_screen(r), st, r->ks, pr, vol, cam, a);
+      }
+      else if (pow2 && !(PART & MDH_PF_CUSTOM)) launch_screen_g<(PART & MDH_PF_CUSTOM) ? PART : (PART | MDH_PF_POW2), 0>(r, st, pr, vol, cam, a, blocks);
+      else launch_screen_g<PART, 0>(r, st, pr, vol, cam, a, blocks);
+   }
    else if (r->opt_mode == 1) launch_screen_g<PART, 1>(r, st, pr, vol, cam, a, blocks);
    else launch_screen_g<PART, 2>(r, st, pr, vol, cam, a, blocks);
 }
@@ -1264,6 +1283,10 @@ static int run_pass(mdh_renderer *r, int pass, hipStream_t st, int src, int dst,
    for (int k = 0; k < r->npk; ++k) has_custom = has_custom || r->pk[k].type == PK_CUSTOM;
    for (int k = 0; k < r->nlk; ++k) has_custom = has_custom || r->lk[k].type == LK_CUSTOM;
    const int pf = (r->part.enable != 0 ? MDH_PF_PART : 0) | (has_custom ? MDH_PF_CUSTOM : 0);
+   // the probe-sampling kernels (radiance, mode-0 screen) have a variant for atlases whose every dimension is a power of two
+   auto is_pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
+   const bool pow2 = is_pow2(r->probes.probe_count[0]) && is_pow2(r->probes.probe_count[1]) && is_pow2(r->probes.radiance_resolution) &&
+                     is_pow2(r->probes.irradiance_resolution);
 #define MDH_LAUNCH_PF(KERNEL, GRID, BLOCK, LDS, ...)                                                      \
    do {                                                                                                   \
       switch (pf) {                                                                                       \
@@ -1288,10 +1311,14 @@ static int run_pass(mdh_renderer *r, int pass, hipStream_t st, int src, int dst,
    JitModule *jm = nullptr;
    if (jit) {
       switch (pass) {
-      case MDH_PASS_RADIANCE: snprintf(kname, sizeof kname, "k_radiance<%d>", pf); break;
+      case MDH_PASS_RADIANCE: snprintf(kname, sizeof kname, "k_radiance<%d>", pf | (pow2 ? MDH_PF_POW2 : 0)); break;
       case MDH_PASS_VISIBILITY: snprintf(kname, sizeof kname, "k_visibility<%d>", pf); break;
       case MDH_PASS_SCATTERING: snprintf(kname, sizeof kname, "k_scattering<%d>", pf); break;
-      case MDH_PASS_SCREEN: snprintf(kname, sizeof kname, "k_screen<%d, %d, %s>", pf, r->opt_mode, r->opt_gbuffer ? "true" : "false"); break;
+      case MDH_PASS_SCREEN: {
+         const bool alt = r->opt_mode == 0 && (r->opt_spec == 1 || r->opt_spec == 3);
+         snprintf(kname, sizeof kname, "k_screen<%d, %d, %s, %s>", pf | (pow2 && r->opt_mode == 0 && !alt ? MDH_PF_POW2 : 0), r->opt_mode, r->opt_gbuffer ? "true" : "false", alt ? "true" : "false");
+         break;
+      }
       default: jit = false; break;
       }
       if (jit && !(jm = jit_module(r, {kname}))) { r->opt_jit = 0; jit = false; }
@@ -1316,6 +1343,9 @@ static int run_pass(mdh_renderer *r, int pass, hipStream_t st, int src, int dst,
             struct { KScene sc; KProbes pr; } args = {r->ks, pr};
             int rc = jit_launch(jm->fn[kname], blocks, MDH_BLOCK, lds_bytes_march(r), st, args);
             if (rc != MDH_OK) return rc;
+         } else if (pow2 && !has_custom) {
+            if (pf & MDH_PF_PART) hipLaunchKernelGGL(k_radiance<MDH_PF_PART | MDH_PF_POW2>, dim3(blocks), dim3(MDH_BLOCK), lds_bytes_march(r), st, r->ks, pr);
+            else hipLaunchKernelGGL(k_radiance<MDH_PF_POW2>, dim3(blocks), dim3(MDH_BLOCK), lds_bytes_march(r), st, r->ks, pr);
          } else
             MDH_LAUNCH_PF(k_radiance, dim3(blocks), dim3(MDH_BLOCK), lds_bytes_march(r), r->ks, pr);
       }
@@ -1372,6 +1402,7 @@ static int run_pass(mdh_renderer *r, int pass, hipStream_t st, int src, int dst,
       a.n_tiles = a.tiles_x * ((r->H + 7) / 8);
       a.rank = r->opt_rank; a.world = r->opt_world;
       a.ao_steps = r->opt_ao;
+      a.spec_mode = r->opt_spec;
       a.fb = r->d_fb2[fbix]; a.gb_index = (int *)r->d_gb2[fbix][0]; a.gb_t = (float *)r->d_gb2[fbix][1]; a.gb_steps = (int *)r->d_gb2[fbix][2];
       a.window = nullptr;
       if (r->opt_window == 1 || (r->opt_window == 2 && r->swaps > 0)) { // the window's pixels straight into pinned host memory (mdh_swap_buffers)
@@ -1391,10 +1422,10 @@ static int run_pass(mdh_renderer *r, int pass, hipStream_t st, int src, int dst,
             if (rc != MDH_OK) return rc;
          } else
          switch (pf) {
-         case 0: launch_screen_m<0>(r, st, pr, vol, cam, a, blocks); break;
-         case 1: launch_screen_m<1>(r, st, pr, vol, cam, a, blocks); break;
-         case 2: launch_screen_m<2>(r, st, pr, vol, cam, a, blocks); break;
-         default: launch_screen_m<3>(r, st, pr, vol, cam, a, blocks); break;
+         case 0: launch_screen_m<0>(r, st, pr, vol, cam, a, blocks, pow2); break;
+         case 1: launch_screen_m<1>(r, st, pr, vol, cam, a, blocks, pow2); break;
+         case 2: launch_screen_m<2>(r, st, pr, vol, cam, a, blocks, pow2); break;
+         default: launch_screen_m<3>(r, st, pr, vol, cam, a, blocks, pow2); break;
          }
       }
       break;

@@ -100,6 +100,15 @@ struct KProbes {
    void *rad;         // probe-major [probe][y][x]
    void *irr;
    int probe_begin, probe_end; // slice this rank updates
+   // Wave-uniform fp32 values the pixel program needs at every atlas tap, computed once on the host with the same
+   // IEEE operations (one correctly rounded division / subtraction / conversion each): as kernel arguments they are
+   // scalar operands; computed in the kernel they are vector instructions on uniform data that the compiler hoists
+   // into VGPRs which then stay live (or spilled to scratch) through the whole pixel program.
+   float irr_lo, irr_hi; // 0.5f / ires, 1.0f - irr_lo: the clamp of an irradiance tap inside its tile (render_probes.glsl:53-57)
+   float rad_lo, rad_hi; // 0.5f / rres, 1.0f - rad_lo (render_probes.glsl:190-194)
+   float irr_w, irr_h, rad_w, rad_h; // (float)(pcx * ires), (float)(pcy * ires), (float)(pcx * rres), (float)(pcy * rres)
+   float fpcx, fpcy;     // (float)pcx, (float)pcy
+   int rad_lods;         // radiance_lods = int(log2(radiance_resolution)) (probe_utils.glsl:17): the highest set bit
 };
 
 struct KCamera {
@@ -115,6 +124,17 @@ struct KVolumetrics {
    float *vis;   // 3 floats per texel
    float4 *scat; // rgb + ray length
 };
+
+// The lane's index in its wavefront taken from the hardware at the point of use (two instructions, no inputs).  A
+// volatile statement is neither hoisted nor merged with an earlier one: what is derived from it (the pixel of the
+// screen pass's epilogue, the thread's LDS park row) is recomputed where it is needed instead of being kept in a
+// VGPR -- or in scratch -- across the whole pixel program.
+MDH_DEV int lane_index_fresh()
+{
+   int l;
+   asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+   return l;
+}
 
 // ------------------------------------------------------------------------------ vec math
 struct f3 { float x, y, z; };
@@ -799,9 +819,10 @@ template <bool INFO, bool CUSTOM> MDH_DEV float partitioning_lookup(const KScene
 #endif
    return closest;
 }
-// PART is a set of flags: bit 0 = the space partition is on, bit 1 = the scene has user-defined kinds
+// PART is a set of flags: bit 0 = the space partition is on, bit 1 = the scene has user-defined kinds,
 #define MDH_PF_PART 1
 #define MDH_PF_CUSTOM 2
+#define MDH_PF_POW2 4 // bit 2 = the probe counts and both tile resolutions are powers of two (every atlas address is shifts and masks)
 template <int PART> MDH_DEV float sdf(const KScene &sc, f3 x)
 {
    int dummy;
@@ -955,12 +976,12 @@ MDH_DEV i3 world_to_grid(const KProbes &pr, f3 p)
 }
 MDH_DEV int grid_to_probe_id(const KProbes &pr, i3 g) { return g.z * pr.gx * pr.gy + g.y * pr.gx + g.x; }
 // x / probe_count: a multiplication when the count is a power of two (exact: the same real value, rounded once)
-MDH_DEV float div_pcx(const KProbes &pr, float x) { return pr.inv_pcx != 0.0f ? x * pr.inv_pcx : x / (float)pr.pcx; }
-MDH_DEV float div_pcy(const KProbes &pr, float y) { return pr.inv_pcy != 0.0f ? y * pr.inv_pcy : y / (float)pr.pcy; }
-MDH_DEV f2 probe_id_to_coord(const KProbes &pr, int id)
+template <bool P2 = false> MDH_DEV float div_pcx(const KProbes &pr, float x) { return (P2 || pr.inv_pcx != 0.0f) ? x * pr.inv_pcx : x / pr.fpcx; }
+template <bool P2 = false> MDH_DEV float div_pcy(const KProbes &pr, float y) { return (P2 || pr.inv_pcy != 0.0f) ? y * pr.inv_pcy : y / pr.fpcy; }
+template <bool P2 = false> MDH_DEV f2 probe_id_to_coord(const KProbes &pr, int id)
 {
-   int y = pr.pcx_shift >= 0 ? (id >> pr.pcx_shift) : (id / pr.pcx), x = id - y * pr.pcx;
-   return F2(div_pcx(pr, (float)x), div_pcy(pr, (float)y));
+   int y = (P2 || pr.pcx_shift >= 0) ? (id >> pr.pcx_shift) : (id / pr.pcx), x = id - y * pr.pcx;
+   return F2(div_pcx<P2>(pr, (float)x), div_pcy<P2>(pr, (float)y));
 }
 // glsl/probe_utils.glsl:58-92
 MDH_DEV float sign_not_zero(float v) { return v >= 0.0f ? 1.0f : -1.0f; }
@@ -990,12 +1011,18 @@ MDH_DEV f2 ray_dir_to_ray_id(f3 d)
 }
 
 // -------------------------------------------------------------------------- textures
-// GL_MIRRORED_REPEAT (support/render_passes.adb:111-112)
-MDH_DEV int mirror(int i, int n)
+// GL_MIRRORED_REPEAT (support/render_passes.adb:111-112).  P2: n is a power of two (the modulo is a mask; with a
+// runtime divisor the compiler hoists the reciprocal set-up of every distinct divisor into VGPRs that stay live through
+// the whole kernel -- seven of them in the screen pass, four of which ended up in scratch)
+template <bool P2 = false> MDH_DEV int mirror(int i, int n)
 {
    if ((unsigned)i < (unsigned)n) return i; // inside the image: the usual case, no integer division
-   int m = i % (2 * n);
-   if (m < 0) m += 2 * n;
+   int m;
+   if (P2) m = i & (2 * n - 1);
+   else {
+      m = i % (2 * n);
+      if (m < 0) m += 2 * n;
+   }
    return m >= n ? 2 * n - 1 - m : m;
 }
 MDH_DEV float unorm8(float x) { return (x != x) ? 0.0f : __builtin_rintf(clamp_(x, 0.0f, 1.0f) * 255.0f); }
@@ -1004,10 +1031,10 @@ MDH_DEV float unorm8(float x) { return (x != x) ? 0.0f : __builtin_rintf(clamp_(
 // rank's probe slice is one contiguous range (DESIGN.md "HBM layout").  (X, Y) are texel
 // coordinates of the reference's 2-D atlas image, X = tile_x * res + x.
 // `shift` = log2(res) when res is a power of two (wave-uniform fast path), else -1
-MDH_DEV unsigned atlas_index(int pcx, int res, int shift, int X, int Y)
+template <bool P2 = false> MDH_DEV unsigned atlas_index(int pcx, int res, int shift, int X, int Y)
 {
    int tx, ty;
-   if (shift >= 0) { tx = X >> shift; ty = Y >> shift; }
+   if (P2 || shift >= 0) { tx = X >> shift; ty = Y >> shift; }
    else { tx = X / res; ty = Y / res; }
    return ((unsigned)(ty * pcx + tx) * res + (Y - ty * res)) * res + (X - tx * res);
 }
@@ -1034,17 +1061,18 @@ MDH_DEV void atlas_store(void *base, int fmt, unsigned idx, f3 v)
       ((float4 *)base)[idx] = t;
    }
 }
-// GL_LINEAR on the atlas image of pcx*res x pcy*res texels (render_passes.adb:113-114)
-MDH_DEV f3 atlas_sample(const void *base, int fmt, int pcx, int pcy, int res, int shift, float cx, float cy, int u8_tab)
+// GL_LINEAR on the atlas image of pcx*res x pcy*res texels (render_passes.adb:113-114); Wf, Hf = (float)(pcx * res), (float)(pcy * res)
+template <bool P2 = false>
+MDH_DEV f3 atlas_sample(const void *base, int fmt, int pcx, int pcy, int res, int shift, float Wf, float Hf, float cx, float cy, int u8_tab)
 {
    const int W = pcx * res, H = pcy * res;
-   float px = cx * (float)W - 0.5f, py = cy * (float)H - 0.5f;
+   float px = cx * Wf - 0.5f, py = cy * Hf - 0.5f;
    float fx0 = __builtin_floorf(px), fy0 = __builtin_floorf(py);
    float fx = px - fx0, fy = py - fy0;
-   int x0 = mirror((int)fx0, W), x1 = mirror((int)fx0 + 1, W), y0 = mirror((int)fy0, H), y1 = mirror((int)fy0 + 1, H);
+   int x0 = mirror<P2>((int)fx0, W), x1 = mirror<P2>((int)fx0 + 1, W), y0 = mirror<P2>((int)fy0, H), y1 = mirror<P2>((int)fy0 + 1, H);
    float w00 = (1.0f - fx) * (1.0f - fy), w10 = fx * (1.0f - fy), w01 = (1.0f - fx) * fy, w11 = fx * fy;
-   f3 a = atlas_texel(base, fmt, atlas_index(pcx, res, shift, x0, y0), u8_tab), b = atlas_texel(base, fmt, atlas_index(pcx, res, shift, x1, y0), u8_tab);
-   f3 c = atlas_texel(base, fmt, atlas_index(pcx, res, shift, x0, y1), u8_tab), d = atlas_texel(base, fmt, atlas_index(pcx, res, shift, x1, y1), u8_tab);
+   f3 a = atlas_texel(base, fmt, atlas_index<P2>(pcx, res, shift, x0, y0), u8_tab), b = atlas_texel(base, fmt, atlas_index<P2>(pcx, res, shift, x1, y0), u8_tab);
+   f3 c = atlas_texel(base, fmt, atlas_index<P2>(pcx, res, shift, x0, y1), u8_tab), d = atlas_texel(base, fmt, atlas_index<P2>(pcx, res, shift, x1, y1), u8_tab);
    return ((a * w00 + b * w10) + c * w01) + d * w11;
 }
 
@@ -1056,16 +1084,17 @@ struct AtlasTap {
    unsigned t00, t10, t01, t11; // RGBA8 texels; float4 atlases: the four texel indices
    float fx, fy;
 };
-MDH_DEV AtlasTap atlas_tap_issue(const void *base, int fmt, int pcx, int pcy, int res, int shift, float cx, float cy)
+template <bool P2 = false>
+MDH_DEV AtlasTap atlas_tap_issue(const void *base, int fmt, int pcx, int pcy, int res, int shift, float Wf, float Hf, float cx, float cy)
 {
    const int W = pcx * res, H = pcy * res;
-   float px = cx * (float)W - 0.5f, py = cy * (float)H - 0.5f;
+   float px = cx * Wf - 0.5f, py = cy * Hf - 0.5f;
    float fx0 = __builtin_floorf(px), fy0 = __builtin_floorf(py);
    AtlasTap t;
    t.fx = px - fx0; t.fy = py - fy0;
-   int x0 = mirror((int)fx0, W), x1 = mirror((int)fx0 + 1, W), y0 = mirror((int)fy0, H), y1 = mirror((int)fy0 + 1, H);
-   t.t00 = atlas_index(pcx, res, shift, x0, y0); t.t10 = atlas_index(pcx, res, shift, x1, y0);
-   t.t01 = atlas_index(pcx, res, shift, x0, y1); t.t11 = atlas_index(pcx, res, shift, x1, y1);
+   int x0 = mirror<P2>((int)fx0, W), x1 = mirror<P2>((int)fx0 + 1, W), y0 = mirror<P2>((int)fy0, H), y1 = mirror<P2>((int)fy0 + 1, H);
+   t.t00 = atlas_index<P2>(pcx, res, shift, x0, y0); t.t10 = atlas_index<P2>(pcx, res, shift, x1, y0);
+   t.t01 = atlas_index<P2>(pcx, res, shift, x0, y1); t.t11 = atlas_index<P2>(pcx, res, shift, x1, y1);
    if (fmt == 0) {
       const unsigned *b = (const unsigned *)base;
       t.t00 = b[t.t00]; t.t10 = b[t.t10]; t.t01 = b[t.t01]; t.t11 = b[t.t11];
@@ -1100,7 +1129,7 @@ template <int C> MDH_DEV void tex_sample(const float *data, int W, int H, float 
    float px = cx * (float)W - 0.5f, py = cy * (float)H - 0.5f;
    float fx0 = __builtin_floorf(px), fy0 = __builtin_floorf(py);
    float fx = px - fx0, fy = py - fy0;
-   int x0 = mirror((int)fx0, W), x1 = mirror((int)fx0 + 1, W), y0 = mirror((int)fy0, H), y1 = mirror((int)fy0 + 1, H);
+   int x0 = mirror<false>((int)fx0, W), x1 = mirror<false>((int)fx0 + 1, W), y0 = mirror<false>((int)fy0, H), y1 = mirror<false>((int)fy0 + 1, H);
    float w00 = (1.0f - fx) * (1.0f - fy), w10 = fx * (1.0f - fy), w01 = (1.0f - fx) * fy, w11 = fx * fy;
    const float *a = data + ((size_t)y0 * W + x0) * C, *b = data + ((size_t)y0 * W + x1) * C;
    const float *c = data + ((size_t)y1 * W + x0) * C, *d = data + ((size_t)y1 * W + x1) * C;

@@ -65,6 +65,7 @@ struct ScreenArgs {
    int tiles_x, n_tiles; // 8x8 tiles of the whole image
    int rank, world;      // this launch draws tiles rank, rank + world, ...
    int ao_steps;
+   int spec_mode; // M_COMPUTE_INDIRECT_SPECULAR (MDH_OPT_INDIRECT_SPECULAR)
    float4 *fb; // W*H, row 0 = top
    int *gb_index;
    float *gb_t;
@@ -73,56 +74,89 @@ struct ScreenArgs {
 };
 
 // draw_screen.glsl:20-30.  One wavefront per 8x8 pixel tile: lane = (y & 7) * 8 + (x & 7);
-// the tile's 64 pixels run through the ray state machine of mdh_march.h together.
-template <int PART, int MODE, bool GBUF>
+// the tile's 64 pixels walk the structured pixel program of mdh_march.h together.
+//
+// Nothing of the prologue stays live across the pixel program: the pixel's coordinates, its camera ray and the
+// arguments only the epilogue needs (volumetrics, framebuffer, camera) are derived AGAIN after it, from the kernel
+// argument segment read through a pointer the compiler cannot trace back and from a lane index taken from the hardware
+// (tile_pixel).  Kept live they cost ~10 VGPRs and ~20 SGPRs which the compiler spilled to scratch (80 bytes per
+// lane written and read back through HBM: 172 MB per launch at 1080p against a 33 MB framebuffer).
+MDH_DEV void tile_pixel(const ScreenArgs &a, int tile, int lane, int &i, int &j, float &u, float &v)
+{
+   i = (tile % a.tiles_x) * 8 + (lane & 7);
+   j = (tile / a.tiles_x) * 8 + (lane >> 3);
+   u = centre(i, a.W);
+   v = -centre(j, a.H); // row 0 = top
+}
+// ALT: the variant whose second shaded point runs render_probes.glsl's other two indirect-specular bodies (modes 1 and 3)
+template <int PART, int MODE, bool GBUF, bool ALT = false>
 __global__ __launch_bounds__(MDH_BLOCK, MDH_OCC(PART)) void k_screen(KScene sc, KProbes pr, KVolumetrics vol, KCamera cam, ScreenArgs a)
 {
    stage_table(sc);
-   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
    const int own = blockIdx.x * (MDH_BLOCK / 64) + wave;
    const int tile = a.rank + own * a.world;
    if (tile >= a.n_tiles) return; // wave-uniform
    PH_KERNEL_BEGIN();
-   const int i = (tile % a.tiles_x) * 8 + (lane & 7), j = (tile / a.tiles_x) * 8 + (lane >> 3);
-   const bool valid = i < a.W && j < a.H;
-   const float u = centre(i, a.W), v = -centre(j, a.H); // row 0 = top
-   f3 origin, dir;
-   camera_ray(cam, u, v, origin, dir);
-   MachineCfg cfg; // renderers.adb:136-143
-   cfg.direct_specular = true;
-   cfg.indirect_specular = true;
-   cfg.ao_steps = a.ao_steps;
+   f3 c;
    PrimaryHit ph;
    bool hit;
    f3 pos;
-   f3 c = MDH_SHADE<PART, MODE, true, MDH_SCR_QVIS != 0>(sc, pr, cfg, valid, origin, dir, ph, hit, pos);
-#ifdef MDH_PHASES
-   if (!valid) { PH_KERNEL_END(); return; }
-#endif
-   if (!valid) return;
+   {
+      int i, j;
+      float u, v;
+      tile_pixel(a, tile, lane, i, j, u, v);
+      const bool valid = i < a.W && j < a.H;
+      f3 origin, dir;
+      camera_ray(cam, u, v, origin, dir);
+      MachineCfg cfg; // renderers.adb:136-143
+      cfg.direct_specular = true;
+      cfg.spec_mode = a.spec_mode;
+      cfg.ao_steps = a.ao_steps;
+      c = MDH_SHADE<PART, MODE, ALT ? 2 : 1, MDH_SCR_QVIS != 0>(sc, pr, cfg, valid, origin, dir, ph, hit, pos);
+   }
 #if MDH_RELOAD_ARGS
-   // The arguments only the epilogue needs (volumetrics, the framebuffer) are read again from the kernel
-   // argument segment here, through a pointer the compiler cannot trace back: it then does not keep ~20
-   // scalar registers of them alive (or spilled to vector lanes) across the whole pixel program.
    struct KArgs { KScene sc; KProbes pr; KVolumetrics vol; KCamera cam; ScreenArgs a; };
    typedef const KArgs __attribute__((address_space(4))) *KArgsPtr; // constant address space: scalar loads
    KArgsPtr ka = (KArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
    asm volatile("" : "+s"(ka));
    KVolumetrics vol2;
    ScreenArgs a2;
+   KCamera cam2;
    {
       typedef const int __attribute__((address_space(4))) *IntPtr;
-      IntPtr pv = (IntPtr)&ka->vol, pa = (IntPtr)&ka->a;
-      int *dv = (int *)&vol2, *da = (int *)&a2;
+      IntPtr pv = (IntPtr)&ka->vol, pa = (IntPtr)&ka->a, pc = (IntPtr)&ka->cam;
+      int *dv = (int *)&vol2, *da = (int *)&a2, *dc = (int *)&cam2;
 #pragma unroll
       for (int q = 0; q < (int)(sizeof(KVolumetrics) / 4); ++q) dv[q] = pv[q];
 #pragma unroll
       for (int q = 0; q < (int)(sizeof(ScreenArgs) / 4); ++q) da[q] = pa[q];
+#pragma unroll
+      for (int q = 0; q < (int)(sizeof(KCamera) / 4); ++q) dc[q] = pc[q];
    }
 #define vol vol2
 #define a a2
+#define cam cam2
 #endif
-   if (MODE == 0 && vol.enabled) c = render_volumetrics(sc, vol, c, origin, pos, hit, F2(u, v));
+   // the pixel again (the same integer and fp32 operations on the same inputs: the same values)
+   int i, j;
+   float u, v;
+   {
+      int wave2 = wave;
+      asm volatile("" : "+s"(wave2));
+      const int tile2 = a.rank + ((int)blockIdx.x * (MDH_BLOCK / 64) + wave2) * a.world;
+      tile_pixel(a, tile2, lane_index_fresh(), i, j, u, v);
+   }
+   const bool valid = i < a.W && j < a.H;
+#ifdef MDH_PHASES
+   if (!valid) { PH_KERNEL_END(); return; }
+#endif
+   if (!valid) return;
+   if (MODE == 0 && vol.enabled) {
+      f3 origin, dir;
+      camera_ray(cam, u, v, origin, dir);
+      c = render_volumetrics(sc, vol, c, origin, pos, hit, F2(u, v));
+   }
    if (MODE != 1) // draw_screen.glsl:29
       c = F3(pow_(c.x / (c.x + 1.0f), 0.4545f), pow_(c.y / (c.y + 1.0f), 0.4545f), pow_(c.z / (c.z + 1.0f), 0.4545f));
    const size_t px = (size_t)j * a.W + i;
@@ -136,6 +170,7 @@ __global__ __launch_bounds__(MDH_BLOCK, MDH_OCC(PART)) void k_screen(KScene sc, 
 #if MDH_RELOAD_ARGS
 #undef vol
 #undef a
+#undef cam
 #endif
    PH_KERNEL_END();
 }
@@ -180,12 +215,12 @@ template <int PART> __global__ __launch_bounds__(MDH_BLOCK, MDH_OCC_RAD(PART)) v
    const f3 ray_dir = ray_id_to_ray_dir(F2(fract_(nc.x * (float)pr.pcx), fract_(nc.y * (float)pr.pcy)));
    MachineCfg cfg; // renderers.adb:115-117: no specular; AO and volumetrics macros undefined
    cfg.direct_specular = false;
-   cfg.indirect_specular = false;
+   cfg.spec_mode = 0;
    cfg.ao_steps = 0;
    PrimaryHit ph;
    bool hit;
    f3 pos;
-   f3 c = MDH_SHADE<PART, 0, false, MDH_RAD_QVIS != 0>(sc, pr, cfg, valid, world, ray_dir, ph, hit, pos);
+   f3 c = MDH_SHADE<PART, 0, 0, MDH_RAD_QVIS != 0>(sc, pr, cfg, valid, world, ray_dir, ph, hit, pos);
    if (valid) atlas_store(pr.rad, pr.fmt, atlas_index(pr.pcx, pr.rres, pr.rshift, i, j), c);
    PH_KERNEL_END();
 }
@@ -226,7 +261,7 @@ __global__ __launch_bounds__(MDH_IRR_BLOCK) void k_irradiance(KProbes pr)
    do {                                                                                                                 \
       const int yy = (tap_) / pr.rres, xx = (tap_) - yy * pr.rres;                                                       \
       f2 c = F2(clamp_(rad_coord.x + (float)xx * step.x, step.x, 1.0f - step.x), clamp_(rad_coord.y + (float)yy * step.y, step.y, 1.0f - step.y)); \
-      f3 rad = atlas_sample(pr.rad, pr.fmt, pr.pcx, pr.pcy, pr.rres, pr.rshift, c.x, c.y, -1);                          \
+      f3 rad = atlas_sample(pr.rad, pr.fmt, pr.pcx, pr.pcy, pr.rres, pr.rshift, pr.rad_w, pr.rad_h, c.x, c.y, -1);      \
       f3 rad_dir = ray_id_to_ray_dir(F2(fract_(c.x * pcx), fract_(c.y * pcy)));                                          \
       s_taps[2 * (slot_)] = make_float4(rad.x, rad.y, rad.z, 1.0f);                                                      \
       s_taps[2 * (slot_) + 1] = make_float4(rad_dir.x, rad_dir.y, rad_dir.z, 0.0f);                                      \

@@ -27,7 +27,7 @@
 
 struct MachineCfg {
    bool direct_specular;   // M_COMPUTE_DIRECT_SPECULAR
-   bool indirect_specular; // M_COMPUTE_INDIRECT_SPECULAR == 2
+   int spec_mode;          // M_COMPUTE_INDIRECT_SPECULAR: 0 none, 1 .. 3 the three bodies of render_probes.glsl:264-272
    int ao_steps;           // M_AMBIENT_OCCLUSION_STEPS
 };
 
@@ -70,7 +70,7 @@ __device__ unsigned long long g_diag[16];
 // -DMDH_PHASES: wall cycles (s_memtime) per wave spent in each region of the pixel program, summed over waves
 #ifdef MDH_PHASES
 __device__ unsigned long long g_phase[16];
-#define MDH_PH_SLOT 18 // one extra park slot: 32 u64 accumulators per wave
+#define MDH_PH_SLOT 20 // one extra park slot: 32 u64 accumulators per wave
 MDH_DEV unsigned long long *ph_acc_(float *pk) { return (unsigned long long *)(pk + MDH_PH_SLOT * MDH_BLOCK + (threadIdx.x & ~63)); }
 MDH_DEV void ph_add_(float *pk, int id, unsigned long long dt)
 {
@@ -133,21 +133,89 @@ template <int PART> MDH_DEV bool march_plain(const KScene &sc, f3 o, f3 d, float
 // irradiance -- is cold while the reflection's point is shaded: parking it takes 15 VGPRs
 // out of the live set of the inner loops, where hipcc would otherwise spill them to scratch
 // (HBM round trips inside the probe loop; measured 47 % of the wave's cycles waiting).
+// slots: 0-2 P, 3-5 N, 6-8 view direction, 9-11 direct light, 12-14 irradiance, 15-17 the reflection's colour,
+// 18 material id; the visibility queue (radiance pass) uses 12-15 for its entries, 16 and 17 for first step and result
+// before the irradiance is parked
+#define MDH_PARK_SPEC 15
+#define MDH_PARK_MAT 18
+#define MDH_PARK_TAPX 19 // screen pass: the x fraction of the corner's irradiance tap during its visibility march
+#ifndef MDH_PARK_TAP
+#define MDH_PARK_TAP 1
+#endif
 #ifdef MDH_PHASES
-#define MDH_PARK_DWORDS 19
+#define MDH_PARK_DWORDS 21
 #else
-#define MDH_PARK_DWORDS 18
+#define MDH_PARK_DWORDS 20
 #endif
 MDH_DEV float *park_base(const KScene &sc) { return (float *)(s_tab + sc.table_f4); }
-MDH_DEV void park_store3(float *pk, int slot, f3 v)
+// A thread's own column of the park rows is addressed WITHOUT an address register: ds_write_addtid_b32 /
+// ds_read_addtid_b32 take M0[15:0] + offset + 4 * lane (scripts/addtid_probe.hip checks that on the box), so a park
+// access costs one LDS instruction per dword and one scalar -- the LDS byte address of the wave's 64 columns in row 0
+// -- stays live instead of a per-lane address that the compiler kept in scratch.  M0 is saved and restored (it is
+// compiler-reserved); `s_nop 0`: one wait state between a write of M0 and an LDS add-TID instruction.  The reads wait
+// for their data inside the statement (the compiler does not count the LDS operations of an asm statement).
+#ifndef MDH_PARK_ADDTID
+#define MDH_PARK_ADDTID 1
+#endif
+MDH_DEV int park_wave_base(const float *pk)
 {
-   pk[(slot + 0) * MDH_BLOCK + threadIdx.x] = v.x;
-   pk[(slot + 1) * MDH_BLOCK + threadIdx.x] = v.y;
-   pk[(slot + 2) * MDH_BLOCK + threadIdx.x] = v.z;
+   const unsigned lds = (unsigned)(size_t)(const __attribute__((address_space(3))) float *)pk;
+   return __builtin_amdgcn_readfirstlane((int)(lds + (threadIdx.x & ~63u) * 4u));
 }
-MDH_DEV f3 park_load3(const float *pk, int slot)
+MDH_DEV int park_col(const float *pk, int wb) // (the generic form: thread index in the park rows)
 {
-   return F3(pk[(slot + 0) * MDH_BLOCK + threadIdx.x], pk[(slot + 1) * MDH_BLOCK + threadIdx.x], pk[(slot + 2) * MDH_BLOCK + threadIdx.x]);
+   const unsigned lds = (unsigned)(size_t)(const __attribute__((address_space(3))) float *)pk;
+   return (int)((unsigned)wb - lds) / 4 + lane_index_fresh();
+}
+template <int SLOT> MDH_DEV void park_store3(float *pk, int wb, f3 v)
+{
+#if MDH_PARK_ADDTID
+   unsigned keep;
+   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tds_write_addtid_b32 %1 offset:%5\n\tds_write_addtid_b32 %2 offset:%6\n\t"
+                "ds_write_addtid_b32 %3 offset:%7\n\ts_mov_b32 m0, %0"
+                : "=&s"(keep) : "v"(v.x), "v"(v.y), "v"(v.z), "s"(wb), "i"(SLOT * MDH_BLOCK * 4), "i"((SLOT + 1) * MDH_BLOCK * 4), "i"((SLOT + 2) * MDH_BLOCK * 4) : "memory");
+#else
+   const int t = park_col(pk, wb);
+   pk[(SLOT + 0) * MDH_BLOCK + t] = v.x;
+   pk[(SLOT + 1) * MDH_BLOCK + t] = v.y;
+   pk[(SLOT + 2) * MDH_BLOCK + t] = v.z;
+#endif
+}
+template <int SLOT> MDH_DEV f3 park_load3(const float *pk, int wb)
+{
+#if MDH_PARK_ADDTID
+   unsigned keep;
+   f3 v;
+   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tds_read_addtid_b32 %1 offset:%5\n\tds_read_addtid_b32 %2 offset:%6\n\t"
+                "ds_read_addtid_b32 %3 offset:%7\n\ts_waitcnt lgkmcnt(0)\n\ts_mov_b32 m0, %0"
+                : "=&s"(keep), "=&v"(v.x), "=&v"(v.y), "=&v"(v.z) : "s"(wb), "i"(SLOT * MDH_BLOCK * 4), "i"((SLOT + 1) * MDH_BLOCK * 4), "i"((SLOT + 2) * MDH_BLOCK * 4) : "memory");
+   return v;
+#else
+   const int t = park_col(pk, wb);
+   return F3(pk[(SLOT + 0) * MDH_BLOCK + t], pk[(SLOT + 1) * MDH_BLOCK + t], pk[(SLOT + 2) * MDH_BLOCK + t]);
+#endif
+}
+template <int SLOT> MDH_DEV void park_store1(float *pk, int wb, float v)
+{
+#if MDH_PARK_ADDTID
+   unsigned keep;
+   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tds_write_addtid_b32 %1 offset:%3\n\ts_mov_b32 m0, %0"
+                : "=&s"(keep) : "v"(v), "s"(wb), "i"(SLOT * MDH_BLOCK * 4) : "memory");
+#else
+   pk[SLOT * MDH_BLOCK + park_col(pk, wb)] = v;
+#endif
+}
+template <int SLOT> MDH_DEV float park_load1(const float *pk, int wb)
+{
+#if MDH_PARK_ADDTID
+   unsigned keep;
+   float v;
+   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tds_read_addtid_b32 %1 offset:%3\n\ts_waitcnt lgkmcnt(0)\n\ts_mov_b32 m0, %0"
+                : "=&s"(keep), "=&v"(v) : "s"(wb), "i"(SLOT * MDH_BLOCK * 4) : "memory");
+   return v;
+#else
+   return pk[SLOT * MDH_BLOCK + park_col(pk, wb)];
+#endif
 }
 
 
@@ -248,21 +316,82 @@ MDH_DEV int queued_visibility(const KScene &sc, const KProbes &pr, float *pk, f3
    return bits | words[threadIdx.x];
 }
 
-template <int PART, int MODE, bool REFLECT, bool QVIS>
+// sample_radiance_with_specular (render_probes.glsl:71-136, M_COMPUTE_INDIRECT_SPECULAR == 1) from the reflection's hit
+// position on: the eight cage probes of the FIRST point (parked: slots 0-2, its material id in MDH_PARK_MAT) light
+// that position, each weighted by a soft shadow ray from it towards the probe (k = 0.5, raymarching.glsl:4-23 with
+// its min_dist) and the trilinear factor of the first point.  textureLod is level 0 (one level): lod
+// only narrows the clamp of the tap; a total weight of 0 gives 0.
+template <int PART>
+MDH_DEV f3 radiance_with_specular(const KScene &sc, const KProbes &pr, const float *pk, int wb, f3 spec_pos, int u8_tab)
+{
+   const f3 pos = park_load3<0>(pk, wb);
+   const float roughness = tab_float((sc.mat_slot + 2 * __float_as_int(park_load1<MDH_PARK_MAT>(pk, wb)) + 1) * 4);
+   const f3 pos_to_spec_pos = spec_pos - pos;
+   const i3 gp = world_to_grid(pr, pos);
+   const f3 alpha = pos / F3(pr.sx, pr.sy, pr.sz) - F3((float)gp.x, (float)gp.y, (float)gp.z);
+   const float lod = mix_(0.0f, (float)pr.rad_lods, roughness * 2.0f);
+   const int new_res = pr.rres / (int)(lod + 1.0f);
+   const float rmin = 0.5f / (float)new_res, rmax = 1.0f - rmin;
+   float total_weight = 0.0f;
+   f3 radiance = F3(0.0f, 0.0f, 0.0f);
+#pragma unroll 1
+   for (int i = 0; i < 8; ++i) {
+      const i3 q = cage_probe(pr, gp, i);
+      f3 pts = (pos - grid_to_world(pr, q)) + pos_to_spec_pos; // probe_to_spec
+      const float distance = length(pts);
+      pts = pts / distance;
+      float res = 1.0f, prev = 1e20f;
+      bool blocked = false;
+      const float tmax = distance - MDH_MIN_STEP * 5.0f;
+      for (float total = MDH_MIN_STEP * 5.0f; total < tmax;) { // softshadows (spec_pos, -probe_to_spec, .., 0.5)
+         const float dist = sdf<PART>(sc, spec_pos + (-pts) * total);
+         if (dist < MDH_EPS) { blocked = true; break; }
+         const float y = dist * dist / (2.0f * prev);
+         const float d = sqrt_(dist * dist - y * y);
+         res = min_(res, 0.5f * d / max_(0.0f, total - y));
+         prev = dist;
+         total += dist;
+      }
+      float weight = max_(blocked ? 0.0f : res, 0.001f);
+      const f3 tri = F3(mix_(1.0f - alpha.x, alpha.x, (float)(i & 1)), mix_(1.0f - alpha.y, alpha.y, (float)((i >> 1) & 1)),
+                        mix_(1.0f - alpha.z, alpha.z, (float)((i >> 2) & 1)));
+      weight *= tri.x * tri.y * tri.z;
+      const f2 base = probe_id_to_coord(pr, grid_to_probe_id(pr, q));
+      f2 rid = ray_dir_to_ray_id(pts);
+      rid = F2(clamp_(rid.x, rmin, rmax), clamp_(rid.y, rmin, rmax));
+      const f3 tx = atlas_sample(pr.rad, pr.fmt, pr.pcx, pr.pcy, pr.rres, pr.rshift, pr.rad_w, pr.rad_h, base.x + div_pcx(pr, rid.x), base.y + div_pcy(pr, rid.y), u8_tab);
+      radiance = radiance + tx * weight;
+      total_weight += weight;
+   }
+   if (total_weight == 0.0f) return F3(0.0f, 0.0f, 0.0f);
+   return radiance / total_weight;
+}
+
+// SPEC: 0 = no second point (the radiance pass), 1 = the reflection as the reference's renderer fixes it
+// (M_COMPUTE_INDIRECT_SPECULAR = 2, or none), 2 = the kernel variant that holds the two other bodies of
+// render_probes.glsl:264-272 (cfg.spec_mode 1 or 3; MDH_OPT_INDIRECT_SPECULAR)
+template <int PART, int MODE, int SPEC, bool QVIS>
 MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCfg cfg, bool lane_valid, f3 from, f3 dir_in,
                             PrimaryHit &ph, bool &hit, f3 &pos_out)
 {
+   constexpr bool P2 = (PART & MDH_PF_POW2) != 0;
+   constexpr bool REFLECT = SPEC != 0;
+   // the second point goes through the whole of pixel_color_probes' lighting (compute_indirect_specular) ...
+   const bool full2 = SPEC == 2 && cfg.spec_mode == 3;
+   // ... or is only a position that the cage probes of the FIRST point light (sample_radiance_with_specular)
+   const bool cage1 = SPEC == 2 && cfg.spec_mode == 1;
    const int u8_tab = sc.u8_slot * 4;
    float *pk = park_base(sc);
+   const int wb = park_wave_base(pk);
    hit = false;
    ph.index = -1; ph.t = 0.0f; ph.steps = 0;
-   f3 specular_col = F3(0.0f, 0.0f, 0.0f);
-   int mat_id = 0;
+   // (the reflection's colour and the primary hit's material id wait in LDS for the combine, like P, N and the light)
+   if (REFLECT) park_store3<MDH_PARK_SPEC>(pk, wb, F3(0.0f, 0.0f, 0.0f));
    bool shaded = false; // the primary ray hit and the full shading ran
    // the ray that finds the next point to shade
    f3 ro = from, rd = dir_in;
    bool active = lane_valid;
-   park_store3(pk, 6, dir_in);
+   park_store3<6>(pk, wb, dir_in);
 #pragma unroll 1
    for (int ctx = 0; ctx < (REFLECT ? 2 : 1); ++ctx) {
       if (active) {
@@ -273,6 +402,13 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
          PH_ADD(pt, 0);
          if (ctx == 0) { hit = h; ph.steps = steps; }
          active = false; // a miss ends the chain (ctx 1: specular_col stays 0, render_probes.glsl:142-144)
+         if (SPEC == 2 && ctx == 1 && full2 && !h) { // ... or is the sky seen along the reflection, render_probes.glsl:216-218
+            const float s = rd.y * 0.7f;
+            park_store3<MDH_PARK_SPEC>(pk, wb, F3(0.30f - s, 0.36f - s, 0.60f - s));
+         }
+         if (SPEC == 2 && ctx == 1 && cage1) {
+            if (h) park_store3<MDH_PARK_SPEC>(pk, wb, radiance_with_specular<PART>(sc, pr, pk, wb, ro + rd * t, u8_tab));
+         } else
          if (h) {
             const f3 P = ro + rd * t;
             int index = -1;
@@ -281,10 +417,10 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
             int pm;
             primitive_info<(PART & MDH_PF_CUSTOM) != 0>(sc, index, P, N, pm);
             if (ctx == 0) {
-               mat_id = pm;
+               park_store1<MDH_PARK_MAT>(pk, wb, __int_as_float(pm));
                ph.index = index; ph.t = t;
-               park_store3(pk, 0, P);
-               park_store3(pk, 3, N);
+               park_store3<0>(pk, wb, P);
+               park_store3<3>(pk, wb, N);
             }
             PH_ADD(pt, 1);
             if (MODE != 1) {
@@ -297,7 +433,7 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
                f3 Lo = F3(0.0f, 0.0f, 0.0f);
                {
                   Material m = get_material(sc, pm);
-                  if (ctx) m.albedo = F3(0.0f, 0.0f, 0.0f); // render_probes.glsl:202-205
+                  if (ctx && !full2) m.albedo = F3(0.0f, 0.0f, 0.0f); // render_probes.glsl:202-205
 #pragma unroll 1
                   for (int li = 0; li < sc.total_lights; ++li) {
                      f3 L;
@@ -338,16 +474,18 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
                      PH_ADD(pt, 3);
                   }
                }
-               if (ctx == 0) park_store3(pk, 9, Lo); // = direct
-               else specular_col = Lo;                // + the radiance tap below (render_probes.glsl:197-206)
+               if (ctx == 0) park_store3<9>(pk, wb, Lo); // = direct
+               f3 specular_col = Lo;                      // ctx 1: + the radiance tap below (render_probes.glsl:197-206)
                if (MODE == 2) {
                   shaded = true;
                } else {
                   // ---- the 8 cage probes of P (render_probes.glsl:13-63 and :156-184)
                   const i3 gp = world_to_grid(pr, P);
-                  // ctx 0: acc = sum sqrt(irradiance) * w, accw = sum w; ctx 1: acc = best probe_to_spec, accw = best weight
-                  f3 acc = (ctx == 0) ? F3(0.0f, 0.0f, 0.0f) : F3(0.0f, 0.0f, 1.0f);
-                  float accw = (ctx == 0) ? 0.0f : -2.0f;
+                  // sample_irradiance at this point (the first point; the second one in mode 3), or the best cage probe of the second
+                  const bool irrp = ctx == 0 || full2;
+                  // irrp: acc = sum sqrt(irradiance) * w, accw = sum w; else: acc = best probe_to_spec, accw = best weight
+                  f3 acc = irrp ? F3(0.0f, 0.0f, 0.0f) : F3(0.0f, 0.0f, 1.0f);
+                  float accw = irrp ? 0.0f : -2.0f;
                   int best_q = 0; // x | y << 10 | z << 20
                   // Cage corners that the clamp to the grid folds onto an earlier corner (P outside the
                   // probe grid along an axis: all six walls of the example rooms are) name the SAME probe,
@@ -363,27 +501,27 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
                   // measured: the 16 extra VGPRs cost what the taps saved -- DESIGN.md, dropped experiments.)
 #pragma unroll 1
                   for (int i = 0; i < 8; ++i) {
-                     // ctx 1: a folded corner has the weight of its twin, which is not strictly larger
-                     if (ctx == 1 && (i & folded)) continue;
+                     // best probe: a folded corner has the weight of its twin, which is not strictly larger
+                     if (!irrp && (i & folded)) continue;
                      f3 s_term = F3(0.0f, 0.0f, 0.0f); // sqrt(irradiance tap) of this corner's probe
                      float wpre = 0.0f;                // its weight before the trilinear factor
                      const i3 q = cage_probe(pr, gp, i);
                      {
                      const f3 pw = grid_to_world(pr, q);
-                     const f3 hvec = (ctx == 0) ? (pw - P) : (P - pw);
+                     const f3 hvec = irrp ? (pw - P) : (P - pw);
                      const float dist = length(hvec);
-                     f3 vd = hvec / dist; // ctx 0: dir_to_probe, ctx 1: probe_to_spec
-                     if (ctx) vd = -vd;   // the visibility ray always runs from the point to the probe
+                     f3 vd = hvec / dist; // irrp: dir_to_probe, else: probe_to_spec
+                     if (!irrp) vd = -vd; // the visibility ray always runs from the point to the probe
 #if MDH_TAP_EARLY
                      // the irradiance tap of this corner (render_probes.glsl:44-58) depends on the probe and
                      // N only: its texel loads go out now and land while the visibility ray is marched
                      AtlasTap tap;
-                     if (ctx == 0) {
-                        const float irr_min = 0.5f / (float)pr.ires, irr_max = 1.0f - irr_min;
+                     if (irrp) {
                         f2 rid = ray_dir_to_ray_id(N);
-                        rid = F2(clamp_(rid.x, irr_min, irr_max), clamp_(rid.y, irr_min, irr_max));
-                        const f2 base = probe_id_to_coord(pr, grid_to_probe_id(pr, q));
-                        tap = atlas_tap_issue(pr.irr, pr.fmt, pr.pcx, pr.pcy, pr.ires, pr.ishift, base.x + div_pcx(pr, rid.x), base.y + div_pcy(pr, rid.y));
+                        rid = F2(clamp_(rid.x, pr.irr_lo, pr.irr_hi), clamp_(rid.y, pr.irr_lo, pr.irr_hi));
+                        const f2 base = probe_id_to_coord<P2>(pr, grid_to_probe_id(pr, q));
+                        tap = atlas_tap_issue<P2>(pr.irr, pr.fmt, pr.pcx, pr.pcy, pr.ires, pr.ishift, pr.irr_w, pr.irr_h, base.x + div_pcx<P2>(pr, rid.x), base.y + div_pcy<P2>(pr, rid.y));
+                        if (MDH_PARK_TAP && REFLECT) park_store1<MDH_PARK_TAPX>(pk, wb, tap.fx); // (one register less through the visibility march)
                      }
 #endif
                      // raycast_visibility, raymarching.glsl:39-56
@@ -403,7 +541,7 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
                      // ctx 1 keeps the probe with the largest dot(probe_to_spec, -N) * vis (strictly larger
                      // than the best so far).  With vis in {0, 1} the candidate is d or d * 0: once the best
                      // is >= 0, a probe with d <= best cannot win whatever its visibility.
-                     if (ctx == 1 && accw >= 0.0f && dot(-vd, -N) <= accw) vmax = 0.0f;
+                     if (!irrp && accw >= 0.0f && dot(-vd, -N) <= accw) vmax = 0.0f;
 #endif
                      bool first = MDH_SHARE_FIRST_STEP != 0;
                      PH_ADD(pt, 4);
@@ -420,7 +558,7 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
                      }
                      vis_bits |= (vis != 0.0f ? 1 : 0) << i;
                      PH_ADD(pt, 5);
-                     if (ctx == 0) { // render_probes.glsl:26-62
+                     if (irrp) { // render_probes.glsl:26-62
                         float angle = (dot(vd, N) + 1.0f) * 0.5f;
                         float weight = angle * angle + 0.2f;
                         weight *= vis;
@@ -430,13 +568,13 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
 #ifdef MDH_ABL_NO_TAPS
                         f3 tx = F3((float)q.x, (float)q.y, N.x);
 #elif MDH_TAP_EARLY
+                        if (MDH_PARK_TAP && REFLECT) tap.fx = park_load1<MDH_PARK_TAPX>(pk, wb);
                         f3 tx = atlas_tap_resolve(pr.irr, pr.fmt, tap, u8_tab);
 #else
-                        const float irr_min = 0.5f / (float)pr.ires, irr_max = 1.0f - irr_min;
                         f2 rid = ray_dir_to_ray_id(N);
-                        rid = F2(clamp_(rid.x, irr_min, irr_max), clamp_(rid.y, irr_min, irr_max));
-                        f2 base = probe_id_to_coord(pr, grid_to_probe_id(pr, q));
-                        f3 tx = atlas_sample(pr.irr, pr.fmt, pr.pcx, pr.pcy, pr.ires, pr.ishift, base.x + div_pcx(pr, rid.x), base.y + div_pcy(pr, rid.y), u8_tab);
+                        rid = F2(clamp_(rid.x, pr.irr_lo, pr.irr_hi), clamp_(rid.y, pr.irr_lo, pr.irr_hi));
+                        f2 base = probe_id_to_coord<P2>(pr, grid_to_probe_id(pr, q));
+                        f3 tx = atlas_sample<P2>(pr.irr, pr.fmt, pr.pcx, pr.pcy, pr.ires, pr.ishift, pr.irr_w, pr.irr_h, base.x + div_pcx<P2>(pr, rid.x), base.y + div_pcy<P2>(pr, rid.y), u8_tab);
 #endif
                         s_term = sqrt3(tx);
                      } else { // render_probes.glsl:170-183; probe_to_spec = -vd
@@ -445,7 +583,7 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
                         if (weight > accw) { accw = weight; best_q = q.x | (q.y << 10) | (q.z << 20); acc = -vd; }
                      }
                      }
-                     if (ctx == 0) { // render_probes.glsl:34-62: the trilinear factor and the sum
+                     if (irrp) { // render_probes.glsl:34-62: the trilinear factor and the sum
                         float weight = wpre;
                         const f3 alpha = P / F3(pr.sx, pr.sy, pr.sz) - F3((float)gp.x, (float)gp.y, (float)gp.z);
                         f3 tri = F3(mix_(1.0f - alpha.x, alpha.x, (float)(i & 1)), mix_(1.0f - alpha.y, alpha.y, (float)((i >> 1) & 1)),
@@ -456,14 +594,22 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
                      }
                      PH_ADD(pt, 6);
                   }
+                  if (SPEC == 2 && ctx == 1 && full2) { // render_probes.glsl:233-243: indirect (no specular of its own) + direct
+                     f3 irr = F3(0.0f, 0.0f, 0.0f);
+                     if (accw != 0.0f) { irr = acc / accw; irr = irr * irr; }
+                     const Material m = get_material(sc, pm);
+                     specular_col = compute_indirect_lighting(irr, F3(0.0f, 0.0f, 0.0f), -rd, N, reflect(rd, N), m.albedo, m.metallic, m.roughness) + specular_col;
+                     park_store3<MDH_PARK_SPEC>(pk, wb, specular_col);
+                  } else
                   if (ctx == 0) {
                      // render_probes.glsl:65-66 (0/0 fixed as 0)
                      f3 irr = F3(0.0f, 0.0f, 0.0f);
                      if (accw != 0.0f) { irr = acc / accw; irr = irr * irr; }
-                     park_store3(pk, 12, irr);
+                     park_store3<12>(pk, wb, irr);
                      shaded = true;
                      // the reflection ray of render_probes.glsl:262-275 finds the next point
-                     active = cfg.indirect_specular && tab_float((sc.mat_slot + 2 * pm + 1) * 4) < 0.75f;
+                     // (the material id comes back from its park slot: kept in a register across the corner loop it is spilled)
+                     active = cfg.spec_mode != 0 && tab_float((sc.mat_slot + 2 * __float_as_int(park_load1<MDH_PARK_MAT>(pk, wb)) + 1) * 4) < 0.75f;
 #ifdef MDH_ABL_NO_REFLECT
                      active = false;
 #endif
@@ -472,12 +618,12 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
                   } else { // render_probes.glsl:186-208
                      i3 bq;
                      bq.x = best_q & 1023; bq.y = (best_q >> 10) & 1023; bq.z = (best_q >> 20) & 1023;
-                     f2 base = probe_id_to_coord(pr, grid_to_probe_id(pr, bq));
-                     const float rmin = 0.5f / (float)pr.rres, rmax = 1.0f - rmin;
+                     f2 base = probe_id_to_coord<P2>(pr, grid_to_probe_id(pr, bq));
                      f2 brid = ray_dir_to_ray_id(acc);
-                     brid = F2(clamp_(brid.x, rmin, rmax), clamp_(brid.y, rmin, rmax));
-                     f3 radiance = atlas_sample(pr.rad, pr.fmt, pr.pcx, pr.pcy, pr.rres, pr.rshift, base.x + div_pcx(pr, brid.x), base.y + div_pcy(pr, brid.y), u8_tab);
+                     brid = F2(clamp_(brid.x, pr.rad_lo, pr.rad_hi), clamp_(brid.y, pr.rad_lo, pr.rad_hi));
+                     f3 radiance = atlas_sample<P2>(pr.rad, pr.fmt, pr.pcx, pr.pcy, pr.rres, pr.rshift, pr.rad_w, pr.rad_h, base.x + div_pcx<P2>(pr, brid.x), base.y + div_pcy<P2>(pr, brid.y), u8_tab);
                      specular_col = radiance + specular_col;
+                     park_store3<MDH_PARK_SPEC>(pk, wb, specular_col);
                   }
                   PH_ADD(pt, 7);
                }
@@ -487,7 +633,7 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
    }
    // ---- everything parked comes back for the combine
    PH_T0(pc);
-   const f3 dir = park_load3(pk, 6);
+   const f3 dir = park_load3<6>(pk, wb);
    f3 result;
    pos_out = F3(0.0f, 0.0f, 0.0f);
    if (!hit) { // render_probes.glsl:287
@@ -495,16 +641,17 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
       result = F3(0.30f - s, 0.36f - s, 0.60f - s);
       if (!lane_valid) result = F3(0.0f, 0.0f, 0.0f);
    } else {
-      const f3 pos = park_load3(pk, 0), normal = park_load3(pk, 3);
+      const f3 pos = park_load3<0>(pk, wb), normal = park_load3<3>(pk, wb);
       pos_out = pos;
       if (MODE == 1) {
          result = normal * 0.5f + F3s(0.5f);
       } else { // render_probes.glsl:277-285 and lighting.glsl:51-69
          (void)shaded;
-         f3 direct = park_load3(pk, 9);
+         f3 direct = park_load3<9>(pk, wb);
          if (MODE == 0) {
-            const f3 irr = park_load3(pk, 12);
-            Material m = get_material(sc, mat_id);
+            const f3 irr = park_load3<12>(pk, wb);
+            const f3 specular_col = REFLECT ? park_load3<MDH_PARK_SPEC>(pk, wb) : F3(0.0f, 0.0f, 0.0f);
+            Material m = get_material(sc, __float_as_int(park_load1<MDH_PARK_MAT>(pk, wb)));
             const f3 specular_dir = reflect(dir, normal);
             direct = direct + compute_indirect_lighting(irr, specular_col, -dir, normal, specular_dir, m.albedo, m.metallic, m.roughness);
          }

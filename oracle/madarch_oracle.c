@@ -127,7 +127,7 @@ struct orc_renderer {
    int64_t swaps;
    int32_t *gb_index, *gb_steps;
    float *gb_t;
-   int opt_atlas, opt_mode, opt_ao, opt_gbuffer, opt_rank, opt_world, opt_timing, opt_ada_div, opt_irr_all, opt_window;
+   int opt_atlas, opt_mode, opt_ao, opt_gbuffer, opt_rank, opt_world, opt_timing, opt_ada_div, opt_irr_all, opt_window, opt_spec;
    int opt_sdf_mode, opt_threads;
    uint64_t sdf_evals; /* closest_primitive[_info] calls of the last pass set */
 };
@@ -917,6 +917,72 @@ static v3 sample_radiance_no_specular(const orc_renderer *r, v3 pos, v3 normal, 
    return radiance;
 }
 
+/* glsl/render_probes.glsl:71-136 (M_COMPUTE_INDIRECT_SPECULAR == 1).  radiance_lods = int(log2(radiance_resolution))
+   (probe_utils.glsl:17) is taken as the position of the highest set bit; the atlases have one level, so
+   textureLod(.., lod) is level 0 and lod only narrows the clamp of the tap; a total weight of 0
+   (trilinear factors of a point outside the grid can cancel) gives 0, as for the irradiance. */
+static v3 sample_radiance_with_specular(const orc_renderer *r, v3 pos, v3 normal, v3 dir, float roughness)
+{
+   v3 spec_pos;
+   v3 from = add(pos, scale(scale(normal, ORC_MIN_STEP), 5.0f));
+   if (!raycast_hit_position(r, from, dir, r->max_dist, &spec_pos)) return V3(0, 0, 0);
+   v3 pos_to_spec_pos = sub(spec_pos, pos);
+   iv3 gp = world_to_grid(r, pos);
+   v3 alpha = sub(vdiv(pos, probe_spacing(r)), V3((float)gp.x, (float)gp.y, (float)gp.z));
+   int lods = 0;
+   while ((2 << lods) <= r->probes.radiance_resolution) ++lods;
+   float lod = mix_(0.0f, (float)lods, roughness * 2.0f);
+   int new_res = r->probes.radiance_resolution / (int)(lod + 1.0f);
+   float rmin = 0.5f / (float)new_res, rmax = 1.0f - rmin;
+   float total_weight = 0.0f;
+   v3 radiance = V3(0, 0, 0);
+   for (int i = 0; i < 8; ++i) {
+      iv3 o = {i & 1, (i >> 1) & 1, (i >> 2) & 1};
+      iv3 q = {iclamp_(gp.x + o.x, 0, r->probes.grid_dimensions[0] - 1), iclamp_(gp.y + o.y, 0, r->probes.grid_dimensions[1] - 1),
+               iclamp_(gp.z + o.z, 0, r->probes.grid_dimensions[2] - 1)};
+      v3 probe_to_pos = sub(pos, grid_to_world(r, q));
+      v3 probe_to_spec = add(probe_to_pos, pos_to_spec_pos);
+      float distance = length(probe_to_spec);
+      probe_to_spec = divs(probe_to_spec, distance);
+      float weight = fmax_(softshadows(r, spec_pos, neg(probe_to_spec), ORC_MIN_STEP * 5.0f, distance - ORC_MIN_STEP * 5.0f, 0.5f), 0.001f);
+      v3 tri = V3(mix_(1.0f - alpha.x, alpha.x, (float)o.x), mix_(1.0f - alpha.y, alpha.y, (float)o.y),
+                  mix_(1.0f - alpha.z, alpha.z, (float)o.z));
+      weight *= tri.x * tri.y * tri.z;
+      v2 base = probe_id_to_coord(r, grid_to_probe_id(r, q));
+      v2 rid = ray_dir_to_ray_id(probe_to_spec);
+      rid = V2(clamp_(rid.x, rmin, rmax), clamp_(rid.y, rmin, rmax));
+      v2 coord = V2(base.x + rid.x / (float)r->probes.probe_count[0], base.y + rid.y / (float)r->probes.probe_count[1]);
+      float tx[4];
+      tex_sample(&r->tex[MDH_TEX_RADIANCE], coord.x, coord.y, tx);
+      radiance = add(radiance, scale(V3(tx[0], tx[1], tx[2]), weight));
+      total_weight += weight;
+   }
+   if (total_weight == 0.0f) return V3(0, 0, 0);
+   return divs(radiance, total_weight);
+}
+
+/* glsl/render_probes.glsl:211-244 (M_COMPUTE_INDIRECT_SPECULAR == 3): the reflection's hit shaded in full */
+static v3 compute_indirect_lighting(v3 irradiance, v3 radiance, v3 V, v3 N, v3 L, v3 albedo, float metallic, float roughness);
+static v3 compute_indirect_specular(const orc_renderer *r, v3 pos, v3 normal, v3 dir, int direct_specular)
+{
+   int prim_index = -1;
+   v3 spec_pos;
+   v3 from = add(pos, scale(scale(normal, ORC_MIN_STEP), 5.0f));
+   if (!raycast(r, from, dir, &prim_index, &spec_pos, 0, 0)) {
+      float s = dir.y * 0.7f;
+      return V3(0.30f - s, 0.36f - s, 0.60f - s);
+   }
+   v3 spec_normal;
+   int spec_mat;
+   primitive_info(r, prim_index, spec_pos, &spec_normal, &spec_mat);
+   material_t m = get_material(r, spec_mat);
+   v3 direct = compute_direct_lighting(r, spec_pos, spec_normal, dir, m.albedo, m.metallic, m.roughness, direct_specular);
+   v3 irradiance = sample_irradiance(r, spec_pos, spec_normal);
+   v3 specular_dir = reflect(dir, spec_normal);
+   v3 indirect = compute_indirect_lighting(irradiance, V3(0, 0, 0), neg(dir), spec_normal, specular_dir, m.albedo, m.metallic, m.roughness);
+   return add(indirect, direct);
+}
+
 /* -------------------------------------------------------------------- volumetrics */
 #define TAU_SCATTERING 0.1f /* glsl/volumetrics.glsl:12 */
 /* glsl/volumetrics.glsl:21-30 */
@@ -949,7 +1015,7 @@ static v3 render_volumetrics(const orc_renderer *r, v3 L, v3 from, v3 to, int hi
 /* ------------------------------------------------------------ pixel_color_probes */
 typedef struct {
    int direct_specular;   /* M_COMPUTE_DIRECT_SPECULAR   */
-   int indirect_specular; /* M_COMPUTE_INDIRECT_SPECULAR (0 or 2) */
+   int indirect_specular; /* M_COMPUTE_INDIRECT_SPECULAR (0 .. 3) */
    int ao_steps;          /* M_AMBIENT_OCCLUSION_STEPS   */
    int volumetrics;       /* M_RENDER_VOLUMETRICS        */
    int mode;              /* MDH_OPT_SCREEN_MODE         */
@@ -977,7 +1043,11 @@ static v3 pixel_color_probes(const orc_renderer *r, const pass_cfg *cfg, v3 from
          v3 irradiance = sample_irradiance(r, pos, normal);
          v3 specular_col = V3(0, 0, 0);
          v3 specular_dir = reflect(dir, normal);
-         if (cfg->indirect_specular == 2 && m.roughness < 0.75f) specular_col = sample_radiance_no_specular(r, pos, normal, specular_dir);
+         if (cfg->indirect_specular > 0 && m.roughness < 0.75f) { /* render_probes.glsl:264-272 */
+            if (cfg->indirect_specular == 1) specular_col = sample_radiance_with_specular(r, pos, normal, specular_dir, m.roughness);
+            else if (cfg->indirect_specular == 2) specular_col = sample_radiance_no_specular(r, pos, normal, specular_dir);
+            else specular_col = compute_indirect_specular(r, pos, normal, specular_dir, cfg->direct_specular);
+         }
          v3 indirect = compute_indirect_lighting(irradiance, specular_col, neg(dir), normal, specular_dir, m.albedo, m.metallic, m.roughness);
          float ao = compute_ambient_occlusion(r, pos, normal, cfg->ao_steps);
          result = scale(add(direct, indirect), ao);
@@ -1173,7 +1243,7 @@ static int tile_owner(const orc_renderer *r, int px, int py)
 /* draw_screen.glsl:20-30 */
 static void pass_screen(orc_renderer *r)
 {
-   pass_cfg cfg = {1, 2, r->opt_ao, r->vol.enabled ? 1 : 0, r->opt_mode}; /* renderers.adb:136-143 */
+   pass_cfg cfg = {1, r->opt_spec, r->opt_ao, r->vol.enabled ? 1 : 0, r->opt_mode}; /* renderers.adb:136-143; MDH_OPT_INDIRECT_SPECULAR */
    if (cfg.mode != 0) cfg.volumetrics = 0;
    uint64_t evals = 0;
 #pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads(r)) reduction(+ : evals)
@@ -1301,7 +1371,7 @@ int32_t orc_create(int32_t width, int32_t height, const mdh_scene_desc *scene, c
    r->probes = *probes;
    r->vol = *vol;
    r->cam_m[0] = r->cam_m[4] = r->cam_m[8] = 1.0f; /* renderers.adb:225-226 */
-   r->opt_ao = 3; r->opt_world = 1; r->opt_ada_div = 1; r->opt_irr_all = 1; r->opt_window = 2;
+   r->opt_ao = 3; r->opt_world = 1; r->opt_ada_div = 1; r->opt_irr_all = 1; r->opt_window = 2; r->opt_spec = 2;
    tex_alloc(&r->tex[MDH_TEX_RADIANCE], probes->radiance_resolution * probes->probe_count[0], probes->radiance_resolution * probes->probe_count[1], 3, 1);
    tex_alloc(&r->tex[MDH_TEX_IRRADIANCE], probes->irradiance_resolution * probes->probe_count[0], probes->irradiance_resolution * probes->probe_count[1], 3, 1);
    r->tex[MDH_TEX_RADIANCE].flush_nan = r->tex[MDH_TEX_IRRADIANCE].flush_nan = 1;
@@ -1348,6 +1418,10 @@ int32_t orc_set_option(orc_renderer *r, int32_t option, int32_t value)
       if (value < 0 || value > 2) return seterr(MDH_E_INVALID, "bad value");
       r->opt_window = value;
       break;
+   case MDH_OPT_INDIRECT_SPECULAR:
+      if (value < 0 || value > 3) return seterr(MDH_E_INVALID, "indirect specular mode is 0 .. 3");
+      r->opt_spec = value;
+      break;
    case ORC_OPT_SDF_MODE: r->opt_sdf_mode = value; break;
    case ORC_OPT_THREADS: r->opt_threads = value; break;
    default: return seterr(MDH_E_INVALID, "unknown option");
@@ -1370,6 +1444,7 @@ int32_t orc_get_option(orc_renderer *r, int32_t option, int32_t *value)
    case MDH_OPT_JIT: *value = 0; break;
    case MDH_OPT_IRRADIANCE_ALL: *value = r->opt_irr_all; break;
    case MDH_OPT_WINDOW: *value = r->opt_window; break;
+   case MDH_OPT_INDIRECT_SPECULAR: *value = r->opt_spec; break;
    case ORC_OPT_SDF_MODE: *value = r->opt_sdf_mode; break;
    case ORC_OPT_THREADS: *value = nthreads(r); break;
    default: return seterr(MDH_E_INVALID, "unknown option");

@@ -534,3 +534,27 @@ def test_library_slices_are_the_exchanges_slices(hip):
                         assert (off.value, own.value) == sharding.slice_bytes(P, res, texel, rank, world)
                 R.Set_Option(B.OPT_RANK, 0)
             R.Destroy()
+
+
+@pytest.mark.parametrize("spec", [0, 1, 3])
+@pytest.mark.parametrize("scene,W,H,probes,atlas", [("global_illumination", 80, 56, SMALL_PROBES, 0), ("global_illumination", 56, 40, ODD_PROBES, 1),
+                                                     ("simple_scene", 64, 48, SMALL_PROBES, 0), ("light_shafts", 48, 40, None, 0)])
+def test_indirect_specular_modes(hip, orc, spec, scene, W, H, probes, atlas):
+    """M_COMPUTE_INDIRECT_SPECULAR other than the 2 the reference's renderer fixes (render_probes.glsl:264-272):
+    0 none, 1 sample_radiance_with_specular (:71-136), 3 compute_indirect_specular (:211-244) -- through the
+    brute-force scan, the space partition and the volumetric composite, RGB8 and fp32 atlases, power-of-two and odd
+    atlas dimensions."""
+    outs = []
+    for b in (hip, orc):
+        R = make(scene, W, H, b, atlas=atlas, probes=probes)
+        R.Set_Option(B.OPT_INDIRECT_SPECULAR, spec)
+        assert R.Get_Option(B.OPT_INDIRECT_SPECULAR) == spec
+        outs.append(snapshot(R, 3))
+    assert_parity(*outs)
+    assert (outs[0]["image"].view(np.uint32) == outs[1]["image"].view(np.uint32)).mean() > 0.999
+    # the mode really is another image than the default's
+    R = make(scene, W, H, hip, atlas=atlas, probes=probes)
+    assert R.Get_Option(B.OPT_INDIRECT_SPECULAR) == 2
+    assert not same_bits(snapshot(R, 3)["image"], outs[0]["image"])
+    with pytest.raises(B.MadarchError):
+        R.Set_Option(B.OPT_INDIRECT_SPECULAR, 4)

@@ -106,3 +106,25 @@ def test_ball_game_on_the_oracle(orc):
     assert min(vy) < -1.0 and vy[-1] > 0.0
     assert G.Ball_Bodies[0][0] == 2 and abs(float(G.Ball_Bodies[0][2][2]) - 10.0) < 1e-6
     assert np.isfinite(G.R.Read_Framebuffer()).mean() > 0.99
+
+
+def test_indirect_specular_option_on_the_oracle(orc):
+    """MDH_OPT_INDIRECT_SPECULAR: default 2 (madarch-renderers.adb:138), four different images, out-of-range refused."""
+    import numpy as np
+    from helpers import SMALL_PROBES, make
+    from madarch_amd import _binding as B
+    imgs = []
+    for spec in (0, 1, 2, 3):
+        R = make("global_illumination", 48, 32, orc, probes=SMALL_PROBES)
+        assert R.Get_Option(B.OPT_INDIRECT_SPECULAR) == 2
+        R.Set_Option(B.OPT_INDIRECT_SPECULAR, spec)
+        for _ in range(2):
+            R.Render()
+        imgs.append(R.Read_Framebuffer())
+        assert np.isfinite(imgs[-1]).all()
+    for i in range(4):
+        for j in range(i):
+            assert not np.array_equal(imgs[i], imgs[j])
+    import pytest
+    with pytest.raises(B.MadarchError):
+        R.Set_Option(B.OPT_INDIRECT_SPECULAR, -1)
