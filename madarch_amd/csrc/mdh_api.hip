@@ -90,10 +90,15 @@ static bool resolve_kind(Kind &k, const mdh_kind_decl &d, bool is_light)
    static const char *P[4] = {"Sphere", "Plane", "Box", "Triangle"};
    static const char *L[2] = {"PointLight", "SpotLight"};
    if (!d.name || !d.components) return false;
+   // A kind's behaviour is its expressions (madarch-primitives.ads:24-30, madarch-lights.ads:20-24), never its name: one
+   // that brings programs runs them, whatever it is called; the hand-written device functions are taken only by a kind
+   // that brings none and carries one of the library's own names (the reference's own six kinds).
    k.type = -1;
-   for (int t = 0; t < (is_light ? 2 : 4); ++t)
-      if (strcmp(d.name, is_light ? L[t] : P[t]) == 0) k.type = t;
-   const bool custom = k.type < 0 && d.dist_code && d.normal_code && (is_light || d.material_code);
+   const bool has_programs = d.dist_code || d.normal_code || d.material_code;
+   if (!has_programs)
+      for (int t = 0; t < (is_light ? 2 : 4); ++t)
+         if (strcmp(d.name, is_light ? L[t] : P[t]) == 0) k.type = t;
+   const bool custom = has_programs && d.dist_code && d.normal_code && (is_light || d.material_code);
    if (custom) k.type = is_light ? (int)LK_CUSTOM : (int)PK_CUSTOM;
    if (k.type < 0 || d.n_components < 1 || d.n_components > 8 || d.max_count < 0) return false;
    k.max_count = d.max_count;

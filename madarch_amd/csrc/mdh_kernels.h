@@ -176,8 +176,8 @@ __global__ __launch_bounds__(MDH_BLOCK, MDH_OCC(PART)) void k_screen(KScene sc, 
 }
 
 // ---------------------------------------------------------------------- radiance pass
-// compute_probe_radiance.glsl:16-27.  One wavefront per 8x8 texel tile of one probe's
-// octahedral map; all 64 rays of a wave leave the same probe position.
+// compute_probe_radiance.glsl:16-27.  One lane per radiance texel (one probe ray); a wavefront = the same
+// octahedral texel of MDH_RAD_PROBES_PER_WAVE = 64 consecutive probes (64 parallel rays from 64 origins).
 template <int PART> __global__ __launch_bounds__(MDH_BLOCK, MDH_OCC_RAD(PART)) void k_radiance(KScene sc, KProbes pr)
 {
    stage_table(sc);

@@ -3,7 +3,7 @@ name, its component list and -- for a user-defined kind -- the two expression bu
 Lights.Create (madarch-lights.ads:20-24):
     Sample   (L : Struct_Expr; Pos, Normal, Dir, Dist : Expr) -> Expr      radiance (vector)
     Position (L : Struct_Expr)                                  -> Expr      vector
-PointLight and SpotLight are hand-written device code identified by name; any other kind is
+PointLight and SpotLight (the library's own kind objects, which bring no expressions) are hand-written device code; any other kind, whatever its name, is
 compiled to MDH_X programs (madarch_amd/exprs.py) that the kernels interpret."""
 from .. import exprs, values
 
@@ -20,7 +20,8 @@ class Light:
         return "Light(%r)" % self.name
 
     def is_user_defined(self):
-        return self.name not in BUILT_IN
+        # by content, not by name: a kind that brings expressions runs them even if it is called "PointLight"
+        return bool(self.sample or self.position) or self.name not in BUILT_IN
 
     # Get_Sample_Expr / Get_Position_Expr (madarch-lights.ads:31-37)
     def Get_Sample_Expr(self, Inst, Pos, Normal, Dir, Dist):

@@ -6,7 +6,7 @@ expression builders of Primitives.Create (madarch-primitives.ads:24-30):
     Normal   (S : Struct_Expr; P : Expr) -> Expr      vector
     Material (S : Struct_Expr)           -> Expr      int
 The four built-in kinds (Sphere, Plane, Box, Triangle) are hand-written device functions in
-madarch_amd/csrc and are identified by name; any other kind is compiled from its expressions
+madarch_amd/csrc, taken by the library's own kind objects of those names (which bring no expressions); any other kind -- also one that merely shares such a name -- is compiled from its expressions
 to the MDH_X register programs of include/madarch_hip.h (madarch_amd/exprs.py) that the kernels
 interpret -- the analogue of the GLSL the reference generates from the same trees.
 """
@@ -25,7 +25,8 @@ class Primitive:
         return "Primitive(%r)" % self.name
 
     def is_user_defined(self):
-        return self.name not in BUILT_IN
+        # by content, not by name: a kind that brings expressions runs them even if it is called "Sphere"
+        return bool(self.distance or self.normal or self.material) or self.name not in BUILT_IN
 
     # Get_Dist_Expr / Get_Normal_Expr / Get_Material_Expr (madarch-primitives.ads:37-50)
     def Get_Dist_Expr(self, Inst, Point):

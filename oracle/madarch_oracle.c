@@ -1273,11 +1273,16 @@ static const char *LIGHT_NAMES[2] = {"PointLight", "SpotLight"};
 
 static int resolve_kind(kind_t *k, const mdh_kind_decl *d, int is_light)
 {
+   /* A kind's behaviour is its expressions (madarch-primitives.ads:24-30, madarch-lights.ads:20-24), never its name:
+      one that brings programs runs them, whatever it is called; the hand-written built-in paths are taken only by
+      a kind that brings none and carries one of the library's own names (the reference's own six kinds). */
    k->type = -1;
    int n = is_light ? 2 : 4;
-   for (int t = 0; t < n; ++t)
-      if (strcmp(d->name, is_light ? LIGHT_NAMES[t] : PRIM_NAMES[t]) == 0) k->type = t;
-   int custom = k->type < 0 && d->dist_code && d->normal_code && (is_light || d->material_code);
+   const int has_programs = d->dist_code || d->normal_code || d->material_code;
+   if (!has_programs)
+      for (int t = 0; t < n; ++t)
+         if (strcmp(d->name, is_light ? LIGHT_NAMES[t] : PRIM_NAMES[t]) == 0) k->type = t;
+   int custom = has_programs && d->dist_code && d->normal_code && (is_light || d->material_code);
    if (custom) k->type = is_light ? (int)LK_CUSTOM : (int)PK_CUSTOM;
    if (k->type < 0 || d->n_components > 8 || d->n_components < 1) return 0;
    k->max_count = d->max_count;
@@ -1782,6 +1787,15 @@ int32_t orc_probe_softshadow(orc_renderer *r, int32_t n, const float *org, const
 {
    for (int q = 0; q < n; ++q)
       out[q] = softshadows(r, V3(org[3 * q], org[3 * q + 1], org[3 * q + 2]), V3(dir[3 * q], dir[3 * q + 1], dir[3 * q + 2]), 0.0f, tmax[q], k);
+   return MDH_OK;
+}
+/* sample_irradiance (render_probes.glsl:6-69) at n points with normals, from the current irradiance atlas */
+int32_t orc_probe_sample_irradiance(orc_renderer *r, int32_t n, const float *pos, const float *nrm, float *out)
+{
+   for (int q = 0; q < n; ++q) {
+      v3 c = sample_irradiance(r, V3(pos[3 * q], pos[3 * q + 1], pos[3 * q + 2]), V3(nrm[3 * q], nrm[3 * q + 1], nrm[3 * q + 2]));
+      out[3 * q] = c.x; out[3 * q + 1] = c.y; out[3 * q + 2] = c.z;
+   }
    return MDH_OK;
 }
 /* single SDF / normal of a built-in kind from raw parameters (a: vec3, b: vec3 or scalar in b[0], c: vec3) */

@@ -76,6 +76,8 @@ def build(seed, binding):
         R.Update_Partitioning(int(rng.integers(0, 3)))
     R.Set_Option(B.OPT_FRAME_OVERLAP, int(rng.choice([0, 1, 2])))  # (the schedule must not show)
     R.Set_Option(B.OPT_WINDOW, int(rng.integers(0, 2)))
+    # (a generator of its own: the scenes of the seeds run before this option existed stay what they were)
+    R.Set_Option(B.OPT_INDIRECT_SPECULAR, int(np.random.default_rng(int(seed) ^ 0x5BEC).choice([2, 2, 0, 1, 3])))
     frames = int(rng.integers(1, 4))
     out = snapshot(R, frames)
     if part_on:

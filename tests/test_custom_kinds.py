@@ -203,3 +203,55 @@ def test_hip_rejects_invalid_programs(hip):
     with pytest.raises(B.MadarchError) as e:
         renderers.Create(windows.Open(8, 8, "x"), Scene, Probes=SMALL_PROBES, Volumetrics=renderers.No_Volumetrics, Binding=hip)
     assert e.value.status == B.MDH_E_UNSUPPORTED_KIND
+
+
+# ---- a kind is what its expressions say, not what it is called (madarch-primitives.ads:24-30)
+def _ring_scene(binding, kind, light_kind=None):
+    """A floor, a torus of the given kind and one light; the primary-ray geometry of a 40 x 28 frame."""
+    Scene = scenes.Compile(All_Primitives=[(planes.Plane, 2), (kind, 2)], All_Lights=[(light_kind or point_lights.Point_Light, 2)],
+                           Partitioning=scenes.Partitioning_Settings(Enable=False))
+    R = renderers.Create(windows.Open(40, 28, "ring"), Scene, Probes=SMALL_PROBES, Volumetrics=renderers.No_Volumetrics, Binding=binding)
+    R.Add_Primitive(planes.Plane, planes.Create((0.0, 1.0, 0.0), 1.0, 0))
+    R.Add_Primitive(kind, ck.torus((2.5, 1.5, 4.0), 1.2, 0.4, 1))
+    R.Set_Material(0, materials.Create((0.4, 0.4, 0.4), 0.0, 0.6))
+    R.Set_Material(1, materials.Create((0.8, 0.2, 0.1), 0.3, 0.4))
+    if light_kind is None:
+        R.Set_Light(1, point_lights.Point_Light, point_lights.Create((3.0, 5.0, 1.0), (0.9, 0.9, 0.8)))
+    else:
+        R.Set_Light(1, light_kind, ck.lamp((3.0, 6.0, 2.0), 1.0, (1.2, 1.1, 0.9)))
+    R.Set_Camera_Position((2.0, 2.0, 0.0))
+    R.Set_Option(B.OPT_GBUFFER, 1)
+    return R
+
+
+# the torus of tests/custom_kinds.py under the NAME of a built-in kind, and the lamp light called "PointLight"
+Sphere_Named_Torus = ck.primitives.Create("Sphere", ck.Torus.comps, ck.Torus.distance, ck.Torus.normal, ck.Torus.material)
+Point_Light_Named_Lamp = ck.lights.Create("PointLight", ck.Lamp.comps, ck.Lamp.sample, ck.Lamp.position)
+
+
+def test_oracle_kind_named_sphere_runs_its_own_expressions(orc):
+    a = snapshot(_ring_scene(orc, ck.Torus), 1)
+    b = snapshot(_ring_scene(orc, Sphere_Named_Torus), 1)
+    for k in a:
+        assert same_bits(a[k], b[k]), k
+    # ... and the hole of the ring shows the floor (a sphere of that centre would cover it)
+    assert len(np.unique(a["gb_index"])) >= 2
+    c = snapshot(_ring_scene(orc, ck.Torus, ck.Lamp), 1)
+    d = snapshot(_ring_scene(orc, Sphere_Named_Torus, Point_Light_Named_Lamp), 1)
+    for k in c:
+        assert same_bits(c[k], d[k]), k
+    assert not same_bits(a["image"], c["image"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("jit", [1, 0])
+def test_hip_kind_named_sphere_runs_its_own_expressions(hip, orc, jit):
+    """A user kind called "Sphere" whose Distance is a torus (and a light called "PointLight" whose Sample is the
+    lamp's) must go through its MDH_X programs -- compiled or interpreted -- not through the hand-written sphere."""
+    want = snapshot(_ring_scene(orc, Sphere_Named_Torus, Point_Light_Named_Lamp), 2)
+    R = _ring_scene(hip, Sphere_Named_Torus, Point_Light_Named_Lamp)
+    R.Set_Option(B.OPT_JIT, jit)
+    got = snapshot(R, 2)
+    from helpers import assert_parity
+    assert_parity(got, want)
+    assert same_bits(got["image"], snapshot(_ring_scene(hip, ck.Torus, ck.Lamp), 2)["image"])

@@ -259,3 +259,199 @@ def test_transcendental_algorithms_against_libm(orc):
         f.restype, f.argtypes = C.c_float, [C.c_float]
         for x in rng.uniform(lo, hi, 3000).astype(np.float32):
             assert abs(f(float(x)) - ref(np.float64(x))) < tol, (name, x)
+
+
+# ------------------------------------------------------------------------------------------------
+# Independent float64 restatements, written from the GLSL, of the three pieces of the path that no
+# known answer above covers: soft shadows, sample_irradiance and the irradiance fold.  They share no
+# code with the oracle (own SDF of the global_illumination room, own octahedral maps, own bilinear
+# filter) and run in float64, so agreement is within fp32 rounding, not to the bit.
+GI_PLANES = [((0.0, 1.0, 0.0), 1.0), ((0.0, -1.0, 0.0), 7.0), ((1.0, 0.0, 0.0), 1.0), ((-1.0, 0.0, 0.0), 7.0), ((0.0, 0.0, 1.0), 6.0), ((0.0, 0.0, -1.0), 7.0)]
+
+
+def gi_sdf64(p):
+    """min over the primitives of examples/global_illumination/main.adb:40-74, float64"""
+    d = min(np.dot(n, p) + o for n, o in GI_PLANES)
+    d = min(d, np.linalg.norm(np.array([3.0, 4.0, 3.0]) - p) - 1.0)                      # spheres.ads:13-14
+    q = np.abs(np.array([3.0, 0.0, 4.0]) - p) - np.array([1.5, 1.5, 1.5])                # boxes.adb:7-15
+    return min(d, np.linalg.norm(np.maximum(q, 0.0)) + min(max(q[0], q[1], q[2]), 0.0), 20.0)
+
+
+def softshadows64(o, d, tmin, tmax, k):  # raymarching.glsl:4-23
+    res, prev, t = 1.0, 1e20, tmin
+    while t < tmax:
+        s = gi_sdf64(o + d * t)
+        if s < 0.001:
+            return 0.0
+        y = s * s / (2.0 * prev)
+        e = np.sqrt(s * s - y * y)
+        den = max(0.0, t - y)
+        res = min(res, k * e / den) if den > 0.0 else res
+        prev = s
+        t += s
+    return res
+
+
+def visibility64(o, d, tmax):  # raymarching.glsl:39-56
+    t = 0.0
+    while t < tmax:
+        s = gi_sdf64(o + d * t)
+        if s < 0.001:
+            return 0.0
+        t += s
+    return 1.0
+
+
+def oct_encode64(v):  # probe_utils.glsl:58-70, 88-92
+    p = v[:2] / np.abs(v).sum()
+    if v[2] <= 0.0:
+        p = (1.0 - np.abs(p[::-1])) * np.where(p >= 0.0, 1.0, -1.0)
+    return (p + 1.0) * 0.5
+
+
+def oct_decode64(e):  # probe_utils.glsl:72-86
+    e = e * 2.0 - 1.0
+    v = np.array([e[0], e[1], 1.0 - abs(e[0]) - abs(e[1])])
+    if v[2] < 0.0:
+        v[:2] = (1.0 - np.abs(v[1::-1])) * np.where(v[:2] >= 0.0, 1.0, -1.0)
+    return v / np.linalg.norm(v)
+
+
+def bilinear64(img, cx, cy):
+    """GL_LINEAR with GL_MIRRORED_REPEAT on an (H, W, 3) image (render_passes.adb:111-114)"""
+    H, W = img.shape[:2]
+    px, py = cx * W - 0.5, cy * H - 0.5
+    x0, y0 = int(np.floor(px)), int(np.floor(py))
+    fx, fy = px - x0, py - y0
+
+    def mir(i, n):
+        m = i % (2 * n)
+        return 2 * n - 1 - m if m >= n else m
+    t = lambda x, y: img[mir(y, H), mir(x, W)].astype(np.float64)  # noqa: E731
+    return (t(x0, y0) * (1 - fx) * (1 - fy) + t(x0 + 1, y0) * fx * (1 - fy)) + t(x0, y0 + 1) * (1 - fx) * fy + t(x0 + 1, y0 + 1) * fx * fy
+
+
+def _gi_renderer(orc, atlas=1):
+    from helpers import SMALL_PROBES
+    from madarch_amd import _binding as B
+    R = examples.global_illumination(8, 8, Probes=SMALL_PROBES, Binding=orc)
+    R.Set_Option(B.OPT_ATLAS_FORMAT, atlas)
+    return R, SMALL_PROBES
+
+
+@pytest.mark.parametrize("k", [64.0, 2.0])
+def test_softshadows_against_float64(orc, k):
+    """raymarching.glsl:4-23 from seeded points of the room towards the light and towards random directions, with
+    the renderer's k = 64 (lighting.glsl:29) and a wide penumbra (k = 2)."""
+    R, _ = _gi_renderer(orc)
+    rng = np.random.RandomState(11)
+    pts = seeded_points(160, (-0.5, -0.5, -5.0), (6.5, 6.5, 6.5), seed=SEED + 7).astype(np.float64)
+    light = np.array([3.5, 5.0, 2.0])
+    rows = []
+    for i, p in enumerate(pts):
+        if gi_sdf64(p) < 0.3:
+            continue
+        if i % 2:
+            d = light - p
+            tmax = np.linalg.norm(d)
+            d = d / tmax
+        else:
+            d = rng.normal(size=3)
+            d /= np.linalg.norm(d)
+            tmax = rng.uniform(1.0, 6.0)
+        rows.append((p, d, tmax, softshadows64(p, d, 0.0, tmax, k)))
+    n = len(rows)
+    assert n > 80
+    out = np.zeros(n, np.float32)
+    org = np.array([r[0] for r in rows], np.float32)
+    dirs = np.array([r[1] for r in rows], np.float32)
+    tmax = np.array([r[2] for r in rows], np.float32)
+    orc.lib.orc_probe_softshadow(R._h, n, cf(org), cf(dirs), cf(tmax), C.c_float(k), cf(out))
+    want = np.array([r[3] for r in rows])
+    # a ray that grazes a surface can end blocked in one precision and graze past in the other: those aside,
+    # the penumbra value agrees to fp32 accuracy of a ~20-step march
+    agree = np.isclose(out, want, rtol=2e-3, atol=2e-4)
+    assert agree.mean() > 0.97
+    assert (want == 0.0).sum() > 5 and (want == 1.0).sum() > 5
+    if k < 64.0:
+        assert ((want > 0.0) & (want < 1.0)).sum() > 20
+
+
+def test_sample_irradiance_against_float64(orc):
+    """render_probes.glsl:6-69 on a random fp32 irradiance atlas: cage probes, visibility rays, the crushed and
+    trilinear weights, clamped bilinear taps, the sqrt / square."""
+    from madarch_amd import _binding as B
+    R, P = _gi_renderer(orc)
+    rng = np.random.RandomState(13)
+    W, H = P.Probe_Count[0] * P.Irradiance_Resolution, P.Probe_Count[1] * P.Irradiance_Resolution
+    atlas = rng.uniform(0.0, 1.0, size=(H, W, 3)).astype(np.float32)
+    R.Write_Texture(B.TEX_IRRADIANCE, atlas)
+    sp, dims, ires, pc = np.array(P.Grid_Spacing, np.float64), np.array(P.Grid_Dimensions), P.Irradiance_Resolution, np.array(P.Probe_Count)
+    pts = seeded_points(60, (0.2, 0.2, 0.2), (6.0, 5.5, 5.5), seed=SEED + 9).astype(np.float64)
+    pos, nrm, want = [], [], []
+    for p in pts:
+        if gi_sdf64(p) < 0.4:
+            continue
+        n = rng.normal(size=3)
+        n /= np.linalg.norm(n)
+        g = np.floor(p / sp).astype(int)
+        alpha = p / sp - g
+        acc, wsum = np.zeros(3), 0.0
+        for i in range(8):
+            off = np.array([i & 1, (i >> 1) & 1, (i >> 2) & 1])
+            c = np.clip(g + off, 0, dims - 1)
+            h = c * sp - p
+            dist = np.linalg.norm(h)
+            dp = h / dist
+            w = ((dp @ n + 1.0) * 0.5) ** 2 + 0.2
+            w *= visibility64(p + n * 0.05 * 5.0, dp, dist - 0.05 * 5.0)
+            if w < 0.2:
+                w *= w * w / 0.04
+            tri = np.where(off == 1, alpha, 1.0 - alpha)
+            w *= tri.prod()
+            pid = c[2] * dims[0] * dims[1] + c[1] * dims[0] + c[0]
+            base = np.array([pid % pc[0], pid // pc[0]]) / pc
+            rid = np.clip(oct_encode64(n), 0.5 / ires, 1.0 - 0.5 / ires)
+            tex = bilinear64(atlas, *(base + rid / pc))
+            acc += np.sqrt(tex) * w
+            wsum += w
+        pos.append(p); nrm.append(n); want.append((acc / wsum) ** 2 if wsum else np.zeros(3))
+    n = len(pos)
+    assert n > 30
+    out = np.zeros((n, 3), np.float32)
+    orc.lib.orc_probe_sample_irradiance(R._h, n, cf(np.array(pos, np.float32)), cf(np.array(nrm, np.float32)), cf(out))
+    ok = np.isclose(out, np.array(want), rtol=3e-4, atol=1e-5).all(axis=1)
+    assert ok.mean() > 0.95  # (a visibility ray that grazes the sphere or the box may flip between precisions)
+
+
+def test_irradiance_fold_against_float64(orc):
+    """update_probe_irradiance.glsl:8-43 on a random fp32 radiance atlas: every texel of a few probes, with the
+    corner-sample bleed into the neighbouring tiles."""
+    from madarch_amd import _binding as B
+    R, P = _gi_renderer(orc)
+    rng = np.random.RandomState(17)
+    rres, ires, pc = P.Radiance_Resolution, P.Irradiance_Resolution, np.array(P.Probe_Count)
+    rad = rng.uniform(0.0, 1.0, size=(pc[1] * rres, pc[0] * rres, 3)).astype(np.float32)
+    R.Write_Texture(B.TEX_RADIANCE, rad)
+    R.Render_Pass(B.PASS_IRRADIANCE)
+    got = R.Read_Texture(B.TEX_IRRADIANCE)
+    step = 1.0 / pc / rres
+    for probe in (0, 7, 20, 35):  # a corner tile, an edge tile, inner tiles
+        ty, tx = divmod(probe, pc[0])
+        base = np.array([tx, ty]) / pc
+        taps = []
+        for y in range(rres):
+            for x in range(rres):
+                c = np.clip(base + np.array([x, y]) * step, step, 1.0 - step)
+                taps.append((bilinear64(rad, c[0], c[1]), oct_decode64((c * pc) % 1.0)))
+        for ky in range(ires):
+            for kx in range(ires):
+                i, j = tx * ires + kx, ty * ires + ky
+                nc = (np.array([(2 * i + 1) / (pc[0] * ires) - 1.0, (2 * j + 1) / (pc[1] * ires) - 1.0]) + 1.0) * 0.5
+                irr_dir = oct_decode64((nc * pc) % 1.0)
+                acc, wsum = np.zeros(3), 0.0
+                for r_, d_ in taps:
+                    w = max(irr_dir @ d_, 0.0)
+                    acc += r_ * w
+                    wsum += w
+                assert np.allclose(got[j, i], acc / wsum, rtol=2e-4, atol=1e-6), (probe, kx, ky)
