@@ -6,6 +6,7 @@
 --        Window : Windows.Window;
 --        Scene  : Scenes.Scene;
 --        Handle : Madarch_HIP.Handle;
+--        Last_Material_Index : Materials.Id := 0;   --  as in the reference's record
 --     end record;
 --
 --  SOURCE ONLY: written against GNAT conventions but never compiled in this
@@ -19,6 +20,7 @@ with System;
 
 with GPU_Types;
 with Madarch.Components;
+with Madarch.Scenes.HIP;
 with Madarch_HIP;
 
 package body Madarch.Renderers is
@@ -73,7 +75,9 @@ package body Madarch.Renderers is
       return Renderer
    is
       H    : aliased HIP.Handle;
-      Desc : aliased HIP.Scene_Desc;       --  filled from Scenes.Get_Primitives / Get_Lights
+      Desc : aliased HIP.Scene_Desc;       --  kinds, components, declared counts, MDH_X programs
+      Keep : Scenes.HIP.Description;       --  owns what Desc points to until mdh_create has copied it
+      S    : HIP.Status;
       P    : aliased HIP.Probe_Settings :=
         (int (Probes.Radiance_Resolution), int (Probes.Irradiance_Resolution),
          (int (Probes.Probe_Count (GL.X)), int (Probes.Probe_Count (GL.Y))),
@@ -91,10 +95,13 @@ package body Madarch.Renderers is
           int (Volumetrics.Scattering_Resolution (GL.Y))),
          C_float (Volumetrics.Scattering_Step_Size));
    begin
-      Scenes.Describe (Scene, Desc);   --  small addition to Madarch.Scenes: fills Desc
-      Check (HIP.Create (int (Window.Width), int (Window.Height),
-                         Desc'Access, P'Access, V'Access, 0, H'Access));
-      return new Renderer_Internal'(Window => Window, Scene => Scene, Handle => H);
+      Scenes.HIP.Describe (Scene, Desc, Keep);   --  ada/madarch-scenes-hip.ads
+      S := HIP.Create (int (Window.Width), int (Window.Height),
+                       Desc'Access, P'Access, V'Access, 0, H'Access);
+      Scenes.HIP.Free (Keep);
+      Check (S);
+      return new Renderer_Internal'
+        (Window => Window, Scene => Scene, Handle => H, Last_Material_Index => 0);
    end Create;
 
    --  madarch-renderers.adb:302-321 (five passes + Swap_Buffers)
@@ -139,10 +146,10 @@ package body Madarch.Renderers is
       Entity : Entities.Entity)
    is
       Blob : aliased constant Byte_Array :=
-        Element_Blob (Scenes.Get_Primitive_Element_Type (Self.Scene, Prim), Entity);
+        Element_Blob (Scenes.HIP.Get_Primitive_Element_Type (Self.Scene, Prim), Entity);
    begin
       Check (HIP.Set_Primitive
-        (Self.Handle, int (Scenes.Kind_Index (Self.Scene, Prim)), int (Index),
+        (Self.Handle, int (Scenes.HIP.Kind_Index (Self.Scene, Prim)), int (Index),
          Blob'Address, Blob'Length));
    end Set_Primitive;
 
@@ -151,11 +158,11 @@ package body Madarch.Renderers is
      (Self : in out Renderer; Prim : Primitives.Primitive; Entity : Entities.Entity)
    is
       Blob  : aliased constant Byte_Array :=
-        Element_Blob (Scenes.Get_Primitive_Element_Type (Self.Scene, Prim), Entity);
+        Element_Blob (Scenes.HIP.Get_Primitive_Element_Type (Self.Scene, Prim), Entity);
       Count : aliased int;
    begin
       Check (HIP.Add_Primitive
-        (Self.Handle, int (Scenes.Kind_Index (Self.Scene, Prim)),
+        (Self.Handle, int (Scenes.HIP.Kind_Index (Self.Scene, Prim)),
          Blob'Address, Blob'Length, Count'Access));
    end Add_Primitive;
 
@@ -165,10 +172,10 @@ package body Madarch.Renderers is
       Entity : Entities.Entity)
    is
       Blob : aliased constant Byte_Array :=
-        Element_Blob (Scenes.Get_Light_Element_Type (Self.Scene, Lit), Entity);
+        Element_Blob (Scenes.HIP.Get_Light_Element_Type (Self.Scene, Lit), Entity);
    begin
       Check (HIP.Set_Light
-        (Self.Handle, int (Index), int (Scenes.Kind_Index (Self.Scene, Lit)),
+        (Self.Handle, int (Index), int (Scenes.HIP.Kind_Index (Self.Scene, Lit)),
          Blob'Address, Blob'Length));
    end Set_Light;
 
@@ -210,7 +217,7 @@ package body Madarch.Renderers is
       Ixs  : aliased array (Prims'Range) of aliased int;
    begin
       for I in Prims'Range loop
-         Ixs (I) := int (Scenes.Kind_Index (Self.Scene, Prims (I)));
+         Ixs (I) := int (Scenes.HIP.Kind_Index (Self.Scene, Prims (I)));
       end loop;
       Check (HIP.Eval_Distance_To
         (Self.Handle, 1, P'Address, Ixs'Address, Ixs'Length, N'Address, D'Address));
