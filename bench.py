@@ -35,6 +35,8 @@ WORKLOADS = {
     "simple_scene_1080p_direct": ("simple_scene", 1920, 1080, None, 2),
     "light_shafts_1080p": ("light_shafts", 1920, 1080, None, 0),
     "global_illumination_4096sq_ddgi8x8x8": ("global_illumination", 4096, 4096, "gi8", 0),
+    # --rehearse-cpu only: the control flow of this file with N ranks on the CPU (gloo, the oracle as the engine)
+    "rehearsal_small": ("global_illumination", 96, 64, None, 0),
 }
 
 
@@ -164,6 +166,50 @@ def cpu_baseline_exprs():
             "sample": "%d frames of 256x256 simple_scene, screen mode 1 (primary rays, normal colour), space partition on (%.1f s) after 1 warm-up frame" % (frames, dt)}
 
 
+def rehearse_cpu(args, rank, world):
+    """The N-rank control flow of main() on the CPU: process group (gloo), ShardedFrame with the exchange make_exchange
+    picks for the host, barrier + max-over-ranks timing, rank 0 printing one line.  The engine is the oracle and the
+    frame is tiny: the line carries "rehearsal": true and no throughput claim."""
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from madarch_amd import _binding as B
+    from madarch_amd import sharding
+    from oracle_engine import ORC_OPT_THREADS, oracle_binding
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    if world > 1:
+        dist.init_process_group("gloo")
+    R = make_renderer("rehearsal_small", oracle_binding())
+    R.Set_Option(ORC_OPT_THREADS, 2)
+    frame = sharding.ShardedFrame(R, rank, world, sharding.HostExchange(dist) if world > 1 else None)
+
+    def sync():
+        R.Finish()
+        if world > 1:
+            dist.barrier()
+    for _ in range(args.warmup):
+        frame.Render()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        frame.Render()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    img = frame.Gather_Framebuffer(dist if world > 1 else None)
+    if rank == 0:
+        import hashlib
+        print(json.dumps({"rehearsal": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+                          "frame_sha1": hashlib.sha1(img.tobytes()).hexdigest(), "engine": "CPU oracle over gloo (control flow only)"}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -180,6 +226,7 @@ def main():
     ap.add_argument("--swap-buffers", action="store_true", help="Swap_Buffers after every frame and fetch the window's RGBA8 pixels of the frame before (the PCIe-inclusive rate; never the default)")
     ap.add_argument("--animate-light", action="store_true", help="set the light anew before every frame, as the example's main loop does (global_illumination/main.adb:219-232)")
     ap.add_argument("--rehearse-rccl", action="store_true", help="one rank, but through the RCCL exchange path of the sharded frame (rehearsal of the N > 1 code path on one GPU)")
+    ap.add_argument("--rehearse-cpu", action="store_true", help="TEST ONLY: this file's N-rank control flow on the CPU -- gloo, the oracle as the engine, a tiny frame; prints a line marked as a rehearsal, never a result")
     args = ap.parse_args()
 
     import torch
@@ -193,6 +240,8 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
         args.gpus = world
+    if args.rehearse_cpu:
+        return rehearse_cpu(args, rank, world)
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 or args.rehearse_rccl:

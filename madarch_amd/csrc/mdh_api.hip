@@ -612,6 +612,13 @@ static KProbes make_probes(const mdh_renderer *r)
    p.fpcx = (float)p.pcx; p.fpcy = (float)p.pcy;
    p.rad_lods = 0;
    while ((2 << p.rad_lods) <= p.rres) ++p.rad_lods;
+   // div_magic: exact for numerators below 65536 -- texel coordinates of an atlas image, probe ids
+   auto magic = [](int d) { return (unsigned)((1ull << 32) / (unsigned long long)d + 1ull); };
+   const bool small = (long long)p.pcx * p.rres < 65536 && (long long)p.pcy * p.rres < 65536 && (long long)p.pcx * p.ires < 65536 &&
+                      (long long)p.pcy * p.ires < 65536 && (long long)p.pcx * p.pcy < 65536;
+   p.m_rres = small && p.rres > 1 ? magic(p.rres) : 0u;
+   p.m_ires = small && p.ires > 1 ? magic(p.ires) : 0u;
+   p.m_pcx = small && p.pcx > 1 ? magic(p.pcx) : 0u;
    return p;
 }
 static KCamera make_camera(const mdh_renderer *r)

@@ -109,6 +109,7 @@ struct KProbes {
    float irr_w, irr_h, rad_w, rad_h; // (float)(pcx * ires), (float)(pcy * ires), (float)(pcx * rres), (float)(pcy * rres)
    float fpcx, fpcy;     // (float)pcx, (float)pcy
    int rad_lods;         // radiance_lods = int(log2(radiance_resolution)) (probe_utils.glsl:17): the highest set bit
+   unsigned m_rres, m_ires, m_pcx; // div_magic's numbers for rres, ires and pcx (0: the atlas is too large for them)
 };
 
 struct KCamera {
@@ -203,6 +204,14 @@ MDH_DEV float sqrt_(float x)
 }
 MDH_DEV float clamp_(float x, float lo, float hi) { return min_(max_(x, lo), hi); }
 MDH_DEV int iclamp_(int x, int lo, int hi) { return min(max(x, lo), hi); }
+// x / d for 0 <= x < 65536 through the host's magic number m = floor (2^32 / d) + 1: mulhi (x, m) is the exact quotient
+// while x * d < 2^32 (the error term x * (m d - 2^32) <= x d stays below 2^32).  m = 0: no magic, divide.
+MDH_DEV int div_magic(int x, int d, unsigned m)
+{
+   if (m) return (int)__umulhi((unsigned)x, m);
+   asm volatile("" : "+v"(d)); // (the cold path keeps its division set-up to itself: see mirror)
+   return x / d;
+}
 MDH_DEV float sign_(float x) { return x < 0.0f ? -1.0f : (x > 0.0f ? 1.0f : 0.0f); }
 MDH_DEV float fract_(float x) { return x - __builtin_floorf(x); }
 MDH_DEV float mix_(float x, float y, float a) { return x * (1.0f - a) + y * a; }
@@ -980,7 +989,7 @@ template <bool P2 = false> MDH_DEV float div_pcx(const KProbes &pr, float x) { r
 template <bool P2 = false> MDH_DEV float div_pcy(const KProbes &pr, float y) { return (P2 || pr.inv_pcy != 0.0f) ? y * pr.inv_pcy : y / pr.fpcy; }
 template <bool P2 = false> MDH_DEV f2 probe_id_to_coord(const KProbes &pr, int id)
 {
-   int y = (P2 || pr.pcx_shift >= 0) ? (id >> pr.pcx_shift) : (id / pr.pcx), x = id - y * pr.pcx;
+   int y = (P2 || pr.pcx_shift >= 0) ? (id >> pr.pcx_shift) : div_magic(id, pr.pcx, pr.m_pcx), x = id - y * pr.pcx;
    return F2(div_pcx<P2>(pr, (float)x), div_pcy<P2>(pr, (float)y));
 }
 // glsl/probe_utils.glsl:58-92
@@ -1016,13 +1025,21 @@ MDH_DEV f2 ray_dir_to_ray_id(f3 d)
 // the whole kernel -- seven of them in the screen pass, four of which ended up in scratch)
 template <bool P2 = false> MDH_DEV int mirror(int i, int n)
 {
-   if ((unsigned)i < (unsigned)n) return i; // inside the image: the usual case, no integer division
-   int m;
-   if (P2) m = i & (2 * n - 1);
-   else {
-      m = i % (2 * n);
-      if (m < 0) m += 2 * n;
+   if ((unsigned)i < (unsigned)n) return i; // inside the image: the usual case
+   if (P2) {
+      const int m = i & (2 * n - 1);
+      return m >= n ? 2 * n - 1 - m : m;
    }
+   // one reflection covers [-n, 2n): every tap of this library (coordinates clamped inside a tile, or a texel
+   // beside the image) -- the same value as the modulo form below
+   if ((unsigned)(i + n) < (unsigned)(3 * n)) return i < 0 ? -1 - i : 2 * n - 1 - i;
+   // farther out: the general form.  The divisor goes through an opaque per-lane register HERE so that the set-up of
+   // the division stays in this cold path (with a uniform divisor the compiler hoists a reciprocal per distinct
+   // image size into VGPRs that live -- or spill -- through the whole pixel program).
+   int n2 = 2 * n;
+   asm volatile("" : "+v"(n2));
+   int m = i % n2;
+   if (m < 0) m += n2;
    return m >= n ? 2 * n - 1 - m : m;
 }
 MDH_DEV float unorm8(float x) { return (x != x) ? 0.0f : __builtin_rintf(clamp_(x, 0.0f, 1.0f) * 255.0f); }
@@ -1031,11 +1048,12 @@ MDH_DEV float unorm8(float x) { return (x != x) ? 0.0f : __builtin_rintf(clamp_(
 // rank's probe slice is one contiguous range (DESIGN.md "HBM layout").  (X, Y) are texel
 // coordinates of the reference's 2-D atlas image, X = tile_x * res + x.
 // `shift` = log2(res) when res is a power of two (wave-uniform fast path), else -1
-template <bool P2 = false> MDH_DEV unsigned atlas_index(int pcx, int res, int shift, int X, int Y)
+// `magic`: div_magic's number for res (KProbes::m_rres / m_ires)
+template <bool P2 = false> MDH_DEV unsigned atlas_index(int pcx, int res, int shift, int X, int Y, unsigned magic = 0u)
 {
    int tx, ty;
    if (P2 || shift >= 0) { tx = X >> shift; ty = Y >> shift; }
-   else { tx = X / res; ty = Y / res; }
+   else { tx = div_magic(X, res, magic); ty = div_magic(Y, res, magic); }
    return ((unsigned)(ty * pcx + tx) * res + (Y - ty * res)) * res + (X - tx * res);
 }
 // u8_tab = float index of the k / 255 table in LDS (KScene::u8_slot * 4), or < 0: divide
@@ -1063,7 +1081,7 @@ MDH_DEV void atlas_store(void *base, int fmt, unsigned idx, f3 v)
 }
 // GL_LINEAR on the atlas image of pcx*res x pcy*res texels (render_passes.adb:113-114); Wf, Hf = (float)(pcx * res), (float)(pcy * res)
 template <bool P2 = false>
-MDH_DEV f3 atlas_sample(const void *base, int fmt, int pcx, int pcy, int res, int shift, float Wf, float Hf, float cx, float cy, int u8_tab)
+MDH_DEV f3 atlas_sample(const void *base, int fmt, int pcx, int pcy, int res, int shift, float Wf, float Hf, float cx, float cy, int u8_tab, unsigned magic = 0u)
 {
    const int W = pcx * res, H = pcy * res;
    float px = cx * Wf - 0.5f, py = cy * Hf - 0.5f;
@@ -1071,8 +1089,8 @@ MDH_DEV f3 atlas_sample(const void *base, int fmt, int pcx, int pcy, int res, in
    float fx = px - fx0, fy = py - fy0;
    int x0 = mirror<P2>((int)fx0, W), x1 = mirror<P2>((int)fx0 + 1, W), y0 = mirror<P2>((int)fy0, H), y1 = mirror<P2>((int)fy0 + 1, H);
    float w00 = (1.0f - fx) * (1.0f - fy), w10 = fx * (1.0f - fy), w01 = (1.0f - fx) * fy, w11 = fx * fy;
-   f3 a = atlas_texel(base, fmt, atlas_index<P2>(pcx, res, shift, x0, y0), u8_tab), b = atlas_texel(base, fmt, atlas_index<P2>(pcx, res, shift, x1, y0), u8_tab);
-   f3 c = atlas_texel(base, fmt, atlas_index<P2>(pcx, res, shift, x0, y1), u8_tab), d = atlas_texel(base, fmt, atlas_index<P2>(pcx, res, shift, x1, y1), u8_tab);
+   f3 a = atlas_texel(base, fmt, atlas_index<P2>(pcx, res, shift, x0, y0, magic), u8_tab), b = atlas_texel(base, fmt, atlas_index<P2>(pcx, res, shift, x1, y0, magic), u8_tab);
+   f3 c = atlas_texel(base, fmt, atlas_index<P2>(pcx, res, shift, x0, y1, magic), u8_tab), d = atlas_texel(base, fmt, atlas_index<P2>(pcx, res, shift, x1, y1, magic), u8_tab);
    return ((a * w00 + b * w10) + c * w01) + d * w11;
 }
 
@@ -1085,7 +1103,7 @@ struct AtlasTap {
    float fx, fy;
 };
 template <bool P2 = false>
-MDH_DEV AtlasTap atlas_tap_issue(const void *base, int fmt, int pcx, int pcy, int res, int shift, float Wf, float Hf, float cx, float cy)
+MDH_DEV AtlasTap atlas_tap_issue(const void *base, int fmt, int pcx, int pcy, int res, int shift, float Wf, float Hf, float cx, float cy, unsigned magic = 0u)
 {
    const int W = pcx * res, H = pcy * res;
    float px = cx * Wf - 0.5f, py = cy * Hf - 0.5f;
@@ -1093,8 +1111,8 @@ MDH_DEV AtlasTap atlas_tap_issue(const void *base, int fmt, int pcx, int pcy, in
    AtlasTap t;
    t.fx = px - fx0; t.fy = py - fy0;
    int x0 = mirror<P2>((int)fx0, W), x1 = mirror<P2>((int)fx0 + 1, W), y0 = mirror<P2>((int)fy0, H), y1 = mirror<P2>((int)fy0 + 1, H);
-   t.t00 = atlas_index<P2>(pcx, res, shift, x0, y0); t.t10 = atlas_index<P2>(pcx, res, shift, x1, y0);
-   t.t01 = atlas_index<P2>(pcx, res, shift, x0, y1); t.t11 = atlas_index<P2>(pcx, res, shift, x1, y1);
+   t.t00 = atlas_index<P2>(pcx, res, shift, x0, y0, magic); t.t10 = atlas_index<P2>(pcx, res, shift, x1, y0, magic);
+   t.t01 = atlas_index<P2>(pcx, res, shift, x0, y1, magic); t.t11 = atlas_index<P2>(pcx, res, shift, x1, y1, magic);
    if (fmt == 0) {
       const unsigned *b = (const unsigned *)base;
       t.t00 = b[t.t00]; t.t10 = b[t.t10]; t.t01 = b[t.t01]; t.t11 = b[t.t11];

@@ -359,12 +359,40 @@ MDH_DEV f3 radiance_with_specular(const KScene &sc, const KProbes &pr, const flo
       const f2 base = probe_id_to_coord(pr, grid_to_probe_id(pr, q));
       f2 rid = ray_dir_to_ray_id(pts);
       rid = F2(clamp_(rid.x, rmin, rmax), clamp_(rid.y, rmin, rmax));
-      const f3 tx = atlas_sample(pr.rad, pr.fmt, pr.pcx, pr.pcy, pr.rres, pr.rshift, pr.rad_w, pr.rad_h, base.x + div_pcx(pr, rid.x), base.y + div_pcy(pr, rid.y), u8_tab);
+      const f3 tx = atlas_sample(pr.rad, pr.fmt, pr.pcx, pr.pcy, pr.rres, pr.rshift, pr.rad_w, pr.rad_h, base.x + div_pcx(pr, rid.x), base.y + div_pcy(pr, rid.y), u8_tab, pr.m_rres);
       radiance = radiance + tx * weight;
       total_weight += weight;
    }
    if (total_weight == 0.0f) return F3(0.0f, 0.0f, 0.0f);
    return radiance / total_weight;
+}
+
+// The probe settings again, from the kernel argument segment, at the point of use.  Both march kernels take
+// (KScene, KProbes, ...): held in scalar registers from the kernel's entry, the 48 dwords of KProbes stay live across
+// every march loop of the pixel program, and what does not fit is copied to and from VGPR lanes with a vector
+// instruction per use (the screen kernel had a thousand such copies, a third of them in inner loops).  Re-read where a
+// block of probe code begins -- a few scalar loads through a pointer the compiler cannot trace, served by the scalar
+// cache -- they are live for that block only.
+#ifndef MDH_PROBES_FRESH
+#define MDH_PROBES_FRESH 1
+#endif
+MDH_DEV KProbes probes_fresh(const KProbes &pr)
+{
+#if MDH_PROBES_FRESH
+   struct KHead { KScene sc; KProbes pr; };
+   typedef const KHead __attribute__((address_space(4))) *KHeadPtr;
+   KHeadPtr ka = (KHeadPtr)__builtin_amdgcn_kernarg_segment_ptr();
+   asm volatile("" : "+s"(ka));
+   typedef const int __attribute__((address_space(4))) *IntPtr;
+   IntPtr src = (IntPtr)&ka->pr;
+   KProbes r;
+   int *dst = (int *)&r;
+#pragma unroll
+   for (int q = 0; q < (int)(sizeof(KProbes) / 4); ++q) dst[q] = src[q];
+   return r;
+#else
+   return pr;
+#endif
 }
 
 // SPEC: 0 = no second point (the radiance pass), 1 = the reflection as the reference's renderer fixes it
@@ -480,7 +508,8 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
                   shaded = true;
                } else {
                   // ---- the 8 cage probes of P (render_probes.glsl:13-63 and :156-184)
-                  const i3 gp = world_to_grid(pr, P);
+                  const KProbes pg = probes_fresh(pr);
+                  const i3 gp = world_to_grid(pg, P);
                   // sample_irradiance at this point (the first point; the second one in mode 3), or the best cage probe of the second
                   const bool irrp = ctx == 0 || full2;
                   // irrp: acc = sum sqrt(irradiance) * w, accw = sum w; else: acc = best probe_to_spec, accw = best weight
@@ -491,8 +520,8 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
                   // probe grid along an axis: all six walls of the example rooms are) name the SAME probe,
                   // hence the same visibility ray: its result is reused instead of marched again.
                   // bit a of `folded`: corners differing only in axis a coincide.
-                  const int folded = ((gp.x < 0 || gp.x >= pr.gx - 1) ? 1 : 0) | ((gp.y < 0 || gp.y >= pr.gy - 1) ? 2 : 0) |
-                                     ((gp.z < 0 || gp.z >= pr.gz - 1) ? 4 : 0);
+                  const int folded = ((gp.x < 0 || gp.x >= pg.gx - 1) ? 1 : 0) | ((gp.y < 0 || gp.y >= pg.gy - 1) ? 2 : 0) |
+                                     ((gp.z < 0 || gp.z >= pg.gz - 1) ? 4 : 0);
                   int vis_bits = 0; // bit i: visibility of corner i
                   PH_ADD(pt, 2);
                   if (QVIS && ctx == 0) vis_bits = queued_visibility<PART>(sc, pr, pk, P, N, gp, folded, sd0);
@@ -503,11 +532,12 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
                   for (int i = 0; i < 8; ++i) {
                      // best probe: a folded corner has the weight of its twin, which is not strictly larger
                      if (!irrp && (i & folded)) continue;
+                     KProbes pq = probes_fresh(pr); // (live up to the visibility march, read again behind it)
                      f3 s_term = F3(0.0f, 0.0f, 0.0f); // sqrt(irradiance tap) of this corner's probe
                      float wpre = 0.0f;                // its weight before the trilinear factor
-                     const i3 q = cage_probe(pr, gp, i);
+                     const i3 q = cage_probe(pq, gp, i);
                      {
-                     const f3 pw = grid_to_world(pr, q);
+                     const f3 pw = grid_to_world(pq, q);
                      const f3 hvec = irrp ? (pw - P) : (P - pw);
                      const float dist = length(hvec);
                      f3 vd = hvec / dist; // irrp: dir_to_probe, else: probe_to_spec
@@ -518,9 +548,9 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
                      AtlasTap tap;
                      if (irrp) {
                         f2 rid = ray_dir_to_ray_id(N);
-                        rid = F2(clamp_(rid.x, pr.irr_lo, pr.irr_hi), clamp_(rid.y, pr.irr_lo, pr.irr_hi));
-                        const f2 base = probe_id_to_coord<P2>(pr, grid_to_probe_id(pr, q));
-                        tap = atlas_tap_issue<P2>(pr.irr, pr.fmt, pr.pcx, pr.pcy, pr.ires, pr.ishift, pr.irr_w, pr.irr_h, base.x + div_pcx<P2>(pr, rid.x), base.y + div_pcy<P2>(pr, rid.y));
+                        rid = F2(clamp_(rid.x, pq.irr_lo, pq.irr_hi), clamp_(rid.y, pq.irr_lo, pq.irr_hi));
+                        const f2 base = probe_id_to_coord<P2>(pq, grid_to_probe_id(pq, q));
+                        tap = atlas_tap_issue<P2>(pq.irr, pq.fmt, pq.pcx, pq.pcy, pq.ires, pq.ishift, pq.irr_w, pq.irr_h, base.x + div_pcx<P2>(pq, rid.x), base.y + div_pcy<P2>(pq, rid.y), pq.m_ires);
                         if (MDH_PARK_TAP && REFLECT) park_store1<MDH_PARK_TAPX>(pk, wb, tap.fx); // (one register less through the visibility march)
                      }
 #endif
@@ -557,6 +587,7 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
                         total += sd;
                      }
                      vis_bits |= (vis != 0.0f ? 1 : 0) << i;
+                     pq = probes_fresh(pr);
                      PH_ADD(pt, 5);
                      if (irrp) { // render_probes.glsl:26-62
                         float angle = (dot(vd, N) + 1.0f) * 0.5f;
@@ -569,12 +600,12 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
                         f3 tx = F3((float)q.x, (float)q.y, N.x);
 #elif MDH_TAP_EARLY
                         if (MDH_PARK_TAP && REFLECT) tap.fx = park_load1<MDH_PARK_TAPX>(pk, wb);
-                        f3 tx = atlas_tap_resolve(pr.irr, pr.fmt, tap, u8_tab);
+                        f3 tx = atlas_tap_resolve(pq.irr, pq.fmt, tap, u8_tab);
 #else
                         f2 rid = ray_dir_to_ray_id(N);
-                        rid = F2(clamp_(rid.x, pr.irr_lo, pr.irr_hi), clamp_(rid.y, pr.irr_lo, pr.irr_hi));
-                        f2 base = probe_id_to_coord<P2>(pr, grid_to_probe_id(pr, q));
-                        f3 tx = atlas_sample<P2>(pr.irr, pr.fmt, pr.pcx, pr.pcy, pr.ires, pr.ishift, pr.irr_w, pr.irr_h, base.x + div_pcx<P2>(pr, rid.x), base.y + div_pcy<P2>(pr, rid.y), u8_tab);
+                        rid = F2(clamp_(rid.x, pq.irr_lo, pq.irr_hi), clamp_(rid.y, pq.irr_lo, pq.irr_hi));
+                        f2 base = probe_id_to_coord<P2>(pq, grid_to_probe_id(pq, q));
+                        f3 tx = atlas_sample<P2>(pq.irr, pq.fmt, pq.pcx, pq.pcy, pq.ires, pq.ishift, pq.irr_w, pq.irr_h, base.x + div_pcx<P2>(pq, rid.x), base.y + div_pcy<P2>(pq, rid.y), u8_tab, pq.m_ires);
 #endif
                         s_term = sqrt3(tx);
                      } else { // render_probes.glsl:170-183; probe_to_spec = -vd
@@ -585,7 +616,7 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
                      }
                      if (irrp) { // render_probes.glsl:34-62: the trilinear factor and the sum
                         float weight = wpre;
-                        const f3 alpha = P / F3(pr.sx, pr.sy, pr.sz) - F3((float)gp.x, (float)gp.y, (float)gp.z);
+                        const f3 alpha = P / F3(pq.sx, pq.sy, pq.sz) - F3((float)gp.x, (float)gp.y, (float)gp.z);
                         f3 tri = F3(mix_(1.0f - alpha.x, alpha.x, (float)(i & 1)), mix_(1.0f - alpha.y, alpha.y, (float)((i >> 1) & 1)),
                                     mix_(1.0f - alpha.z, alpha.z, (float)((i >> 2) & 1)));
                         weight *= tri.x * tri.y * tri.z;
@@ -618,10 +649,11 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
                   } else { // render_probes.glsl:186-208
                      i3 bq;
                      bq.x = best_q & 1023; bq.y = (best_q >> 10) & 1023; bq.z = (best_q >> 20) & 1023;
-                     f2 base = probe_id_to_coord<P2>(pr, grid_to_probe_id(pr, bq));
+                     const KProbes pq = probes_fresh(pr);
+                     f2 base = probe_id_to_coord<P2>(pq, grid_to_probe_id(pq, bq));
                      f2 brid = ray_dir_to_ray_id(acc);
-                     brid = F2(clamp_(brid.x, pr.rad_lo, pr.rad_hi), clamp_(brid.y, pr.rad_lo, pr.rad_hi));
-                     f3 radiance = atlas_sample<P2>(pr.rad, pr.fmt, pr.pcx, pr.pcy, pr.rres, pr.rshift, pr.rad_w, pr.rad_h, base.x + div_pcx<P2>(pr, brid.x), base.y + div_pcy<P2>(pr, brid.y), u8_tab);
+                     brid = F2(clamp_(brid.x, pq.rad_lo, pq.rad_hi), clamp_(brid.y, pq.rad_lo, pq.rad_hi));
+                     f3 radiance = atlas_sample<P2>(pq.rad, pq.fmt, pq.pcx, pq.pcy, pq.rres, pq.rshift, pq.rad_w, pq.rad_h, base.x + div_pcx<P2>(pq, brid.x), base.y + div_pcy<P2>(pq, brid.y), u8_tab, pq.m_rres);
                      specular_col = radiance + specular_col;
                      park_store3<MDH_PARK_SPEC>(pk, wb, specular_col);
                   }

@@ -4,7 +4,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/pmc_breakdown${1:+_$1}
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-B="python3 $ROOT/bench.py --steps 10 --warmup 3 --prewarm-s 0.02 --no-cpu-baseline --no-serial-segment --serial"
+B="python3 $ROOT/bench.py ${WORKLOAD:+--workload $WORKLOAD} --steps 10 --warmup 3 --prewarm-s 0.02 --no-cpu-baseline --no-serial-segment --serial"
 timeout -k 10 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM --kernel-trace --output-format csv -d $OUT/a -- $B > /dev/null 2>&1
 timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_BRANCH --kernel-trace --output-format csv -d $OUT/b -- $B > /dev/null 2>&1
 timeout -k 10 300 rocprofv3 --pmc SQ_IFETCH SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_FLAT SQ_INSTS_FLAT SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $OUT/c -- $B > /dev/null 2>&1
