@@ -227,7 +227,11 @@ enum {
     *       hit, plus that point's direct specular (M_ADD_INDIRECT_SPECULAR = 1);
     *   3 = compute_indirect_specular (:211-244): the reflection's hit shaded in full (direct light + irradiance).
     * textureLod on the single-level atlases is level 0 in every mode. */
-   MDH_OPT_INDIRECT_SPECULAR = 12
+   MDH_OPT_INDIRECT_SPECULAR = 12,
+   /* Temporal blending of the irradiance atlas -- NOT in the reference, off by default (SURVEY.md section 8f-4 lists
+    * it as a deviation): the irradiance pass stores mix (fresh, previous, h) with h = value / 1000 (0 .. 999), `previous`
+    * being the texel the atlas held before the pass, as stored (RGB8: its 8-bit levels).  0 = the reference. */
+   MDH_OPT_HYSTERESIS_PERMILLE = 13
 };
 
 /* passes of Renderers.Render (madarch-renderers.adb:302-321) */

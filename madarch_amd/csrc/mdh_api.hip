@@ -177,7 +177,7 @@ struct mdh_renderer {
    int last_material_index = 0;
    float cam_pos[3] = {0, 0, 0}, cam_m[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}; // renderers.adb:225-226
    // options
-   int opt_atlas = 0, opt_mode = 0, opt_ao = 3, opt_gbuffer = 0, opt_rank = 0, opt_world = 1, opt_timing = 0, opt_ada_div = 1, opt_spec = 2;
+   int opt_atlas = 0, opt_mode = 0, opt_ao = 3, opt_gbuffer = 0, opt_rank = 0, opt_world = 1, opt_timing = 0, opt_ada_div = 1, opt_spec = 2, opt_hyst = 0;
    // device state
    std::vector<float4> table_host;
    // The scene table lives in a ring of buffers: an edit (Set_Light every frame in the reference's examples) is
@@ -850,6 +850,7 @@ extern "C" int32_t mdh_set_option(mdh_renderer *r, int32_t option, int32_t value
       break;
    case MDH_OPT_FRAME_OVERLAP: if (value < 0 || value > 2) return seterr(MDH_E_INVALID, "frame overlap is 0, 1 or 2"); r->opt_overlap = value; break;
    case MDH_OPT_INDIRECT_SPECULAR: if (value < 0 || value > 3) return seterr(MDH_E_INVALID, "indirect specular mode is 0 .. 3"); r->opt_spec = value; break;
+   case MDH_OPT_HYSTERESIS_PERMILLE: if (value < 0 || value > 999) return seterr(MDH_E_INVALID, "hysteresis is 0 .. 999 per mille"); r->opt_hyst = value; break;
    default: return seterr(MDH_E_INVALID, "unknown option");
    }
    return MDH_OK;
@@ -871,6 +872,7 @@ extern "C" int32_t mdh_get_option(mdh_renderer *r, int32_t option, int32_t *valu
    case MDH_OPT_IRRADIANCE_ALL: *value = r->opt_irr_all; break;
    case MDH_OPT_WINDOW: *value = r->opt_window; break;
    case MDH_OPT_INDIRECT_SPECULAR: *value = r->opt_spec; break;
+   case MDH_OPT_HYSTERESIS_PERMILLE: *value = r->opt_hyst; break;
    default: return seterr(MDH_E_INVALID, "unknown option");
    }
    return MDH_OK;
@@ -1375,7 +1377,8 @@ static int run_pass(mdh_renderer *r, int pass, hipStream_t st, int src, int dst,
             r->irr_lds_granted = true;
          }
       }
-      if (n > 0) hipLaunchKernelGGL(k_irradiance, dim3(n), dim3(MDH_IRR_BLOCK), lds, st, pr);
+      // (hysteresis: the previous frame's irradiance is set `src` -- the same set when the pass runs in place)
+      if (n > 0) hipLaunchKernelGGL(k_irradiance, dim3(n), dim3(MDH_IRR_BLOCK), lds, st, pr, (const void *)r->d_irr2[src], (float)r->opt_hyst / 1000.0f);
       break;
    }
    case MDH_PASS_VISIBILITY: {

@@ -245,7 +245,15 @@ template <int PART> __global__ __launch_bounds__(MDH_BLOCK, MDH_OCC_RAD(PART)) v
 #define MDH_IRR_CHUNK 256 // taps per LDS buffer when one wavefront folds (0 = all taps staged at once)
 #endif
 typedef float pk2 __attribute__((ext_vector_type(2))); // two fp32 per VALU instruction (v_pk_mul_f32 / v_pk_add_f32: IEEE per component)
-__global__ __launch_bounds__(MDH_IRR_BLOCK) void k_irradiance(KProbes pr)
+// `prev`, `hyst`: MDH_OPT_HYSTERESIS_PERMILLE (not in the reference; 0 = off): the texel is stored as
+// mix (fresh, what the previous frame's atlas holds, hyst)
+MDH_DEV f3 irradiance_blend(const KProbes &pr, const void *prev, float hyst, unsigned idx, f3 fresh)
+{
+   if (hyst == 0.0f) return fresh;
+   const f3 old = atlas_texel(prev, pr.fmt, idx, -1);
+   return F3(mix_(fresh.x, old.x, hyst), mix_(fresh.y, old.y, hyst), mix_(fresh.z, old.z, hyst));
+}
+__global__ __launch_bounds__(MDH_IRR_BLOCK) void k_irradiance(KProbes pr, const void *prev, float hyst)
 {
    extern __shared__ float4 s_taps[]; // [2 * rres * rres]: {rad.xyz, 1} {dir.xyz, -}
    const int probe = pr.probe_begin + blockIdx.x;
@@ -303,7 +311,8 @@ __global__ __launch_bounds__(MDH_IRR_BLOCK) void k_irradiance(KProbes pr)
       }
       if ((int)threadIdx.x < pr.ires * pr.ires) {
          const f3 irradiance = F3(acc_xy.x, acc_xy.y, acc_zw.x) / acc_zw.y;
-         atlas_store(pr.irr, pr.fmt, atlas_index(pr.pcx, pr.ires, pr.ishift, i, j), irradiance);
+         const unsigned idx = atlas_index(pr.pcx, pr.ires, pr.ishift, i, j);
+         atlas_store(pr.irr, pr.fmt, idx, irradiance_blend(pr, prev, hyst, idx, irradiance));
       }
       return;
    }
@@ -342,7 +351,8 @@ __global__ __launch_bounds__(MDH_IRR_BLOCK) void k_irradiance(KProbes pr)
       }
 #endif
       irradiance = irradiance / total_weight;
-      atlas_store(pr.irr, pr.fmt, atlas_index(pr.pcx, pr.ires, pr.ishift, i, j), irradiance);
+      const unsigned idx = atlas_index(pr.pcx, pr.ires, pr.ishift, i, j);
+      atlas_store(pr.irr, pr.fmt, idx, irradiance_blend(pr, prev, hyst, idx, irradiance));
    }
 }
 

@@ -127,7 +127,7 @@ struct orc_renderer {
    int64_t swaps;
    int32_t *gb_index, *gb_steps;
    float *gb_t;
-   int opt_atlas, opt_mode, opt_ao, opt_gbuffer, opt_rank, opt_world, opt_timing, opt_ada_div, opt_irr_all, opt_window, opt_spec;
+   int opt_atlas, opt_mode, opt_ao, opt_gbuffer, opt_rank, opt_world, opt_timing, opt_ada_div, opt_irr_all, opt_window, opt_spec, opt_hyst;
    int opt_sdf_mode, opt_threads;
    uint64_t sdf_evals; /* closest_primitive[_info] calls of the last pass set */
 };
@@ -1152,6 +1152,11 @@ static void pass_irradiance(orc_renderer *r)
                total_weight += w;
             }
          irradiance = divs(irradiance, total_weight);
+         if (r->opt_hyst > 0) { /* MDH_OPT_HYSTERESIS_PERMILLE (not in the reference): mix (fresh, previous, h) */
+            const float h = (float)r->opt_hyst / 1000.0f;
+            const float *old = t->data + ((size_t)j * t->w + i) * t->c;
+            irradiance = V3(mix_(irradiance.x, old[0], h), mix_(irradiance.y, old[1], h), mix_(irradiance.z, old[2], h));
+         }
          float o[3] = {irradiance.x, irradiance.y, irradiance.z};
          tex_store(t, i, j, o);
       }
@@ -1427,6 +1432,10 @@ int32_t orc_set_option(orc_renderer *r, int32_t option, int32_t value)
       if (value < 0 || value > 3) return seterr(MDH_E_INVALID, "indirect specular mode is 0 .. 3");
       r->opt_spec = value;
       break;
+   case MDH_OPT_HYSTERESIS_PERMILLE:
+      if (value < 0 || value > 999) return seterr(MDH_E_INVALID, "hysteresis is 0 .. 999 per mille");
+      r->opt_hyst = value;
+      break;
    case ORC_OPT_SDF_MODE: r->opt_sdf_mode = value; break;
    case ORC_OPT_THREADS: r->opt_threads = value; break;
    default: return seterr(MDH_E_INVALID, "unknown option");
@@ -1450,6 +1459,7 @@ int32_t orc_get_option(orc_renderer *r, int32_t option, int32_t *value)
    case MDH_OPT_IRRADIANCE_ALL: *value = r->opt_irr_all; break;
    case MDH_OPT_WINDOW: *value = r->opt_window; break;
    case MDH_OPT_INDIRECT_SPECULAR: *value = r->opt_spec; break;
+   case MDH_OPT_HYSTERESIS_PERMILLE: *value = r->opt_hyst; break;
    case ORC_OPT_SDF_MODE: *value = r->opt_sdf_mode; break;
    case ORC_OPT_THREADS: *value = nthreads(r); break;
    default: return seterr(MDH_E_INVALID, "unknown option");

@@ -559,3 +559,23 @@ def test_indirect_specular_modes(hip, orc, spec, scene, W, H, probes, atlas):
     assert same_bits(snapshot(R, 3)["image"], outs[0]["image"]) == (scene == "light_shafts")
     with pytest.raises(B.MadarchError):
         R.Set_Option(B.OPT_INDIRECT_SPECULAR, 4)
+
+
+@pytest.mark.parametrize("atlas,overlap,probes", [(0, 2, SMALL_PROBES), (1, 0, ODD_PROBES), (1, 2, SMALL_PROBES)])
+def test_hysteresis_blends_with_the_previous_frames_irradiance(hip, orc, atlas, overlap, probes):
+    """MDH_OPT_HYSTERESIS_PERMILLE (a deviation the survey lists, off by default): stored = mix (fresh, previous, h),
+    `previous` being the other atlas set when frames are in flight and the texel itself when the pass runs in place."""
+    outs = []
+    for b in (hip, orc):
+        R = make("global_illumination", 56, 40, b, atlas=atlas, probes=probes)
+        assert R.Get_Option(B.OPT_HYSTERESIS_PERMILLE) == 0
+        R.Set_Option(B.OPT_HYSTERESIS_PERMILLE, 850)
+        R.Set_Option(B.OPT_FRAME_OVERLAP, overlap)
+        outs.append(snapshot(R, 5))
+    assert_parity(*outs)
+    plain = snapshot(make("global_illumination", 56, 40, hip, atlas=atlas, probes=probes), 5)
+    assert not same_bits(plain["irradiance"], outs[0]["irradiance"])
+    # five frames at h = 0.85 have let in 1 - 0.85^5 = 56 % of the light: dimmer than the unblended atlas
+    assert outs[0]["irradiance"].mean() < plain["irradiance"].mean()
+    with pytest.raises(B.MadarchError):
+        make("global_illumination", 16, 8, hip).Set_Option(B.OPT_HYSTERESIS_PERMILLE, 1000)
