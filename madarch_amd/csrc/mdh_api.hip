@@ -548,7 +548,7 @@ static int commit_scene(mdh_renderer *r, hipStream_t up)
    memcpy(t.data(), H, sizeof H);
    s.table_f4 = (int)t.size();
    // (the march kernels park MDH_PARK_DWORDS floats per thread behind the table, lds_bytes_march)
-   if ((size_t)s.table_f4 * 16 + (size_t)MDH_PARK_DWORDS * MDH_BLOCK * sizeof(float) > 64 * 1024)
+   if ((size_t)s.table_f4 * 16 + (size_t)MDH_SCR_PARK_ROWS * MDH_BLOCK * sizeof(float) > 64 * 1024)
       return seterr(MDH_E_INVALID, "scene tables exceed the 64 KiB LDS budget of a workgroup");
    if (t.size() > r->table_cap) { // grow the whole ring (rare: the table only grows with the primitive counts)
       HIP_TRY(hipDeviceSynchronize());
@@ -965,14 +965,8 @@ static size_t lds_bytes(const mdh_renderer *r) { return (size_t)r->ks.table_f4 *
 static size_t lds_bytes_march(const mdh_renderer *r) { return lds_bytes(r) + (size_t)MDH_PARK_DWORDS * MDH_BLOCK * sizeof(float); }
 // the screen pass runs without the visibility queue, whose entries, first steps and result words are the park
 // slots from 15 up: 3 KiB less per workgroup, room for one more workgroup of a neighbouring pass on the CU
-#ifndef MDH_SCR_PARK_DWORDS
-#if MDH_SCR_QVIS || defined(MDH_PHASES)
-#define MDH_SCR_PARK_DWORDS MDH_PARK_DWORDS
-#else
-#define MDH_SCR_PARK_DWORDS MDH_PARK_DWORDS
-#endif
-#endif
-static size_t lds_bytes_screen(const mdh_renderer *r) { return lds_bytes(r) + (size_t)MDH_SCR_PARK_DWORDS * MDH_BLOCK * sizeof(float); }
+// (the screen pass has its ring of probe terms behind the common rows, mdh_march.h: MDH_SCR_PARK_ROWS)
+static size_t lds_bytes_screen(const mdh_renderer *r) { return lds_bytes(r) + (size_t)MDH_SCR_PARK_ROWS * MDH_BLOCK * sizeof(float); }
 
 // ------------------------------------------------------------------ hiprtc build of user-defined kinds
 // MDH_OPT_JIT: instead of interpreting the MDH_X programs, compile them.  Every program becomes a

@@ -24,6 +24,9 @@
 #ifndef MDH_SKIP_NULL_RAYS
 #define MDH_SKIP_NULL_RAYS 1
 #endif
+#ifndef MDH_TWIN_PREV
+#define MDH_TWIN_PREV 1
+#endif
 
 struct MachineCfg {
    bool direct_specular;   // M_COMPUTE_DIRECT_SPECULAR
@@ -147,6 +150,15 @@ template <int PART> MDH_DEV bool march_plain(const KScene &sc, f3 o, f3 d, float
 #else
 #define MDH_PARK_DWORDS 20
 #endif
+// screen pass only: the ring of probe terms of corners folded along y -- two entries of {term.xyz, weight}.  During
+// the first point's corner loop the rows of its irradiance (12-14, parked behind the loop) and of the reflection's
+// colour (15-17, cleared behind the loop) are free: entry 0 = rows 12-15, entry 1 = rows 16, 17 and two rows of its own.
+#ifndef MDH_TWIN_RING
+#define MDH_TWIN_RING 1
+#endif
+#define MDH_PARK_RING2 (MDH_PARK_DWORDS + 1) // (behind the diagnostics' row)
+#define MDH_SCR_PARK_ROWS (MDH_TWIN_RING ? MDH_PARK_RING2 + 2 : MDH_PARK_DWORDS)
+MDH_DEV int ring_row(int entry, int c) { return entry == 0 ? 12 + c : (c < 2 ? 16 + c : MDH_PARK_RING2 + c - 2); }
 MDH_DEV float *park_base(const KScene &sc) { return (float *)(s_tab + sc.table_f4); }
 // A thread's own column of the park rows is addressed WITHOUT an address register: ds_write_addtid_b32 /
 // ds_read_addtid_b32 take M0[15:0] + offset + 4 * lane (scripts/addtid_probe.hip checks that on the box), so a park
@@ -413,8 +425,8 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
    const int wb = park_wave_base(pk);
    hit = false;
    ph.index = -1; ph.t = 0.0f; ph.steps = 0;
-   // (the reflection's colour and the primary hit's material id wait in LDS for the combine, like P, N and the light)
-   if (REFLECT) park_store3<MDH_PARK_SPEC>(pk, wb, F3(0.0f, 0.0f, 0.0f));
+   // (the reflection's colour and the primary hit's material id wait in LDS for the combine, like P, N and the light;
+   //  the colour's rows are cleared behind the first point's corner loop, which uses them meanwhile)
    bool shaded = false; // the primary ray hit and the full shading ran
    // the ray that finds the next point to shade
    f3 ro = from, rd = dir_in;
@@ -528,6 +540,11 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
                   PH_ADD(pt, 5);
                   // (Reusing the whole irradiance term of a folded corner's twin through a small register ring was
                   // measured: the 16 extra VGPRs cost what the taps saved -- DESIGN.md, dropped experiments.)
+                  // A corner folded onto its twin along x follows it directly (i - 1): the twin's probe term -- direction,
+                  // visibility, weight before the trilinear factor, irradiance tap -- is this corner's, value for value,
+                  // and is still in registers.  (Twins along y and z are two and four corners back: see above.)
+                  f3 s_keep = F3(0.0f, 0.0f, 0.0f);
+                  float w_keep = 0.0f;
 #pragma unroll 1
                   for (int i = 0; i < 8; ++i) {
                      // best probe: a folded corner has the weight of its twin, which is not strictly larger
@@ -536,7 +553,23 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
                      f3 s_term = F3(0.0f, 0.0f, 0.0f); // sqrt(irradiance tap) of this corner's probe
                      float wpre = 0.0f;                // its weight before the trilinear factor
                      const i3 q = cage_probe(pq, gp, i);
-                     {
+                     const bool twin_prev = MDH_TWIN_PREV && irrp && (i & 1) && (folded & 1);
+                     // A corner folded along y (and not z) has its twin two corners back: that term waits in a two-entry
+                     // ring in LDS (MDH_PARK_RING: 2 x 4 rows; twins along z would need four entries, 16 rows: no room).
+                     const bool ring = MDH_TWIN_RING && REFLECT && ctx == 0 && (folded & 6) == 2;
+                     const bool twin_ring = ring && (i & 2) && !twin_prev;
+                     if (twin_prev) {
+                        s_term = s_keep;
+                        wpre = w_keep;
+                        vis_bits |= ((vis_bits >> (i - 1)) & 1) << i;
+                     } else if (twin_ring) {
+                        const int twin = i & ~folded;
+                        const float *e = pk + park_col(pk, wb);
+                        const int en = twin & 1;
+                        s_term = F3(e[ring_row(en, 0) * MDH_BLOCK], e[ring_row(en, 1) * MDH_BLOCK], e[ring_row(en, 2) * MDH_BLOCK]);
+                        wpre = e[ring_row(en, 3) * MDH_BLOCK];
+                        vis_bits |= ((vis_bits >> twin) & 1) << i;
+                     } else {
                      const f3 pw = grid_to_world(pq, q);
                      const f3 hvec = irrp ? (pw - P) : (P - pw);
                      const float dist = length(hvec);
@@ -622,6 +655,13 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
                         weight *= tri.x * tri.y * tri.z;
                         acc = acc + s_term * weight;
                         accw += weight;
+                        if (MDH_TWIN_PREV) { s_keep = s_term; w_keep = wpre; }
+                        if (ring && i == (i & ~folded)) { // a corner with twins to come: its term into the ring
+                           float *e = pk + park_col(pk, wb);
+                           const int en = i & 1;
+                           e[ring_row(en, 0) * MDH_BLOCK] = s_term.x; e[ring_row(en, 1) * MDH_BLOCK] = s_term.y;
+                           e[ring_row(en, 2) * MDH_BLOCK] = s_term.z; e[ring_row(en, 3) * MDH_BLOCK] = wpre;
+                        }
                      }
                      PH_ADD(pt, 6);
                   }
@@ -637,6 +677,7 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
                      f3 irr = F3(0.0f, 0.0f, 0.0f);
                      if (accw != 0.0f) { irr = acc / accw; irr = irr * irr; }
                      park_store3<12>(pk, wb, irr);
+                     if (REFLECT) park_store3<MDH_PARK_SPEC>(pk, wb, F3(0.0f, 0.0f, 0.0f));
                      shaded = true;
                      // the reflection ray of render_probes.glsl:262-275 finds the next point
                      // (the material id comes back from its park slot: kept in a register across the corner loop it is spilled)
