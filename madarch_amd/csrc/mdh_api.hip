@@ -965,7 +965,6 @@ static size_t lds_bytes(const mdh_renderer *r) { return (size_t)r->ks.table_f4 *
 static size_t lds_bytes_march(const mdh_renderer *r) { return lds_bytes(r) + (size_t)MDH_PARK_DWORDS * MDH_BLOCK * sizeof(float); }
 // the screen pass runs without the visibility queue, whose entries, first steps and result words are the park
 // slots from 15 up: 3 KiB less per workgroup, room for one more workgroup of a neighbouring pass on the CU
-// (the screen pass has its ring of probe terms behind the common rows, mdh_march.h: MDH_SCR_PARK_ROWS)
 static size_t lds_bytes_screen(const mdh_renderer *r) { return lds_bytes(r) + (size_t)MDH_SCR_PARK_ROWS * MDH_BLOCK * sizeof(float); }
 
 // ------------------------------------------------------------------ hiprtc build of user-defined kinds

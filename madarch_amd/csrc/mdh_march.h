@@ -150,15 +150,13 @@ template <int PART> MDH_DEV bool march_plain(const KScene &sc, f3 o, f3 d, float
 #else
 #define MDH_PARK_DWORDS 20
 #endif
-// screen pass only: the ring of probe terms of corners folded along y -- two entries of {term.xyz, weight}.  During
-// the first point's corner loop the rows of its irradiance (12-14, parked behind the loop) and of the reflection's
-// colour (15-17, cleared behind the loop) are free: entry 0 = rows 12-15, entry 1 = rows 16, 17 and two rows of its own.
-#ifndef MDH_TWIN_RING
-#define MDH_TWIN_RING 1
-#endif
-#define MDH_PARK_RING2 (MDH_PARK_DWORDS + 1) // (behind the diagnostics' row)
-#define MDH_SCR_PARK_ROWS (MDH_TWIN_RING ? MDH_PARK_RING2 + 2 : MDH_PARK_DWORDS)
-MDH_DEV int ring_row(int entry, int c) { return entry == 0 ? 12 + c : (c < 2 ? 16 + c : MDH_PARK_RING2 + c - 2); }
+// screen pass only, during the FIRST point's corner loop: the rows of its irradiance (12-14, parked behind the loop) and
+// of the reflection's colour (15-17, cleared behind the loop) are free and hold what the loop needs at every corner but
+// must not keep in registers across its marches -- the position inside the cage (alpha) and the clamped octahedral
+// texel of N
+#define MDH_PARK_ALPHA 12
+#define MDH_PARK_RIDN 15
+#define MDH_SCR_PARK_ROWS MDH_PARK_DWORDS
 MDH_DEV float *park_base(const KScene &sc) { return (float *)(s_tab + sc.table_f4); }
 // A thread's own column of the park rows is addressed WITHOUT an address register: ds_write_addtid_b32 /
 // ds_read_addtid_b32 take M0[15:0] + offset + 4 * lane (scripts/addtid_probe.hip checks that on the box), so a park
@@ -540,9 +538,26 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
                   PH_ADD(pt, 5);
                   // (Reusing the whole irradiance term of a folded corner's twin through a small register ring was
                   // measured: the 16 extra VGPRs cost what the taps saved -- DESIGN.md, dropped experiments.)
+                  // what does not depend on the corner, once (the compiler can no longer hoist it by itself: inside the loop the
+                  // probe parameters are read afresh per corner): the position inside the cage and the clamped octahedral
+                  // texel of N
+                  f3 alpha = F3(0.0f, 0.0f, 0.0f);
+                  f2 rid_n = F2(0.0f, 0.0f);
+                  const bool parked = REFLECT && ctx == 0; // (the rows are free then: see MDH_PARK_ALPHA)
+                  if (irrp) {
+                     alpha = P / F3(pg.sx, pg.sy, pg.sz) - F3((float)gp.x, (float)gp.y, (float)gp.z);
+                     rid_n = ray_dir_to_ray_id(N);
+                     rid_n = F2(clamp_(rid_n.x, pg.irr_lo, pg.irr_hi), clamp_(rid_n.y, pg.irr_lo, pg.irr_hi));
+                     if (parked) { // five registers less through the visibility marches
+                        park_store3<MDH_PARK_ALPHA>(pk, wb, alpha);
+                        park_store1<MDH_PARK_RIDN>(pk, wb, rid_n.x);
+                        park_store1<MDH_PARK_RIDN + 1>(pk, wb, rid_n.y);
+                     }
+                  }
                   // A corner folded onto its twin along x follows it directly (i - 1): the twin's probe term -- direction,
                   // visibility, weight before the trilinear factor, irradiance tap -- is this corner's, value for value,
-                  // and is still in registers.  (Twins along y and z are two and four corners back: see above.)
+                  // and is still in registers.  (Twins along y and z are two and four corners back: a ring of terms in LDS for
+                  // y was measured at +0.4 %, DESIGN.md.)
                   f3 s_keep = F3(0.0f, 0.0f, 0.0f);
                   float w_keep = 0.0f;
 #pragma unroll 1
@@ -554,21 +569,10 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
                      float wpre = 0.0f;                // its weight before the trilinear factor
                      const i3 q = cage_probe(pq, gp, i);
                      const bool twin_prev = MDH_TWIN_PREV && irrp && (i & 1) && (folded & 1);
-                     // A corner folded along y (and not z) has its twin two corners back: that term waits in a two-entry
-                     // ring in LDS (MDH_PARK_RING: 2 x 4 rows; twins along z would need four entries, 16 rows: no room).
-                     const bool ring = MDH_TWIN_RING && REFLECT && ctx == 0 && (folded & 6) == 2;
-                     const bool twin_ring = ring && (i & 2) && !twin_prev;
                      if (twin_prev) {
                         s_term = s_keep;
                         wpre = w_keep;
                         vis_bits |= ((vis_bits >> (i - 1)) & 1) << i;
-                     } else if (twin_ring) {
-                        const int twin = i & ~folded;
-                        const float *e = pk + park_col(pk, wb);
-                        const int en = twin & 1;
-                        s_term = F3(e[ring_row(en, 0) * MDH_BLOCK], e[ring_row(en, 1) * MDH_BLOCK], e[ring_row(en, 2) * MDH_BLOCK]);
-                        wpre = e[ring_row(en, 3) * MDH_BLOCK];
-                        vis_bits |= ((vis_bits >> twin) & 1) << i;
                      } else {
                      const f3 pw = grid_to_world(pq, q);
                      const f3 hvec = irrp ? (pw - P) : (P - pw);
@@ -580,8 +584,7 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
                      // N only: its texel loads go out now and land while the visibility ray is marched
                      AtlasTap tap;
                      if (irrp) {
-                        f2 rid = ray_dir_to_ray_id(N);
-                        rid = F2(clamp_(rid.x, pq.irr_lo, pq.irr_hi), clamp_(rid.y, pq.irr_lo, pq.irr_hi));
+                        const f2 rid = parked ? F2(park_load1<MDH_PARK_RIDN>(pk, wb), park_load1<MDH_PARK_RIDN + 1>(pk, wb)) : rid_n;
                         const f2 base = probe_id_to_coord<P2>(pq, grid_to_probe_id(pq, q));
                         tap = atlas_tap_issue<P2>(pq.irr, pq.fmt, pq.pcx, pq.pcy, pq.ires, pq.ishift, pq.irr_w, pq.irr_h, base.x + div_pcx<P2>(pq, rid.x), base.y + div_pcy<P2>(pq, rid.y), pq.m_ires);
                         if (MDH_PARK_TAP && REFLECT) park_store1<MDH_PARK_TAPX>(pk, wb, tap.fx); // (one register less through the visibility march)
@@ -635,8 +638,7 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
                         if (MDH_PARK_TAP && REFLECT) tap.fx = park_load1<MDH_PARK_TAPX>(pk, wb);
                         f3 tx = atlas_tap_resolve(pq.irr, pq.fmt, tap, u8_tab);
 #else
-                        f2 rid = ray_dir_to_ray_id(N);
-                        rid = F2(clamp_(rid.x, pq.irr_lo, pq.irr_hi), clamp_(rid.y, pq.irr_lo, pq.irr_hi));
+                        const f2 rid = rid_n;
                         f2 base = probe_id_to_coord<P2>(pq, grid_to_probe_id(pq, q));
                         f3 tx = atlas_sample<P2>(pq.irr, pq.fmt, pq.pcx, pq.pcy, pq.ires, pq.ishift, pq.irr_w, pq.irr_h, base.x + div_pcx<P2>(pq, rid.x), base.y + div_pcy<P2>(pq, rid.y), u8_tab, pq.m_ires);
 #endif
@@ -649,19 +651,13 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
                      }
                      if (irrp) { // render_probes.glsl:34-62: the trilinear factor and the sum
                         float weight = wpre;
-                        const f3 alpha = P / F3(pq.sx, pq.sy, pq.sz) - F3((float)gp.x, (float)gp.y, (float)gp.z);
+                        if (parked) alpha = park_load3<MDH_PARK_ALPHA>(pk, wb);
                         f3 tri = F3(mix_(1.0f - alpha.x, alpha.x, (float)(i & 1)), mix_(1.0f - alpha.y, alpha.y, (float)((i >> 1) & 1)),
                                     mix_(1.0f - alpha.z, alpha.z, (float)((i >> 2) & 1)));
                         weight *= tri.x * tri.y * tri.z;
                         acc = acc + s_term * weight;
                         accw += weight;
                         if (MDH_TWIN_PREV) { s_keep = s_term; w_keep = wpre; }
-                        if (ring && i == (i & ~folded)) { // a corner with twins to come: its term into the ring
-                           float *e = pk + park_col(pk, wb);
-                           const int en = i & 1;
-                           e[ring_row(en, 0) * MDH_BLOCK] = s_term.x; e[ring_row(en, 1) * MDH_BLOCK] = s_term.y;
-                           e[ring_row(en, 2) * MDH_BLOCK] = s_term.z; e[ring_row(en, 3) * MDH_BLOCK] = wpre;
-                        }
                      }
                      PH_ADD(pt, 6);
                   }
