@@ -73,7 +73,7 @@ __device__ unsigned long long g_diag[16];
 // -DMDH_PHASES: wall cycles (s_memtime) per wave spent in each region of the pixel program, summed over waves
 #ifdef MDH_PHASES
 __device__ unsigned long long g_phase[16];
-#define MDH_PH_SLOT 20 // one extra park slot: 32 u64 accumulators per wave
+#define MDH_PH_SLOT 19 // one extra park slot: 32 u64 accumulators per wave
 MDH_DEV unsigned long long *ph_acc_(float *pk) { return (unsigned long long *)(pk + MDH_PH_SLOT * MDH_BLOCK + (threadIdx.x & ~63)); }
 MDH_DEV void ph_add_(float *pk, int id, unsigned long long dt)
 {
@@ -141,14 +141,10 @@ template <int PART> MDH_DEV bool march_plain(const KScene &sc, f3 o, f3 d, float
 // before the irradiance is parked
 #define MDH_PARK_SPEC 15
 #define MDH_PARK_MAT 18
-#define MDH_PARK_TAPX 19 // screen pass: the x fraction of the corner's irradiance tap during its visibility march
-#ifndef MDH_PARK_TAP
-#define MDH_PARK_TAP 1
-#endif
 #ifdef MDH_PHASES
-#define MDH_PARK_DWORDS 21
-#else
 #define MDH_PARK_DWORDS 20
+#else
+#define MDH_PARK_DWORDS 19
 #endif
 // screen pass only, during the FIRST point's corner loop: the rows of its irradiance (12-14, parked behind the loop) and
 // of the reflection's colour (15-17, cleared behind the loop) are free and hold what the loop needs at every corner but
@@ -587,7 +583,6 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
                         const f2 rid = parked ? F2(park_load1<MDH_PARK_RIDN>(pk, wb), park_load1<MDH_PARK_RIDN + 1>(pk, wb)) : rid_n;
                         const f2 base = probe_id_to_coord<P2>(pq, grid_to_probe_id(pq, q));
                         tap = atlas_tap_issue<P2>(pq.irr, pq.fmt, pq.pcx, pq.pcy, pq.ires, pq.ishift, pq.irr_w, pq.irr_h, base.x + div_pcx<P2>(pq, rid.x), base.y + div_pcy<P2>(pq, rid.y), pq.m_ires);
-                        if (MDH_PARK_TAP && REFLECT) park_store1<MDH_PARK_TAPX>(pk, wb, tap.fx); // (one register less through the visibility march)
                      }
 #endif
                      // raycast_visibility, raymarching.glsl:39-56
@@ -635,7 +630,6 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
 #ifdef MDH_ABL_NO_TAPS
                         f3 tx = F3((float)q.x, (float)q.y, N.x);
 #elif MDH_TAP_EARLY
-                        if (MDH_PARK_TAP && REFLECT) tap.fx = park_load1<MDH_PARK_TAPX>(pk, wb);
                         f3 tx = atlas_tap_resolve(pq.irr, pq.fmt, tap, u8_tab);
 #else
                         const f2 rid = rid_n;
