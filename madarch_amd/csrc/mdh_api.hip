@@ -217,6 +217,8 @@ struct mdh_renderer {
    // single pass works on it in place.  A pipelined mdh_render (frame overlap, see mdh_render) writes the
    // other set while the previous frame's screen pass still reads this one, then flips.
    void *d_rad2[2] = {nullptr, nullptr}, *d_irr2[2] = {nullptr, nullptr};
+   int n_cus = 0;                          // compute units of the device
+   std::map<std::pair<const void *, size_t>, int> resident; // workgroups per CU of (kernel, LDS bytes): rad_first_round
    int last = 0;
    int opt_overlap = 2;
    int opt_irr_all = 1; // MDH_OPT_IRRADIANCE_ALL
@@ -753,6 +755,7 @@ extern "C" int32_t mdh_create(int32_t width, int32_t height, const mdh_scene_des
    if (device < 0 || device >= ndev) { delete r; return seterr(MDH_E_NO_DEVICE, "device ordinal out of range"); }
    hipDeviceProp_t prop;
    if (hipGetDeviceProperties(&prop, device) != hipSuccess || strncmp(prop.gcnArchName, "gfx950", 6) != 0) { delete r; return seterr(MDH_E_NO_DEVICE, "device is not gfx950 (MI355X); the kernels are built for gfx950 only"); }
+   r->n_cus = prop.multiProcessorCount;
    int rc = MDH_OK;
    auto fail = [&](int code) { mdh_destroy(r); return code; };
 #define TRY_OR_FAIL(expr)                                                                                          \
@@ -1159,6 +1162,25 @@ static JitModule *jit_module(mdh_renderer *r, const std::vector<std::string> &ex
    g_jit_cache[key] = m;
    return m;
 }
+// The workgroups of the radiance pass the chip holds at once, when the launch is that and a remainder smaller than
+// it (k_radiance, mdh_kernels.h: the remainder runs at a raised issue priority); 0 otherwise.
+#ifndef MDH_RAD_TAIL_PRIO
+#define MDH_RAD_TAIL_PRIO 1
+#endif
+static int rad_first_round(mdh_renderer *r, const void *kernel, hipFunction_t fn, size_t lds, int blocks)
+{
+   const void *key = kernel ? kernel : (const void *)fn;
+   auto it = r->resident.find({key, lds});
+   if (it == r->resident.end()) {
+      int per_cu = 0;
+      const hipError_t e = kernel ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, MDH_BLOCK, lds)
+                                  : hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, MDH_BLOCK, lds);
+      if (e != hipSuccess) { (void)hipGetLastError(); per_cu = 0; }
+      it = r->resident.insert({{key, lds}, per_cu}).first;
+   }
+   const long first = (long)it->second * r->n_cus;
+   return MDH_RAD_TAIL_PRIO && first > 0 && blocks > first && blocks < 2 * first ? (int)first : 0;
+}
 // launch a function of a JIT module: the arguments are the kernel's by-value structs, laid out as the
 // kernarg segment lays them out (each at its natural alignment = a struct of them)
 template <typename Args> static int jit_launch(hipFunction_t f, int blocks, int block, size_t lds, hipStream_t st, Args &args)
@@ -1346,15 +1368,25 @@ static int run_pass(mdh_renderer *r, int pass, hipStream_t st, int src, int dst,
       }
       if (n > 0) {
          int blocks = (int)((n + MDH_BLOCK - 1) / MDH_BLOCK);
+         const size_t lds = lds_bytes_march(r);
          if (jit) {
-            struct { KScene sc; KProbes pr; } args = {r->ks, pr};
-            int rc = jit_launch(jm->fn[kname], blocks, MDH_BLOCK, lds_bytes_march(r), st, args);
+            struct { KScene sc; KProbes pr; int first_round; } args = {r->ks, pr, rad_first_round(r, nullptr, jm->fn[kname], lds, blocks)};
+            int rc = jit_launch(jm->fn[kname], blocks, MDH_BLOCK, lds, st, args);
             if (rc != MDH_OK) return rc;
-         } else if (pow2 && !has_custom) {
-            if (pf & MDH_PF_PART) hipLaunchKernelGGL(k_radiance<MDH_PF_PART | MDH_PF_POW2>, dim3(blocks), dim3(MDH_BLOCK), lds_bytes_march(r), st, r->ks, pr);
-            else hipLaunchKernelGGL(k_radiance<MDH_PF_POW2>, dim3(blocks), dim3(MDH_BLOCK), lds_bytes_march(r), st, r->ks, pr);
-         } else
-            MDH_LAUNCH_PF(k_radiance, dim3(blocks), dim3(MDH_BLOCK), lds_bytes_march(r), r->ks, pr);
+         } else {
+#define MDH_LAUNCH_RAD(K) hipLaunchKernelGGL(K, dim3(blocks), dim3(MDH_BLOCK), lds, st, r->ks, pr, rad_first_round(r, (const void *)K, nullptr, lds, blocks))
+            if (pow2 && !has_custom) {
+               if (pf & MDH_PF_PART) MDH_LAUNCH_RAD(k_radiance<MDH_PF_PART | MDH_PF_POW2>);
+               else MDH_LAUNCH_RAD(k_radiance<MDH_PF_POW2>);
+            } else
+               switch (pf) {
+               case 0: MDH_LAUNCH_RAD(k_radiance<0>); break;
+               case 1: MDH_LAUNCH_RAD(k_radiance<1>); break;
+               case 2: MDH_LAUNCH_RAD(k_radiance<2>); break;
+               default: MDH_LAUNCH_RAD(k_radiance<3>); break;
+               }
+#undef MDH_LAUNCH_RAD
+         }
       }
       break;
    }
