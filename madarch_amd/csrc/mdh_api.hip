@@ -1314,8 +1314,13 @@ static int run_pass(mdh_renderer *r, int pass, hipStream_t st, int src, int dst,
    const int pf = (r->part.enable != 0 ? MDH_PF_PART : 0) | (has_custom ? MDH_PF_CUSTOM : 0);
    // the probe-sampling kernels (radiance, mode-0 screen) have a variant for atlases whose every dimension is a power of two
    auto is_pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
+   // (... and small enough for what those variants assume besides: probe ids within 24-bit products, RGBA8 byte offsets
+   //  within 32 bits -- mdh_device.h: grid_to_probe_id, atlas_rgba8)
+   const long long pcount = (long long)r->probes.probe_count[0] * r->probes.probe_count[1];
+   const long long rres = r->probes.radiance_resolution, ires = r->probes.irradiance_resolution;
    const bool pow2 = is_pow2(r->probes.probe_count[0]) && is_pow2(r->probes.probe_count[1]) && is_pow2(r->probes.radiance_resolution) &&
-                     is_pow2(r->probes.irradiance_resolution);
+                     is_pow2(r->probes.irradiance_resolution) && pcount < 65536 && pcount * rres * rres <= (1ll << 30) &&
+                     pcount * ires * ires <= (1ll << 30);
 #define MDH_LAUNCH_PF(KERNEL, GRID, BLOCK, LDS, ...)                                                      \
    do {                                                                                                   \
       switch (pf) {                                                                                       \

@@ -983,13 +983,19 @@ MDH_DEV i3 world_to_grid(const KProbes &pr, f3 p)
    g.x = (int)f.x; g.y = (int)f.y; g.z = (int)f.z;
    return g;
 }
-MDH_DEV int grid_to_probe_id(const KProbes &pr, i3 g) { return g.z * pr.gx * pr.gy + g.y * pr.gx + g.x; }
+// (P2: the kernel variants for power-of-two atlases run on fewer than 65 536 probes -- run_pass -- where the products fit
+// the 24-bit multiplier, which issues at the full rate)
+template <bool P2 = false> MDH_DEV int grid_to_probe_id(const KProbes &pr, i3 g)
+{
+   if (P2) return __mul24(g.z, pr.gx * pr.gy) + __mul24(g.y, pr.gx) + g.x;
+   return g.z * pr.gx * pr.gy + g.y * pr.gx + g.x;
+}
 // x / probe_count: a multiplication when the count is a power of two (exact: the same real value, rounded once)
 template <bool P2 = false> MDH_DEV float div_pcx(const KProbes &pr, float x) { return (P2 || pr.inv_pcx != 0.0f) ? x * pr.inv_pcx : x / pr.fpcx; }
 template <bool P2 = false> MDH_DEV float div_pcy(const KProbes &pr, float y) { return (P2 || pr.inv_pcy != 0.0f) ? y * pr.inv_pcy : y / pr.fpcy; }
 template <bool P2 = false> MDH_DEV f2 probe_id_to_coord(const KProbes &pr, int id)
 {
-   int y = (P2 || pr.pcx_shift >= 0) ? (id >> pr.pcx_shift) : div_magic(id, pr.pcx, pr.m_pcx), x = id - y * pr.pcx;
+   int y = (P2 || pr.pcx_shift >= 0) ? (id >> pr.pcx_shift) : div_magic(id, pr.pcx, pr.m_pcx), x = P2 ? (id & (pr.pcx - 1)) : id - y * pr.pcx;
    return F2(div_pcx<P2>(pr, (float)x), div_pcy<P2>(pr, (float)y));
 }
 // glsl/probe_utils.glsl:58-92
@@ -1025,11 +1031,11 @@ MDH_DEV f2 ray_dir_to_ray_id(f3 d)
 // the whole kernel -- seven of them in the screen pass, four of which ended up in scratch)
 template <bool P2 = false> MDH_DEV int mirror(int i, int n)
 {
-   if ((unsigned)i < (unsigned)n) return i; // inside the image: the usual case
-   if (P2) {
+   if (P2) { // (three instructions, inside the image or not: the period is a mask, the reflection a minimum)
       const int m = i & (2 * n - 1);
-      return m >= n ? 2 * n - 1 - m : m;
+      return min(m, 2 * n - 1 - m);
    }
+   if ((unsigned)i < (unsigned)n) return i; // inside the image: the usual case
    // one reflection covers [-n, 2n): every tap of this library (coordinates clamped inside a tile, or a texel
    // beside the image) -- the same value as the modulo form below
    if ((unsigned)(i + n) < (unsigned)(3 * n)) return i < 0 ? -1 - i : 2 * n - 1 - i;
@@ -1056,15 +1062,46 @@ template <bool P2 = false> MDH_DEV unsigned atlas_index(int pcx, int res, int sh
    else { tx = div_magic(X, res, magic); ty = div_magic(Y, res, magic); }
    return ((unsigned)(ty * pcx + tx) * res + (Y - ty * res)) * res + (X - tx * res);
 }
+// The same index as the sum of a term of the row and a term of the column -- ((ty pcx + tx) res + ry) res + rx =
+// (ty pcx res^2 + ry res) + (tx res^2 + rx), exact in the ring of 32-bit integers -- so that the four texels of a
+// bilinear tap share two of each; with powers of two (P2) every product is a shift of masked bits.  (32-bit integer
+// products issue at a quarter of the rate of the other integer operations: the tap's addressing was the largest single
+// item of the screen pass's probe code.)
+template <bool P2> MDH_DEV unsigned atlas_col(int res, int shift, int X, unsigned magic)
+{
+   if (P2) return ((unsigned)(X & ~(res - 1)) << shift) + (unsigned)(X & (res - 1));
+   const int tx = shift >= 0 ? X >> shift : div_magic(X, res, magic);
+   return (unsigned)(tx * res) * (unsigned)res + (unsigned)(X - tx * res);
+}
+template <bool P2> MDH_DEV unsigned atlas_row(int pcx, int res, int shift, int Y, unsigned magic)
+{
+   if (P2) return ((unsigned)(Y & ~(res - 1)) << (shift + (31 - __builtin_clz(pcx)))) + ((unsigned)(Y & (res - 1)) << shift);
+   const int ty = shift >= 0 ? Y >> shift : div_magic(Y, res, magic);
+   return ((unsigned)(ty * pcx) * (unsigned)res + (unsigned)(Y - ty * res)) * (unsigned)res;
+}
+// Atlas reads are GLOBAL loads: through the generic pointer of the argument block they are flat loads, which count as
+// LDS operations too -- every wait for an LDS read (each step of a march) then also waits for the texels in flight.
+// P2: the byte offset of an RGBA8 texel fits 32 bits (run_pass starts these variants on atlases below 4 GiB only), the
+// load takes the base from scalar registers and needs no 64-bit address arithmetic.
+typedef const unsigned __attribute__((address_space(1))) *GlobalU32;
+typedef const char __attribute__((address_space(1))) *GlobalBytes;
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef const f4v __attribute__((address_space(1))) *GlobalF4;
+template <bool P2 = false> MDH_DEV unsigned atlas_rgba8(const void *base, unsigned idx)
+{
+   if (P2) return *(GlobalU32)((GlobalBytes)base + (idx << 2));
+   return ((GlobalU32)base)[idx];
+}
 // u8_tab = float index of the k / 255 table in LDS (KScene::u8_slot * 4), or < 0: divide
-MDH_DEV f3 atlas_texel(const void *base, int fmt, unsigned idx, int u8_tab)
+template <bool P2 = false> MDH_DEV f3 atlas_texel(const void *base, int fmt, unsigned idx, int u8_tab)
 {
    if (fmt == 0) {
-      uchar4 t = ((const uchar4 *)base)[idx];
-      if (u8_tab >= 0) return F3(tab_float(u8_tab + t.x), tab_float(u8_tab + t.y), tab_float(u8_tab + t.z));
-      return F3((float)t.x / 255.0f, (float)t.y / 255.0f, (float)t.z / 255.0f);
+      const unsigned t = atlas_rgba8<P2>(base, idx);
+      const unsigned x = t & 255u, y = (t >> 8) & 255u, z = (t >> 16) & 255u;
+      if (u8_tab >= 0) return F3(tab_float(u8_tab + x), tab_float(u8_tab + y), tab_float(u8_tab + z));
+      return F3((float)x / 255.0f, (float)y / 255.0f, (float)z / 255.0f);
    }
-   float4 t = ((const float4 *)base)[idx];
+   const f4v t = ((GlobalF4)base)[idx];
    return F3(t.x, t.y, t.z);
 }
 MDH_DEV void atlas_store(void *base, int fmt, unsigned idx, f3 v)
@@ -1089,8 +1126,10 @@ MDH_DEV f3 atlas_sample(const void *base, int fmt, int pcx, int pcy, int res, in
    float fx = px - fx0, fy = py - fy0;
    int x0 = mirror<P2>((int)fx0, W), x1 = mirror<P2>((int)fx0 + 1, W), y0 = mirror<P2>((int)fy0, H), y1 = mirror<P2>((int)fy0 + 1, H);
    float w00 = (1.0f - fx) * (1.0f - fy), w10 = fx * (1.0f - fy), w01 = (1.0f - fx) * fy, w11 = fx * fy;
-   f3 a = atlas_texel(base, fmt, atlas_index<P2>(pcx, res, shift, x0, y0, magic), u8_tab), b = atlas_texel(base, fmt, atlas_index<P2>(pcx, res, shift, x1, y0, magic), u8_tab);
-   f3 c = atlas_texel(base, fmt, atlas_index<P2>(pcx, res, shift, x0, y1, magic), u8_tab), d = atlas_texel(base, fmt, atlas_index<P2>(pcx, res, shift, x1, y1, magic), u8_tab);
+   const unsigned c0 = atlas_col<P2>(res, shift, x0, magic), c1 = atlas_col<P2>(res, shift, x1, magic);
+   const unsigned r0 = atlas_row<P2>(pcx, res, shift, y0, magic), r1 = atlas_row<P2>(pcx, res, shift, y1, magic);
+   f3 a = atlas_texel<P2>(base, fmt, r0 + c0, u8_tab), b = atlas_texel<P2>(base, fmt, r0 + c1, u8_tab);
+   f3 c = atlas_texel<P2>(base, fmt, r1 + c0, u8_tab), d = atlas_texel<P2>(base, fmt, r1 + c1, u8_tab);
    return ((a * w00 + b * w10) + c * w01) + d * w11;
 }
 
@@ -1111,12 +1150,10 @@ MDH_DEV AtlasTap atlas_tap_issue(const void *base, int fmt, int pcx, int pcy, in
    AtlasTap t;
    t.fx = px - fx0; t.fy = py - fy0;
    int x0 = mirror<P2>((int)fx0, W), x1 = mirror<P2>((int)fx0 + 1, W), y0 = mirror<P2>((int)fy0, H), y1 = mirror<P2>((int)fy0 + 1, H);
-   t.t00 = atlas_index<P2>(pcx, res, shift, x0, y0, magic); t.t10 = atlas_index<P2>(pcx, res, shift, x1, y0, magic);
-   t.t01 = atlas_index<P2>(pcx, res, shift, x0, y1, magic); t.t11 = atlas_index<P2>(pcx, res, shift, x1, y1, magic);
-   if (fmt == 0) {
-      const unsigned *b = (const unsigned *)base;
-      t.t00 = b[t.t00]; t.t10 = b[t.t10]; t.t01 = b[t.t01]; t.t11 = b[t.t11];
-   }
+   const unsigned c0 = atlas_col<P2>(res, shift, x0, magic), c1 = atlas_col<P2>(res, shift, x1, magic);
+   const unsigned r0 = atlas_row<P2>(pcx, res, shift, y0, magic), r1 = atlas_row<P2>(pcx, res, shift, y1, magic);
+   t.t00 = r0 + c0; t.t10 = r0 + c1; t.t01 = r1 + c0; t.t11 = r1 + c1;
+   if (fmt == 0) { t.t00 = atlas_rgba8<P2>(base, t.t00); t.t10 = atlas_rgba8<P2>(base, t.t10); t.t01 = atlas_rgba8<P2>(base, t.t01); t.t11 = atlas_rgba8<P2>(base, t.t11); }
    return t;
 }
 MDH_DEV f3 u8_texel(unsigned t, int u8_tab) { return F3(tab_float(u8_tab + (t & 255u)), tab_float(u8_tab + ((t >> 8) & 255u)), tab_float(u8_tab + ((t >> 16) & 255u))); }

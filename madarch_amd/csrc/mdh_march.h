@@ -581,7 +581,7 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
                      AtlasTap tap;
                      if (irrp) {
                         const f2 rid = parked ? F2(park_load1<MDH_PARK_RIDN>(pk, wb), park_load1<MDH_PARK_RIDN + 1>(pk, wb)) : rid_n;
-                        const f2 base = probe_id_to_coord<P2>(pq, grid_to_probe_id(pq, q));
+                        const f2 base = probe_id_to_coord<P2>(pq, grid_to_probe_id<P2>(pq, q));
                         tap = atlas_tap_issue<P2>(pq.irr, pq.fmt, pq.pcx, pq.pcy, pq.ires, pq.ishift, pq.irr_w, pq.irr_h, base.x + div_pcx<P2>(pq, rid.x), base.y + div_pcy<P2>(pq, rid.y), pq.m_ires);
                      }
 #endif
@@ -633,7 +633,7 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
                         f3 tx = atlas_tap_resolve(pq.irr, pq.fmt, tap, u8_tab);
 #else
                         const f2 rid = rid_n;
-                        f2 base = probe_id_to_coord<P2>(pq, grid_to_probe_id(pq, q));
+                        f2 base = probe_id_to_coord<P2>(pq, grid_to_probe_id<P2>(pq, q));
                         f3 tx = atlas_sample<P2>(pq.irr, pq.fmt, pq.pcx, pq.pcy, pq.ires, pq.ishift, pq.irr_w, pq.irr_h, base.x + div_pcx<P2>(pq, rid.x), base.y + div_pcy<P2>(pq, rid.y), u8_tab, pq.m_ires);
 #endif
                         s_term = sqrt3(tx);
@@ -681,7 +681,7 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
                      i3 bq;
                      bq.x = best_q & 1023; bq.y = (best_q >> 10) & 1023; bq.z = (best_q >> 20) & 1023;
                      const KProbes pq = probes_fresh(pr);
-                     f2 base = probe_id_to_coord<P2>(pq, grid_to_probe_id(pq, bq));
+                     f2 base = probe_id_to_coord<P2>(pq, grid_to_probe_id<P2>(pq, bq));
                      f2 brid = ray_dir_to_ray_id(acc);
                      brid = F2(clamp_(brid.x, pq.rad_lo, pq.rad_hi), clamp_(brid.y, pq.rad_lo, pq.rad_hi));
                      f3 radiance = atlas_sample<P2>(pq.rad, pq.fmt, pq.pcx, pq.pcy, pq.rres, pq.rshift, pq.rad_w, pq.rad_h, base.x + div_pcx<P2>(pq, brid.x), base.y + div_pcy<P2>(pq, brid.y), u8_tab, pq.m_rres);
