@@ -800,6 +800,7 @@ extern "C" int32_t mdh_create(int32_t width, int32_t height, const mdh_scene_des
    *r->h_warn = 0;
    size_t vis_n = (size_t)vol->visibility_resolution[0] * vol->visibility_resolution[1] * vol->visibility_resolution[2] * 3;
    size_t scat_n = (size_t)vol->scattering_resolution[0] * vol->scattering_resolution[1];
+   if (vis_n / 3 >= (1ull << 32) || scat_n >= (1ull << 32)) { seterr(MDH_E_INVALID, "a volumetrics texture of 2^32 texels or more"); return fail(MDH_E_INVALID); } // (tex_sample: 32-bit texel index)
    for (int s = 0; s < 2; ++s) {
       TRY_OR_FAIL(hipMalloc(&r->d_vis2[s], (vis_n ? vis_n : 1) * 4));
       TRY_OR_FAIL(hipMemsetAsync(r->d_vis2[s], 0, (vis_n ? vis_n : 1) * 4, r->stream));

@@ -1186,8 +1186,11 @@ template <int C> MDH_DEV void tex_sample(const float *data, int W, int H, float 
    float fx = px - fx0, fy = py - fy0;
    int x0 = mirror<false>((int)fx0, W), x1 = mirror<false>((int)fx0 + 1, W), y0 = mirror<false>((int)fy0, H), y1 = mirror<false>((int)fy0 + 1, H);
    float w00 = (1.0f - fx) * (1.0f - fy), w10 = fx * (1.0f - fy), w01 = (1.0f - fx) * fy, w11 = fx * fy;
-   const float *a = data + ((size_t)y0 * W + x0) * C, *b = data + ((size_t)y0 * W + x1) * C;
-   const float *c = data + ((size_t)y1 * W + x0) * C, *d = data + ((size_t)y1 * W + x1) * C;
+   typedef const float __attribute__((address_space(1))) *GlobalF32; // (global loads, not flat ones: see atlas_rgba8)
+   const GlobalF32 g = (GlobalF32)data;
+   const unsigned r0 = (unsigned)y0 * (unsigned)W, r1 = (unsigned)y1 * (unsigned)W; // (two products for the four texels; fewer than 2^32 texels: mdh_create)
+   const GlobalF32 a = g + (size_t)(r0 + (unsigned)x0) * C, b = g + (size_t)(r0 + (unsigned)x1) * C;
+   const GlobalF32 c = g + (size_t)(r1 + (unsigned)x0) * C, d = g + (size_t)(r1 + (unsigned)x1) * C;
 #pragma unroll
    for (int k = 0; k < C; ++k) out[k] = ((a[k] * w00 + b[k] * w10) + c[k] * w01) + d[k] * w11;
 }

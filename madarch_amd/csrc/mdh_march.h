@@ -201,6 +201,20 @@ template <int SLOT> MDH_DEV f3 park_load3(const float *pk, int wb)
    return F3(pk[(SLOT + 0) * MDH_BLOCK + t], pk[(SLOT + 1) * MDH_BLOCK + t], pk[(SLOT + 2) * MDH_BLOCK + t]);
 #endif
 }
+template <int SLOT> MDH_DEV f2 park_load2(const float *pk, int wb)
+{
+#if MDH_PARK_ADDTID
+   unsigned keep;
+   f2 v;
+   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tds_read_addtid_b32 %1 offset:%4\n\tds_read_addtid_b32 %2 offset:%5\n\t"
+                "s_waitcnt lgkmcnt(0)\n\ts_mov_b32 m0, %0"
+                : "=&s"(keep), "=&v"(v.x), "=&v"(v.y) : "s"(wb), "i"(SLOT * MDH_BLOCK * 4), "i"((SLOT + 1) * MDH_BLOCK * 4) : "memory");
+   return v;
+#else
+   const int t = park_col(pk, wb);
+   return F2(pk[(SLOT + 0) * MDH_BLOCK + t], pk[(SLOT + 1) * MDH_BLOCK + t]);
+#endif
+}
 template <int SLOT> MDH_DEV void park_store1(float *pk, int wb, float v)
 {
 #if MDH_PARK_ADDTID
@@ -580,7 +594,7 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
                      // N only: its texel loads go out now and land while the visibility ray is marched
                      AtlasTap tap;
                      if (irrp) {
-                        const f2 rid = parked ? F2(park_load1<MDH_PARK_RIDN>(pk, wb), park_load1<MDH_PARK_RIDN + 1>(pk, wb)) : rid_n;
+                        const f2 rid = parked ? park_load2<MDH_PARK_RIDN>(pk, wb) : rid_n;
                         const f2 base = probe_id_to_coord<P2>(pq, grid_to_probe_id<P2>(pq, q));
                         tap = atlas_tap_issue<P2>(pq.irr, pq.fmt, pq.pcx, pq.pcy, pq.ires, pq.ishift, pq.irr_w, pq.irr_h, base.x + div_pcx<P2>(pq, rid.x), base.y + div_pcy<P2>(pq, rid.y), pq.m_ires);
                      }
