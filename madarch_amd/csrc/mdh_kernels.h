@@ -248,6 +248,9 @@ template <int PART> __global__ __launch_bounds__(MDH_BLOCK, MDH_OCC_RAD(PART)) v
 #ifndef MDH_IRR_PACKED
 #define MDH_IRR_PACKED 1
 #endif
+#ifndef MDH_IRR_PREFETCH
+#define MDH_IRR_PREFETCH 1
+#endif
 #ifndef MDH_IRR_CHUNK
 #define MDH_IRR_CHUNK 256 // taps per LDS buffer when one wavefront folds (0 = all taps staged at once)
 #endif
@@ -300,16 +303,48 @@ __global__ __launch_bounds__(MDH_IRR_BLOCK) void k_irradiance(KProbes pr, const 
          const int base = c * CH, n_here = min(CH, ntaps - base);
          const float4 *buf = s_taps + (size_t)(c & 1) * 2 * CH;
          if (threadIdx.x < 64) {
-            if ((int)threadIdx.x < pr.ires * pr.ires)
-               for (int t = 0; t < n_here; ++t) {
-                  const float4 r = buf[2 * t], d = buf[2 * t + 1];
-                  const pk2 d_xy = {d.x, d.y}, r_xy = {r.x, r.y}, r_z1 = {r.z, r.w};
-                  const pk2 p = dir_xy * d_xy;
-                  const float w = max_((p.x + p.y) + irr_dir.z * d.z, 0.0f);
-                  const pk2 ww = {w, w};
-                  acc_xy = acc_xy + r_xy * ww;
-                  acc_zw = acc_zw + r_z1 * ww;
+            if ((int)threadIdx.x < pr.ires * pr.ires) {
+#define MDH_IRR_FOLD(r_, d_)                                                                  \
+               do {                                                                           \
+                  const float4 r = (r_), d = (d_);                                            \
+                  const pk2 d_xy = {d.x, d.y}, r_xy = {r.x, r.y}, r_z1 = {r.z, r.w};          \
+                  const pk2 p = dir_xy * d_xy;                                                \
+                  const float w = max_((p.x + p.y) + irr_dir.z * d.z, 0.0f);                  \
+                  const pk2 ww = {w, w};                                                      \
+                  acc_xy = acc_xy + r_xy * ww;                                                \
+                  acc_zw = acc_zw + r_z1 * ww;                                                \
+               } while (0)
+#if MDH_IRR_PREFETCH
+               // six taps per turn in two groups of three, each group on its way from LDS while the other is folded (this
+               // one wavefront is the pass's critical path: 1 024 taps in the reference's order, each waiting for its two LDS
+               // reads otherwise).  Three: two groups in flight are 12 LDS reads, and the counter a wavefront waits on
+               // holds 15.
+               constexpr int GR = 3;
+               const int nt = n_here - n_here % (2 * GR);
+               int t = 0;
+               float4 ra[GR], da[GR], rb[GR], db[GR];
+               if (nt > 0) {
+#pragma unroll
+                  for (int k = 0; k < GR; ++k) { ra[k] = buf[2 * k]; da[k] = buf[2 * k + 1]; }
                }
+#pragma unroll 1
+               for (; t < nt; t += 2 * GR) {
+#pragma unroll
+                  for (int k = 0; k < GR; ++k) { rb[k] = buf[2 * (t + GR + k)]; db[k] = buf[2 * (t + GR + k) + 1]; }
+#pragma unroll
+                  for (int k = 0; k < GR; ++k) MDH_IRR_FOLD(ra[k], da[k]);
+                  const int tn = t + 2 * GR < nt ? t + 2 * GR : t; // (the last turn reads its own taps again)
+#pragma unroll
+                  for (int k = 0; k < GR; ++k) { ra[k] = buf[2 * (tn + k)]; da[k] = buf[2 * (tn + k) + 1]; }
+#pragma unroll
+                  for (int k = 0; k < GR; ++k) MDH_IRR_FOLD(rb[k], db[k]);
+               }
+               for (; t < n_here; ++t) MDH_IRR_FOLD(buf[2 * t], buf[2 * t + 1]);
+#else
+               for (int t = 0; t < n_here; ++t) MDH_IRR_FOLD(buf[2 * t], buf[2 * t + 1]);
+#endif
+#undef MDH_IRR_FOLD
+            }
          } else if (c + 1 < nchunks) {
             const int nbase = base + CH, n_next = min(CH, ntaps - nbase), off = ((c + 1) & 1) * CH;
             for (int t = (int)threadIdx.x - 64; t < n_next; t += MDH_IRR_BLOCK - 64) MDH_IRR_STAGE(nbase + t, off + t);
