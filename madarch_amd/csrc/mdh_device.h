@@ -187,10 +187,12 @@ MDH_DEV float min0_raw(float a) { return min_(a, 0.0f); }
 #ifndef MDH_FAST_EXACT_SQRT
 #define MDH_FAST_EXACT_SQRT 0
 #endif
-MDH_DEV float sqrt_(float x)
+// The core of that expansion by itself: v_sqrt_f32, its two neighbours, two fma residuals, two selects -- the
+// compiler's own nine instructions, hence its result, for every input that it does not rescale: 0, anything from
+// 2^-96 up, infinities and NaN (for 0 both residual tests fail and the 0 of v_sqrt_f32 stands).  For callers that
+// KNOW their operand is no positive number below 2^-96.
+MDH_DEV float sqrt_unscaled_(float x)
 {
-#if MDH_FAST_EXACT_SQRT
-   if (__builtin_expect(x < 0x1p-96f && x > 0.0f, 0)) return __builtin_sqrtf(x);
    float s = __builtin_amdgcn_sqrtf(x);
    const int si = __float_as_int(s);
    const float sd = __int_as_float(si - 1), su = __int_as_float(si + 1);
@@ -198,6 +200,12 @@ MDH_DEV float sqrt_(float x)
    s = (vp <= 0.0f) ? sd : s;
    s = (vs > 0.0f) ? su : s;
    return s;
+}
+MDH_DEV float sqrt_(float x)
+{
+#if MDH_FAST_EXACT_SQRT
+   if (__builtin_expect(x < 0x1p-96f && x > 0.0f, 0)) return __builtin_sqrtf(x);
+   return sqrt_unscaled_(x);
 #else
    return __builtin_sqrtf(x);
 #endif
