@@ -24,10 +24,18 @@
 #endif
 // kernels of scenes with user-defined kinds carry the 64-register file of the MDH_X interpreter
 // (not in a hiprtc build, where the programs are plain code)
+// Mode 2 through the space partition (simple_scene: direct light + occlusion) waits for the partition's L2 round trips and
+// has no probe code: more wavefronts per SIMD hide more of them (measured at 1080p with frames in flight: 5 -> 4 416,
+// 6 -> 4 871, 7 -> 5 110 Mpixels/s; with the probe code of mode 0 the same scene LOSES at 6 and 7: ball_game 1 407 / 1 338 /
+// 1 272).
+#ifndef MDH_DIRECT_WAVES_PER_SIMD
+#define MDH_DIRECT_WAVES_PER_SIMD 7
+#endif
+#define MDH_OCC_BUILTIN(PART, MODE) (((MODE) == 2 && ((PART) & MDH_PF_PART)) ? MDH_DIRECT_WAVES_PER_SIMD : MDH_WAVES_PER_SIMD)
 #ifdef MDH_JIT
-#define MDH_OCC(PART) MDH_WAVES_PER_SIMD
+#define MDH_OCC(PART, MODE) MDH_OCC_BUILTIN(PART, MODE)
 #else
-#define MDH_OCC(PART) (((PART) & MDH_PF_CUSTOM) ? 2 : MDH_WAVES_PER_SIMD)
+#define MDH_OCC(PART, MODE) (((PART) & MDH_PF_CUSTOM) ? 2 : MDH_OCC_BUILTIN(PART, MODE))
 #endif
 // The radiance kernel is built for more wavefronts per SIMD than the screen kernel: beside two screen passes it then
 // takes less of the register file (measured with frames in flight: 5 -> 3775, 6 -> 3800, 7 -> 3830, 8 -> 3845 Mpix/s;
@@ -90,7 +98,7 @@ MDH_DEV void tile_pixel(const ScreenArgs &a, int tile, int lane, int &i, int &j,
 }
 // ALT: the variant whose second shaded point runs render_probes.glsl's other two indirect-specular bodies (modes 1 and 3)
 template <int PART, int MODE, bool GBUF, bool ALT = false>
-__global__ __launch_bounds__(MDH_BLOCK, MDH_OCC(PART)) void k_screen(KScene sc, KProbes pr, KVolumetrics vol, KCamera cam, ScreenArgs a)
+__global__ __launch_bounds__(MDH_BLOCK, MDH_OCC(PART, MODE)) void k_screen(KScene sc, KProbes pr, KVolumetrics vol, KCamera cam, ScreenArgs a)
 {
    stage_table(sc);
    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;

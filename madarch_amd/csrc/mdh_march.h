@@ -144,6 +144,10 @@ template <int PART> MDH_DEV bool march_plain(const KScene &sc, f3 o, f3 d, float
 // before the irradiance is parked
 #define MDH_PARK_SPEC 15
 #define MDH_PARK_MAT 18
+// mode 2 (direct light and occlusion only: no probes, no reflection) parks P, N, view direction, direct light and the
+// material id: 13 rows, so that eight of its workgroups fit a CU's LDS
+#define MDH_PARK_MAT_DIRECT 12
+#define MDH_DIRECT_PARK_ROWS 13
 #ifdef MDH_PHASES
 #define MDH_PARK_DWORDS 20
 #else
@@ -427,6 +431,7 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
 {
    constexpr bool P2 = (PART & MDH_PF_POW2) != 0;
    constexpr bool REFLECT = SPEC != 0;
+   constexpr int PARK_MAT = MODE == 2 ? MDH_PARK_MAT_DIRECT : MDH_PARK_MAT; // (no probe rows in mode 2: MDH_DIRECT_PARK_ROWS)
    // the second point goes through the whole of pixel_color_probes' lighting (compute_indirect_specular) ...
    const bool full2 = SPEC == 2 && cfg.spec_mode == 3;
    // ... or is only a position that the cage probes of the FIRST point light (sample_radiance_with_specular)
@@ -468,7 +473,7 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
             int pm;
             primitive_info<(PART & MDH_PF_CUSTOM) != 0>(sc, index, P, N, pm);
             if (ctx == 0) {
-               park_store1<MDH_PARK_MAT>(pk, wb, __int_as_float(pm));
+               park_store1<PARK_MAT>(pk, wb, __int_as_float(pm));
                ph.index = index; ph.t = t;
                park_store3<0>(pk, wb, P);
                park_store3<3>(pk, wb, N);
@@ -696,7 +701,7 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
                      shaded = true;
                      // the reflection ray of render_probes.glsl:262-275 finds the next point
                      // (the material id comes back from its park slot: kept in a register across the corner loop it is spilled)
-                     active = cfg.spec_mode != 0 && tab_float((sc.mat_slot + 2 * __float_as_int(park_load1<MDH_PARK_MAT>(pk, wb)) + 1) * 4) < 0.75f;
+                     active = cfg.spec_mode != 0 && tab_float((sc.mat_slot + 2 * __float_as_int(park_load1<PARK_MAT>(pk, wb)) + 1) * 4) < 0.75f;
 #ifdef MDH_ABL_NO_REFLECT
                      active = false;
 #endif
@@ -739,7 +744,7 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
          if (MODE == 0) {
             const f3 irr = park_load3<12>(pk, wb);
             const f3 specular_col = REFLECT ? park_load3<MDH_PARK_SPEC>(pk, wb) : F3(0.0f, 0.0f, 0.0f);
-            Material m = get_material(sc, __float_as_int(park_load1<MDH_PARK_MAT>(pk, wb)));
+            Material m = get_material(sc, __float_as_int(park_load1<PARK_MAT>(pk, wb)));
             const f3 specular_dir = reflect(dir, normal);
             direct = direct + compute_indirect_lighting(irr, specular_col, -dir, normal, specular_dir, m.albedo, m.metallic, m.roughness);
          }
