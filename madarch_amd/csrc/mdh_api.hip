@@ -544,9 +544,13 @@ static int commit_scene(mdh_renderer *r, hipStream_t up)
       t.push_back(mk4(f[0], f[1], f[2], f[3]));
       t.push_back(mk4(f[4], 0, 0, 0));
    }
+#if MDH_U8_FMA
+   s.u8_slot = -1; // (RGB8 texels are decoded in registers: u8_unorm, mdh_device.h)
+#else
    // k / 255 for k = 0..255: the RGB8 texel decode, one correctly rounded division each
    s.u8_slot = (int)t.size();
    for (int k = 0; k < 256; k += 4) t.push_back(mk4((float)k / 255.0f, (float)(k + 1) / 255.0f, (float)(k + 2) / 255.0f, (float)(k + 3) / 255.0f));
+#endif
    memcpy(t.data(), H, sizeof H);
    s.table_f4 = (int)t.size();
    // (the march kernels park MDH_PARK_DWORDS floats per thread behind the table, lds_bytes_march)

@@ -1100,12 +1100,21 @@ template <bool P2 = false> MDH_DEV unsigned atlas_rgba8(const void *base, unsign
    if (P2) return *(GlobalU32)((GlobalBytes)base + (idx << 2));
    return ((GlobalU32)base)[idx];
 }
+// k / 255 for a byte k, correctly rounded, without a division or a table: 1/255 = c_hi + c_lo with c_hi its nearest
+// float, and fma (k, c_hi, fl (k c_lo)) is the correctly rounded quotient for every k in 0 .. 255 (checked in exact
+// arithmetic for all 256 values: tests/test_oracle_pins.py).  Three instructions (v_cvt_f32_ubyteN takes the byte out
+// of the texel itself); the table costs a bit-field extract, an address and an LDS read per component.
+#ifndef MDH_U8_FMA
+#define MDH_U8_FMA 1
+#endif
+MDH_DEV float u8_unorm(float k) { return __builtin_fmaf(k, 0x1.010102p-8f, k * -0x1.fdfdfep-33f); }
 // u8_tab = float index of the k / 255 table in LDS (KScene::u8_slot * 4), or < 0: divide
 template <bool P2 = false> MDH_DEV f3 atlas_texel(const void *base, int fmt, unsigned idx, int u8_tab)
 {
    if (fmt == 0) {
       const unsigned t = atlas_rgba8<P2>(base, idx);
       const unsigned x = t & 255u, y = (t >> 8) & 255u, z = (t >> 16) & 255u;
+      if (MDH_U8_FMA) return F3(u8_unorm((float)x), u8_unorm((float)y), u8_unorm((float)z));
       if (u8_tab >= 0) return F3(tab_float(u8_tab + x), tab_float(u8_tab + y), tab_float(u8_tab + z));
       return F3((float)x / 255.0f, (float)y / 255.0f, (float)z / 255.0f);
    }
@@ -1164,7 +1173,14 @@ MDH_DEV AtlasTap atlas_tap_issue(const void *base, int fmt, int pcx, int pcy, in
    if (fmt == 0) { t.t00 = atlas_rgba8<P2>(base, t.t00); t.t10 = atlas_rgba8<P2>(base, t.t10); t.t01 = atlas_rgba8<P2>(base, t.t01); t.t11 = atlas_rgba8<P2>(base, t.t11); }
    return t;
 }
-MDH_DEV f3 u8_texel(unsigned t, int u8_tab) { return F3(tab_float(u8_tab + (t & 255u)), tab_float(u8_tab + ((t >> 8) & 255u)), tab_float(u8_tab + ((t >> 16) & 255u))); }
+MDH_DEV f3 u8_texel(unsigned t, int u8_tab)
+{
+#if MDH_U8_FMA
+   return F3(u8_unorm((float)(t & 255u)), u8_unorm((float)((t >> 8) & 255u)), u8_unorm((float)((t >> 16) & 255u)));
+#else
+   return F3(tab_float(u8_tab + (t & 255u)), tab_float(u8_tab + ((t >> 8) & 255u)), tab_float(u8_tab + ((t >> 16) & 255u)));
+#endif
+}
 MDH_DEV f3 atlas_tap_resolve(const void *base, int fmt, const AtlasTap &t, int u8_tab)
 {
    const float fx = t.fx, fy = t.fy;

@@ -455,3 +455,27 @@ def test_irradiance_fold_against_float64(orc):
                     acc += r_ * w
                     wsum += w
                 assert np.allclose(got[j, i], acc / wsum, rtol=2e-4, atol=1e-6), (probe, kx, ky)
+
+
+def test_byte_over_255_by_fma_is_the_correctly_rounded_quotient():
+    """The kernels decode an RGB8 texel without a division or a table (mdh_device.h: u8_unorm): 1/255 = c_hi + c_lo with c_hi
+    its nearest float, and fma (k, c_hi, fl (k c_lo)) must be fl (k / 255) -- what the oracle's division gives -- for every
+    byte k.  Checked here in exact rational arithmetic, each fp32 operation rounded once."""
+    from fractions import Fraction
+
+    def fl(x):  # an exact rational to the nearest float32, ties to even
+        c = np.float32(float(x))
+        best = None
+        for cand in (np.nextafter(c, np.float32(-np.inf)), c, np.nextafter(c, np.float32(np.inf))):
+            key = (abs(Fraction(float(cand)) - x), int(np.float32(cand).view(np.uint32)) & 1)
+            if best is None or key < best[0]:
+                best = (key, np.float32(cand))
+        return best[1]
+
+    c_hi, c_lo = np.float32(float.fromhex("0x1.010102p-8")), np.float32(float.fromhex("-0x1.fdfdfep-33"))
+    assert c_hi == fl(Fraction(1, 255)) and c_lo == fl(Fraction(1, 255) - Fraction(float(c_hi)))
+    for k in range(256):
+        want = np.float32(k) / np.float32(255.0)
+        assert want == fl(Fraction(k, 255))
+        low = fl(Fraction(k) * Fraction(float(c_lo)))
+        assert fl(Fraction(k) * Fraction(float(c_hi)) + Fraction(float(low))) == want, k
