@@ -231,7 +231,11 @@ enum {
    /* Temporal blending of the irradiance atlas -- NOT in the reference, off by default (SURVEY.md section 8f-4 lists
     * it as a deviation): the irradiance pass stores mix (fresh, previous, h) with h = value / 1000 (0 .. 999), `previous`
     * being the texel the atlas held before the pass, as stored (RGB8: its 8-bit levels).  0 = the reference. */
-   MDH_OPT_HYSTERESIS_PERMILLE = 13
+   MDH_OPT_HYSTERESIS_PERMILLE = 13,
+   /* Scheduling only, no effect on any texel: 1 (default) = the radiance pass records every probe ray's primary-march
+    * length and the next frame's pass takes the rays sorted by it (a wavefront pays the longest march among its 64
+    * rays); 0 = rays in probe order. */
+   MDH_OPT_RADIANCE_ORDER = 14
 };
 
 /* passes of Renderers.Render (madarch-renderers.adb:302-321) */

@@ -218,6 +218,15 @@ struct mdh_renderer {
    // other set while the previous frame's screen pass still reads this one, then flips.
    void *d_rad2[2] = {nullptr, nullptr}, *d_irr2[2] = {nullptr, nullptr};
    int n_cus = 0;                          // compute units of the device
+   // RadOrder (mdh_kernels.h): every ray's primary-march steps, the rays sorted by them, the sort's histograms
+   unsigned char *d_rad_steps = nullptr;
+   unsigned *d_rad_order = nullptr, *d_rad_hist = nullptr;
+   long rad_rays_cap = 0;                  // rays the three buffers are sized for
+   long rad_order_rays = 0;                // rays the stored order is of (0: none)
+   int rad_order_begin = -1;               // ... and the first probe of their slice
+   int rad_order_age = 0;                  // radiance passes since the rays were sorted
+   unsigned long rad_order_scene = 0, scene_edits = 0; // scene tables committed when they were sorted / so far
+   int opt_rad_order = MDH_RAD_ORDER_DEFAULT;
    std::map<std::pair<const void *, size_t>, int> resident; // workgroups per CU of (kernel, LDS bytes): rad_first_round
    int last = 0;
    int opt_overlap = 2;
@@ -577,6 +586,7 @@ static int commit_scene(mdh_renderer *r, hipStream_t up)
    ++r->table_version;
    r->tab_seen[stream_index(r, up)] = r->table_version;
    r->tab_slot = ns;
+   ++r->scene_edits;
    s.table = r->d_table_ring[ns];
    s.part_enable = r->part.enable;
    s.part_border = r->part.border_behavior;
@@ -669,7 +679,7 @@ extern "C" int32_t mdh_destroy(mdh_renderer *r)
    if (r->alt_stream) (void)hipStreamSynchronize(r->alt_stream);
    if (r->stream) (void)hipStreamSynchronize(r->stream);
    if (r->query_stream) (void)hipStreamSynchronize(r->query_stream);
-   void *ptrs[] = {r->d_table_ring[0], r->d_table_ring[1], r->d_table_ring[2], r->d_table_ring[3], r->d_part_ring[0], r->d_part_ring[1], r->d_part_ring[2], r->d_part_ring[3], r->d_warn, r->d_query, r->d_rad2[0], r->d_irr2[0], r->d_rad2[1], r->d_irr2[1], r->d_vis2[0], r->d_scat2[0], r->d_vis2[1], r->d_scat2[1], r->d_fb2[0], r->d_fb2[1], r->d_gb2[0][0], r->d_gb2[0][1], r->d_gb2[0][2], r->d_gb2[1][0], r->d_gb2[1][1], r->d_gb2[1][2]};
+   void *ptrs[] = {r->d_table_ring[0], r->d_table_ring[1], r->d_table_ring[2], r->d_table_ring[3], r->d_part_ring[0], r->d_part_ring[1], r->d_part_ring[2], r->d_part_ring[3], r->d_warn, r->d_query, r->d_rad_steps, r->d_rad_order, r->d_rad_hist, r->d_rad2[0], r->d_irr2[0], r->d_rad2[1], r->d_irr2[1], r->d_vis2[0], r->d_scat2[0], r->d_vis2[1], r->d_scat2[1], r->d_fb2[0], r->d_fb2[1], r->d_gb2[0][0], r->d_gb2[0][1], r->d_gb2[0][2], r->d_gb2[1][0], r->d_gb2[1][1], r->d_gb2[1][2]};
    for (void *p : ptrs)
       if (p) (void)hipFree(p);
    for (auto &p : r->pending) { (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1); }
@@ -859,6 +869,7 @@ extern "C" int32_t mdh_set_option(mdh_renderer *r, int32_t option, int32_t value
    case MDH_OPT_FRAME_OVERLAP: if (value < 0 || value > 2) return seterr(MDH_E_INVALID, "frame overlap is 0, 1 or 2"); r->opt_overlap = value; break;
    case MDH_OPT_INDIRECT_SPECULAR: if (value < 0 || value > 3) return seterr(MDH_E_INVALID, "indirect specular mode is 0 .. 3"); r->opt_spec = value; break;
    case MDH_OPT_HYSTERESIS_PERMILLE: if (value < 0 || value > 999) return seterr(MDH_E_INVALID, "hysteresis is 0 .. 999 per mille"); r->opt_hyst = value; break;
+   case MDH_OPT_RADIANCE_ORDER: r->opt_rad_order = value ? 1 : 0; r->rad_order_rays = 0; break;
    default: return seterr(MDH_E_INVALID, "unknown option");
    }
    return MDH_OK;
@@ -881,6 +892,7 @@ extern "C" int32_t mdh_get_option(mdh_renderer *r, int32_t option, int32_t *valu
    case MDH_OPT_WINDOW: *value = r->opt_window; break;
    case MDH_OPT_INDIRECT_SPECULAR: *value = r->opt_spec; break;
    case MDH_OPT_HYSTERESIS_PERMILLE: *value = r->opt_hyst; break;
+   case MDH_OPT_RADIANCE_ORDER: *value = r->opt_rad_order; break;
    default: return seterr(MDH_E_INVALID, "unknown option");
    }
    return MDH_OK;
@@ -1169,6 +1181,9 @@ static JitModule *jit_module(mdh_renderer *r, const std::vector<std::string> &ex
 }
 // The workgroups of the radiance pass the chip holds at once, when the launch is that and a remainder smaller than
 // it (k_radiance, mdh_kernels.h: the remainder runs at a raised issue priority); 0 otherwise.
+#ifndef MDH_RAD_RESORT
+#define MDH_RAD_RESORT 64
+#endif
 #ifndef MDH_RAD_TAIL_PRIO
 #define MDH_RAD_TAIL_PRIO 1
 #endif
@@ -1377,14 +1392,39 @@ static int run_pass(mdh_renderer *r, int pass, hipStream_t st, int src, int dst,
          if (pr.rres % T == 0) n = (long)((pr.probe_end - pr.probe_begin + G - 1) / G) * G * pr.rres * pr.rres;
       }
       if (n > 0) {
+         // the rays in the order of the previous pass's primary-march lengths (RadOrder, mdh_kernels.h)
+         const long rays = (long)(pr.probe_end - pr.probe_begin) * pr.rres * pr.rres;
+         RadOrder ro = {nullptr, nullptr, (int)rays};
+         // (chunks of whole workgroup strides, at most MDH_RO_MAX_CHUNKS of them)
+         const long ro_chunk = std::max(2048l, ((rays + MDH_RO_MAX_CHUNKS - 1) / MDH_RO_MAX_CHUNKS + 1023) / 1024 * 1024);
+         const int ro_chunks = (int)((rays + ro_chunk - 1) / ro_chunk);
+         if (r->opt_rad_order && rays >= 8192 && rays < (1l << 31)) {
+            if (rays > r->rad_rays_cap) {
+               HIP_TRY(hipDeviceSynchronize());
+               for (void *q : {(void *)r->d_rad_steps, (void *)r->d_rad_order, (void *)r->d_rad_hist})
+                  if (q) HIP_TRY(hipFree(q));
+               r->d_rad_steps = nullptr; r->d_rad_order = r->d_rad_hist = nullptr;
+               HIP_TRY(hipMalloc(&r->d_rad_steps, rays));
+               HIP_TRY(hipMalloc(&r->d_rad_order, rays * sizeof(unsigned)));
+               HIP_TRY(hipMalloc(&r->d_rad_hist, 256 * MDH_RO_MAX_CHUNKS * sizeof(unsigned)));
+               r->rad_rays_cap = rays;
+               r->rad_order_rays = 0;
+            }
+            const bool have = r->rad_order_rays == rays && r->rad_order_begin == pr.probe_begin;
+            if (have) { ro.order = r->d_rad_order; n = rays; }
+            // A probe ray's march changes with the scene, not with time: the rays are sorted again after an edit of the scene
+            // (a moved sphere; a light does not change the marches) and every MDH_RAD_RESORT passes besides, which keeps
+            // the three sort kernels (~10 us) out of almost every frame.  A stale order costs speed only.
+            if (!have || r->rad_order_scene != r->scene_edits || ++r->rad_order_age >= MDH_RAD_RESORT) ro.steps = r->d_rad_steps;
+         }
          int blocks = (int)((n + MDH_BLOCK - 1) / MDH_BLOCK);
          const size_t lds = lds_bytes_march(r);
          if (jit) {
-            struct { KScene sc; KProbes pr; int first_round; } args = {r->ks, pr, rad_first_round(r, nullptr, jm->fn[kname], lds, blocks)};
+            struct { KScene sc; KProbes pr; int first_round; RadOrder ro; } args = {r->ks, pr, rad_first_round(r, nullptr, jm->fn[kname], lds, blocks), ro};
             int rc = jit_launch(jm->fn[kname], blocks, MDH_BLOCK, lds, st, args);
             if (rc != MDH_OK) return rc;
          } else {
-#define MDH_LAUNCH_RAD(K) hipLaunchKernelGGL(K, dim3(blocks), dim3(MDH_BLOCK), lds, st, r->ks, pr, rad_first_round(r, (const void *)K, nullptr, lds, blocks))
+#define MDH_LAUNCH_RAD(K) hipLaunchKernelGGL(K, dim3(blocks), dim3(MDH_BLOCK), lds, st, r->ks, pr, rad_first_round(r, (const void *)K, nullptr, lds, blocks), ro)
             if (pow2 && !has_custom) {
                if (pf & MDH_PF_PART) MDH_LAUNCH_RAD(k_radiance<MDH_PF_PART | MDH_PF_POW2>);
                else MDH_LAUNCH_RAD(k_radiance<MDH_PF_POW2>);
@@ -1397,6 +1437,16 @@ static int run_pass(mdh_renderer *r, int pass, hipStream_t st, int src, int dst,
                }
 #undef MDH_LAUNCH_RAD
          }
+         if (ro.steps) { // the next pass's order from this pass's step counts
+            hipLaunchKernelGGL(k_rad_hist, dim3(ro_chunks), dim3(256), 0, st, (const unsigned char *)r->d_rad_steps, (int)rays, (int)ro_chunk, r->d_rad_hist);
+            hipLaunchKernelGGL(k_rad_scan, dim3(1), dim3(256), 0, st, r->d_rad_hist, ro_chunks);
+            hipLaunchKernelGGL(k_rad_scatter, dim3(ro_chunks), dim3(256), 0, st, (const unsigned char *)r->d_rad_steps, (int)rays, (int)ro_chunk, (const unsigned *)r->d_rad_hist, r->d_rad_order);
+            r->rad_order_rays = rays;
+            r->rad_order_begin = pr.probe_begin;
+            r->rad_order_age = 0;
+            r->rad_order_scene = r->scene_edits;
+         } else if (!ro.order)
+            r->rad_order_rays = 0;
       }
       break;
    }

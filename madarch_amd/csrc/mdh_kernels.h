@@ -186,13 +186,22 @@ __global__ __launch_bounds__(MDH_BLOCK, MDH_OCC(PART, MODE)) void k_screen(KScen
 // ---------------------------------------------------------------------- radiance pass
 // compute_probe_radiance.glsl:16-27.  One lane per radiance texel (one probe ray); a wavefront = the same
 // octahedral texel of MDH_RAD_PROBES_PER_WAVE = 64 consecutive probes (64 parallel rays from 64 origins).
+#ifndef MDH_RAD_ORDER_DEFAULT
+#define MDH_RAD_ORDER_DEFAULT 1 // MDH_OPT_RADIANCE_ORDER's initial value
+#endif
+struct RadOrder {
+   const unsigned *order; // [n_rays] ray at every place, or nullptr: rays in probe order
+   unsigned char *steps;  // [n_rays] primary-march steps of every ray (capped at 255), written by the pass; or nullptr
+   int n_rays;
+};
 // `first_round`: the workgroups the chip holds at once (0: not told).  The pass is ONE round of wavefronts and a
 // remainder -- 8 192 wavefronts on 7 168 slots at the headline size -- and ends with its slowest wavefront.  A SIMD
 // issues from its OLDEST wavefront first (measured: within the first round a wavefront's duration follows its launch
 // position, 36 us for the first eighth to 88 us for the seventh, whichever probes it holds), so the remainder, which
 // starts 35-65 us late in slots between six older wavefronts, would finish last by far: it raises its issue priority
 // instead and runs at the speed of a wavefront alone (radiance pass 0.165 -> 0.147 ms).
-template <int PART> __global__ __launch_bounds__(MDH_BLOCK, MDH_OCC_RAD(PART)) void k_radiance(KScene sc, KProbes pr, int first_round)
+// `ro`: the rays of the pass in the order of the PREVIOUS pass's primary-march lengths (RadOrder below), or no order.
+template <int PART> __global__ __launch_bounds__(MDH_BLOCK, MDH_OCC_RAD(PART)) void k_radiance(KScene sc, KProbes pr, int first_round, RadOrder ro)
 {
    if (first_round > 0 && (int)blockIdx.x >= first_round) __builtin_amdgcn_s_setprio(3);
    stage_table(sc);
@@ -204,6 +213,19 @@ template <int PART> __global__ __launch_bounds__(MDH_BLOCK, MDH_OCC_RAD(PART)) v
    const int lane = (int)(lin & 63);
    const long wave_global = lin >> 6;
    int x, y, probe_raw;
+   if (ro.order) { // lane = the ray at this place of the order (a ray: probe of the slice * texels + texel)
+      const unsigned ray = lin < ro.n_rays ? ro.order[lin] : 0xffffffffu;
+      if (pr.rshift >= 0) {
+         probe_raw = ray == 0xffffffffu ? pr.probe_end : pr.probe_begin + (int)(ray >> (2 * pr.rshift));
+         y = (int)(ray >> pr.rshift) & (pr.rres - 1);
+         x = (int)ray & (pr.rres - 1);
+      } else {
+         probe_raw = ray == 0xffffffffu ? pr.probe_end : pr.probe_begin + (int)(ray / (unsigned)per_probe);
+         const int rem = (int)(ray % (unsigned)per_probe);
+         y = rem / pr.rres;
+         x = rem - y * pr.rres;
+      }
+   } else
    if ((pr.rres % T) == 0) {
       const int tpr = pr.rres / T, tiles = tpr * tpr;      // texel tiles per probe
       const int group = (int)(wave_global / tiles), tile = (int)(wave_global % tiles);
@@ -237,7 +259,78 @@ template <int PART> __global__ __launch_bounds__(MDH_BLOCK, MDH_OCC_RAD(PART)) v
    f3 pos;
    f3 c = MDH_SHADE<PART, 0, 0, MDH_RAD_QVIS != 0>(sc, pr, cfg, valid, world, ray_dir, ph, hit, pos);
    if (valid) atlas_store(pr.rad, pr.fmt, atlas_index(pr.pcx, pr.rres, pr.rshift, i, j), c);
+   if (valid && ro.steps) ro.steps[(size_t)(probe_raw - pr.probe_begin) * per_probe + y * pr.rres + x] = (unsigned char)min(ph.steps, 255);
    PH_KERNEL_END();
+}
+
+// ---- Rays in the order of their primary-march lengths.  In lock step a wavefront pays the LONGEST primary march
+// among its 64 rays: 20 of 64 lanes are alive in an average step of that march, which is 60 % of the pass's SDF
+// evaluations.  A probe ray's march hardly changes from frame to frame (the probes do not move): every pass leaves each
+// ray's step count behind, three small kernels sort the rays by it -- a counting sort, longest first -- and the next pass
+// takes its rays in that order, so that the rays of a wavefront end their marches together.  Which lane computes a
+// texel changes, never what it holds.
+//   k_rad_hist:    per chunk of rays (at most MDH_RO_MAX_CHUNKS chunks) a histogram of the 256 keys -> hist[chunk][key]
+//   k_rad_scan:    exclusive prefix over keys (descending) and chunks -> the first place of every (key, chunk)
+//   k_rad_scatter: the chunk's rays to their places
+#define MDH_RO_MAX_CHUNKS 128 // (the scan keeps a key's counts of all chunks in registers)
+// hist is [chunk][key]: every access below is 256 consecutive words
+__global__ __launch_bounds__(256) void k_rad_hist(const unsigned char *steps, int n, int chunk, unsigned *hist)
+{
+   __shared__ unsigned h[256];
+   h[threadIdx.x] = 0u;
+   __syncthreads();
+   const int base = blockIdx.x * chunk; // (chunk is a multiple of 1 024: four rays per thread and turn)
+   for (int i = 4 * threadIdx.x; i < chunk; i += 1024) {
+      if (base + i + 3 < n) {
+         const unsigned w = *(const unsigned *)(steps + base + i);
+         atomicAdd(&h[w & 255u], 1u); atomicAdd(&h[(w >> 8) & 255u], 1u); atomicAdd(&h[(w >> 16) & 255u], 1u); atomicAdd(&h[w >> 24], 1u);
+      } else
+         for (int q = 0; q < 4; ++q)
+            if (base + i + q < n) atomicAdd(&h[steps[base + i + q]], 1u);
+   }
+   __syncthreads();
+   hist[blockIdx.x * 256 + threadIdx.x] = h[threadIdx.x];
+}
+__global__ __launch_bounds__(256) void k_rad_scan(unsigned *hist, int chunks) // one workgroup; thread = key
+{
+   __shared__ unsigned after[256];
+   unsigned v[MDH_RO_MAX_CHUNKS];
+#pragma unroll
+   for (int c = 0; c < MDH_RO_MAX_CHUNKS; ++c) v[c] = c < chunks ? hist[c * 256 + threadIdx.x] : 0u; // (all loads in flight together)
+   unsigned sum = 0u;
+#pragma unroll
+   for (int c = 0; c < MDH_RO_MAX_CHUNKS; ++c) { const unsigned x = v[c]; v[c] = sum; sum += x; }
+   // rays with a larger key come first: the sum of the totals of the keys above this one (a suffix scan in LDS)
+   after[threadIdx.x] = sum;
+   __syncthreads();
+   for (int d = 1; d < 256; d <<= 1) {
+      const unsigned add = (int)threadIdx.x + d < 256 ? after[threadIdx.x + d] : 0u;
+      __syncthreads();
+      after[threadIdx.x] += add;
+      __syncthreads();
+   }
+   const unsigned before = after[threadIdx.x] - sum;
+#pragma unroll
+   for (int c = 0; c < MDH_RO_MAX_CHUNKS; ++c)
+      if (c < chunks) hist[c * 256 + threadIdx.x] = v[c] + before;
+}
+__global__ __launch_bounds__(256) void k_rad_scatter(const unsigned char *steps, int n, int chunk, const unsigned *hist, unsigned *order)
+{
+   __shared__ unsigned place[256];
+   place[threadIdx.x] = hist[blockIdx.x * 256 + threadIdx.x];
+   __syncthreads();
+   const int base = blockIdx.x * chunk;
+   for (int i = 4 * threadIdx.x; i < chunk; i += 1024) {
+      if (base + i + 3 < n) {
+         const unsigned w = *(const unsigned *)(steps + base + i);
+         order[atomicAdd(&place[w & 255u], 1u)] = (unsigned)(base + i);
+         order[atomicAdd(&place[(w >> 8) & 255u], 1u)] = (unsigned)(base + i + 1);
+         order[atomicAdd(&place[(w >> 16) & 255u], 1u)] = (unsigned)(base + i + 2);
+         order[atomicAdd(&place[w >> 24], 1u)] = (unsigned)(base + i + 3);
+      } else
+         for (int q = 0; q < 4; ++q)
+            if (base + i + q < n) order[atomicAdd(&place[steps[base + i + q]], 1u)] = (unsigned)(base + i + q);
+   }
 }
 
 // -------------------------------------------------------------------- irradiance pass

@@ -1436,6 +1436,7 @@ int32_t orc_set_option(orc_renderer *r, int32_t option, int32_t value)
       if (value < 0 || value > 999) return seterr(MDH_E_INVALID, "hysteresis is 0 .. 999 per mille");
       r->opt_hyst = value;
       break;
+   case MDH_OPT_RADIANCE_ORDER: break; /* which lane computes a texel, not what it holds: nothing to restate */
    case ORC_OPT_SDF_MODE: r->opt_sdf_mode = value; break;
    case ORC_OPT_THREADS: r->opt_threads = value; break;
    default: return seterr(MDH_E_INVALID, "unknown option");
@@ -1460,6 +1461,7 @@ int32_t orc_get_option(orc_renderer *r, int32_t option, int32_t *value)
    case MDH_OPT_WINDOW: *value = r->opt_window; break;
    case MDH_OPT_INDIRECT_SPECULAR: *value = r->opt_spec; break;
    case MDH_OPT_HYSTERESIS_PERMILLE: *value = r->opt_hyst; break;
+   case MDH_OPT_RADIANCE_ORDER: *value = 0; break;
    case ORC_OPT_SDF_MODE: *value = r->opt_sdf_mode; break;
    case ORC_OPT_THREADS: *value = nthreads(r); break;
    default: return seterr(MDH_E_INVALID, "unknown option");

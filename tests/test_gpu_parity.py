@@ -579,3 +579,33 @@ def test_hysteresis_blends_with_the_previous_frames_irradiance(hip, orc, atlas, 
     assert outs[0]["irradiance"].mean() < plain["irradiance"].mean()
     with pytest.raises(B.MadarchError):
         make("global_illumination", 16, 8, hip).Set_Option(B.OPT_HYSTERESIS_PERMILLE, 1000)
+
+
+MANY_PROBES = renderers.Probe_Settings(Radiance_Resolution=8, Irradiance_Resolution=4, Probe_Count=(80, 64), Grid_Dimensions=(16, 16, 20),
+                                       Grid_Spacing=(0.45, 0.35, 0.5))
+
+
+@pytest.mark.parametrize("probes,world", [(examples.GI_8X8X8_PROBES, 1), (ODD_PROBES, 1), (MANY_PROBES, 1), (examples.GI_8X8X8_PROBES, 2)])
+def test_radiance_ray_order_changes_no_texel(hip, probes, world):
+    """MDH_OPT_RADIANCE_ORDER: from the second frame on the radiance pass takes its rays sorted by the previous frame's
+    primary-march lengths (power-of-two and other tile sizes, a rank's slice, a light that moves between frames so that
+    the order is stale): WHICH lane computes a texel, never what it holds -- atlases and image are the bits of the pass
+    in probe order, frame after frame."""
+    from madarch_amd.lights import spot_lights
+    outs = []
+    for order in (1, 0):
+        R = make("global_illumination", 64, 40, hip, probes=probes)
+        assert R.Get_Option(B.OPT_RADIANCE_ORDER) == 1
+        R.Set_Option(B.OPT_RADIANCE_ORDER, order)
+        if world > 1:
+            R.Set_Option(B.OPT_WORLD, world)
+            R.Set_Option(B.OPT_RANK, 1)
+        frames = []
+        for f in range(4):
+            if f == 2:
+                R.Set_Light(1, spot_lights.Spot_Light, spot_lights.Create((3.5, 5.0, 2.0), (-1.0, 0.0, 0.0), 3.1415 / 4.0, (0.9, 0.9, 0.8)))
+            frames.append(snapshot(R, 1))
+        outs.append(frames)
+    for a, b in zip(*outs):
+        for key in ("radiance", "irradiance", "image"):
+            assert same_bits(a[key], b[key]), key
