@@ -189,9 +189,17 @@ __global__ __launch_bounds__(MDH_BLOCK, MDH_OCC(PART, MODE)) void k_screen(KScen
 #ifndef MDH_RAD_ORDER_DEFAULT
 #define MDH_RAD_ORDER_DEFAULT 1 // MDH_OPT_RADIANCE_ORDER's initial value
 #endif
+// a step count on a scale of 16 levels: 0 .. 7 as they are, then 8-11, 12-15, 16-23, 24-31, 32-47, 48-63, 64-95, 96 and more
+// (rays of one level differ by a third at most; the two levels of a ray are one byte, one pass of the counting sort)
+MDH_DEV int rad_level(int steps)
+{
+   if (steps < 8) return steps;
+   const int l = 31 - __builtin_clz((unsigned)steps); // 3 for 8-15, 4 for 16-31 ...
+   return min(15, 8 + 2 * (l - 3) + ((steps >> (l - 1)) & 1));
+}
 struct RadOrder {
    const unsigned *order; // [n_rays] ray at every place, or nullptr: rays in probe order
-   unsigned char *steps;  // [n_rays] primary-march steps of every ray (capped at 255), written by the pass; or nullptr
+   unsigned char *steps;  // [n_rays] every ray's sort key (rad_level of its primary-march and shadow steps), written by the pass; or nullptr
    int n_rays;
 };
 // `first_round`: the workgroups the chip holds at once (0: not told).  The pass is ONE round of wavefronts and a
@@ -259,7 +267,8 @@ template <int PART> __global__ __launch_bounds__(MDH_BLOCK, MDH_OCC_RAD(PART)) v
    f3 pos;
    f3 c = MDH_SHADE<PART, 0, 0, MDH_RAD_QVIS != 0>(sc, pr, cfg, valid, world, ray_dir, ph, hit, pos);
    if (valid) atlas_store(pr.rad, pr.fmt, atlas_index(pr.pcx, pr.rres, pr.rshift, i, j), c);
-   if (valid && ro.steps) ro.steps[(size_t)(probe_raw - pr.probe_begin) * per_probe + y * pr.rres + x] = (unsigned char)min(ph.steps, 255);
+   if (valid && ro.steps) // the ray's sort key: the levels of its primary-march and soft-shadow step counts
+      ro.steps[(size_t)(probe_raw - pr.probe_begin) * per_probe + y * pr.rres + x] = (unsigned char)((rad_level(ph.steps & 0xffff) << 4) | rad_level(ph.steps >> 16));
    PH_KERNEL_END();
 }
 

@@ -261,6 +261,9 @@ template <int SLOT> MDH_DEV float park_load1(const float *pk, int wb)
 // LDS: entries are u16 in park slots 12..15 of the wave (free until the irradiance is parked),
 // slot 16 = first-step distance, slot 17 = visibility word.
 // ---------------------------------------------------------------------------------------------
+#ifndef MDH_QVIS_FAR_FIRST
+#define MDH_QVIS_FAR_FIRST 1
+#endif
 #ifndef MDH_QVIS_REFILL
 #define MDH_QVIS_REFILL 16 // idle lanes that trigger a refill
 #endif
@@ -276,8 +279,19 @@ MDH_DEV int queued_visibility(const KScene &sc, const KProbes &pr, float *pk, f3
    pk[16 * MDH_BLOCK + threadIdx.x] = sd0;
    words[threadIdx.x] = 0;
    int bits = 0, njobs = 0;
+   // The queue is taken from its head: every lane lists its FARTHEST cage corner first (the far side of each axis: the
+   // corner j ^ far for j = 0 .. 7 goes from the farthest to the nearest), so that the longest rays of the wave start first
+   // and its last rays are short ones -- the queue drains with fewer idle lanes.  The order of the list decides nothing else.
+   int far = 0;
+#if MDH_QVIS_FAR_FIRST
+   {
+      const f3 lo = grid_to_world(pr, gp);
+      far = ((P.x - lo.x) < (lo.x + pr.sx - P.x) ? 1 : 0) | ((P.y - lo.y) < (lo.y + pr.sy - P.y) ? 2 : 0) | ((P.z - lo.z) < (lo.z + pr.sz - P.z) ? 4 : 0);
+   }
+#endif
 #pragma unroll 1
-   for (int i = 0; i < 8; ++i) {
+   for (int j = 0; j < 8; ++j) {
+      const int i = j ^ far;
       bool need = false;
       if (!(i & folded)) {
          const f3 hvec = grid_to_world(pr, cage_probe(pr, gp, i)) - P;
@@ -515,6 +529,7 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
                         bool first = MDH_SHARE_FIRST_STEP != 0;
                         while (total < L_dist) {
                            MDH_DIAG_STEP(1 + ctx);
+                           if (SPEC == 0) ph.steps += 1 << 16; // (the radiance pass's sort key: shadow steps above the primary ones)
                            float dist = first ? sd0 : sdf<PART>(sc, from_off + L * total);
                            first = false;
                            if (dist < MDH_EPS) { blocked = true; break; }
