@@ -339,7 +339,11 @@ MDH_DEV int queued_visibility(const KScene &sc, const KProbes &pr, float *pk, f3
       }
       if (__ballot(job >= 0) == 0ull) break;
       if (job >= 0) {
+#ifdef MDH_DIAG_DRAIN
+         if (head < njobs) { MDH_DIAG_STEP(3); } else { MDH_DIAG_STEP(4); }
+#else
          MDH_DIAG_STEP(3);
+#endif
          const float sd = sdf<PART>(sc, o + d * total);
          if (sd < MDH_EPS) job = -1; // blocked: the bit stays 0
          else {
