@@ -375,7 +375,8 @@ def main():
             "config": {"workload": args.workload, "scene": scene, "width": W, "height": H,
                        "probe_grid": "8x8x8" if probes == "gi8" else "4x3x3", "atlas": args.atlas,
                        "screen_mode": mode, "parallelism": "tiles+probes/%d" % world + (" (RCCL rehearsal)" if args.rehearse_rccl else ""),
-                       "frame_overlap": overlap, "animated_light": bool(animate), "swap_buffers": bool(args.swap_buffers)},
+                       "frame_overlap": overlap, "animated_light": bool(animate), "swap_buffers": bool(args.swap_buffers),
+                       "radiance_order": int(R.Get_Option(B.OPT_RADIANCE_ORDER))},
             "roofline": {"bound": "hbm", "kernel": "k_screen", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": int(alg_bytes), "bytes_per_pixel": per_px,
