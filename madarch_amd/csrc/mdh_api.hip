@@ -225,7 +225,7 @@ struct mdh_renderer {
    long rad_order_rays = 0;                // rays the stored order is of (0: none)
    int rad_order_begin = -1;               // ... and the first probe of their slice
    int rad_order_age = 0;                  // radiance passes since the rays were sorted
-   unsigned long rad_order_scene = 0, scene_edits = 0; // scene tables committed when they were sorted / so far
+   unsigned long rad_order_scene = 0, geometry_edits = 0; // primitives set or added when the rays were sorted / so far
    int opt_rad_order = MDH_RAD_ORDER_DEFAULT;
    std::map<std::pair<const void *, size_t>, int> resident; // workgroups per CU of (kernel, LDS bytes): rad_first_round
    int last = 0;
@@ -586,7 +586,6 @@ static int commit_scene(mdh_renderer *r, hipStream_t up)
    ++r->table_version;
    r->tab_seen[stream_index(r, up)] = r->table_version;
    r->tab_slot = ns;
-   ++r->scene_edits;
    s.table = r->d_table_ring[ns];
    s.part_enable = r->part.enable;
    s.part_border = r->part.border_behavior;
@@ -934,6 +933,7 @@ extern "C" int32_t mdh_set_primitive(mdh_renderer *r, int32_t kind_ix, int32_t i
 {
    if (!r || kind_ix < 0 || kind_ix >= r->npk) return seterr(MDH_E_INVALID, "bad kind index");
    if (index1 < 1 || index1 > r->host_count[kind_ix]) return seterr(MDH_E_INDEX, "index past the primitives added");
+   ++r->geometry_edits;
    return write_entity(r, r->pk[kind_ix], index1, blob, nbytes);
 }
 // Add_Primitive (renderers.adb:435-456)
@@ -941,6 +941,7 @@ extern "C" int32_t mdh_add_primitive(mdh_renderer *r, int32_t kind_ix, const voi
 {
    if (!r || kind_ix < 0 || kind_ix >= r->npk) return seterr(MDH_E_INVALID, "bad kind index");
    int count = r->host_count[kind_ix] + 1;
+   ++r->geometry_edits;
    int rc = write_entity(r, r->pk[kind_ix], count, blob, nbytes);
    if (rc != MDH_OK) return rc;
    r->host_count[kind_ix] = count;
@@ -1184,6 +1185,9 @@ static JitModule *jit_module(mdh_renderer *r, const std::vector<std::string> &ex
 #ifndef MDH_RAD_RESORT
 #define MDH_RAD_RESORT 64
 #endif
+#ifndef MDH_RAD_RESORT_MOVING
+#define MDH_RAD_RESORT_MOVING 8
+#endif
 #ifndef MDH_RAD_TAIL_PRIO
 #define MDH_RAD_TAIL_PRIO 1
 #endif
@@ -1412,10 +1416,12 @@ static int run_pass(mdh_renderer *r, int pass, hipStream_t st, int src, int dst,
             }
             const bool have = r->rad_order_rays == rays && r->rad_order_begin == pr.probe_begin;
             if (have) { ro.order = r->d_rad_order; n = rays; }
-            // A probe ray's march changes with the scene, not with time: the rays are sorted again after an edit of the scene
-            // (a moved sphere; a light does not change the marches) and every MDH_RAD_RESORT passes besides, which keeps
-            // the three sort kernels (~10 us) out of almost every frame.  A stale order costs speed only.
-            if (!have || r->rad_order_scene != r->scene_edits || ++r->rad_order_age >= MDH_RAD_RESORT) ro.steps = r->d_rad_steps;
+            // A probe ray's march changes with the scene's geometry, not with time, lights or materials: the rays are sorted
+            // again when primitives were set or added since (at most every MDH_RAD_RESORT_MOVING passes: a stale order costs
+            // speed only, and three more launches per frame cost the host of a 0.4 ms frame 10 %) and every MDH_RAD_RESORT
+            // passes besides -- the sort kernels (20 us) are out of almost every frame.
+            ++r->rad_order_age;
+            if (!have || r->rad_order_age >= MDH_RAD_RESORT || (r->rad_order_scene != r->geometry_edits && r->rad_order_age >= MDH_RAD_RESORT_MOVING)) ro.steps = r->d_rad_steps;
          }
          int blocks = (int)((n + MDH_BLOCK - 1) / MDH_BLOCK);
          const size_t lds = lds_bytes_march(r);
@@ -1444,7 +1450,7 @@ static int run_pass(mdh_renderer *r, int pass, hipStream_t st, int src, int dst,
             r->rad_order_rays = rays;
             r->rad_order_begin = pr.probe_begin;
             r->rad_order_age = 0;
-            r->rad_order_scene = r->scene_edits;
+            r->rad_order_scene = r->geometry_edits;
          } else if (!ro.order)
             r->rad_order_rays = 0;
       }
