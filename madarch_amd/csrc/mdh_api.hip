@@ -236,6 +236,7 @@ struct mdh_renderer {
    hipStream_t probe_stream = nullptr;   // radiance + irradiance passes of pipelined frames
    hipStream_t alt_stream = nullptr;     // screen pass of every other pipelined frame
    hipEvent_t ev_screen[2] = {nullptr, nullptr}, ev_probe[2] = {nullptr, nullptr}, ev_join = nullptr, ev_join_alt = nullptr;
+   hipEvent_t ev_vol[2] = {nullptr, nullptr}; // the camera-only volumetric passes of a pipelined frame (on the query stream, beside its probe passes)
    bool ev_screen_valid[2] = {false, false};
    bool alt_pending = false; // work on alt_stream that `stream` has not been ordered after yet
    // an open frame (mdh_frame_begin .. mdh_frame_end)
@@ -683,7 +684,7 @@ extern "C" int32_t mdh_destroy(mdh_renderer *r)
       if (p) (void)hipFree(p);
    for (auto &p : r->pending) { (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1); }
    for (auto e : r->free_events) (void)hipEventDestroy(e);
-   for (hipEvent_t e : {r->ev_screen[0], r->ev_screen[1], r->ev_probe[0], r->ev_probe[1], r->ev_join, r->ev_join_alt, r->ev_table})
+   for (hipEvent_t e : {r->ev_screen[0], r->ev_screen[1], r->ev_probe[0], r->ev_probe[1], r->ev_vol[0], r->ev_vol[1], r->ev_join, r->ev_join_alt, r->ev_table})
       if (e) (void)hipEventDestroy(e);
    for (int q = 0; q < mdh_renderer::TAB_RING; ++q) {
       if (r->h_table_ring[q]) (void)hipHostFree(r->h_table_ring[q]);
@@ -792,7 +793,7 @@ extern "C" int32_t mdh_create(int32_t width, int32_t height, const mdh_scene_des
       prio = prio < 0 ? hi : (prio > 0 ? lo : 0);
       TRY_OR_FAIL(hipStreamCreateWithPriority(&r->probe_stream, hipStreamNonBlocking, prio));
       TRY_OR_FAIL(hipStreamCreateWithFlags(&r->alt_stream, hipStreamNonBlocking));
-      for (hipEvent_t *e : {&r->ev_screen[0], &r->ev_screen[1], &r->ev_probe[0], &r->ev_probe[1], &r->ev_join, &r->ev_join_alt, &r->ev_table}) TRY_OR_FAIL(hipEventCreateWithFlags(e, hipEventDisableTiming));
+      for (hipEvent_t *e : {&r->ev_screen[0], &r->ev_screen[1], &r->ev_probe[0], &r->ev_probe[1], &r->ev_vol[0], &r->ev_vol[1], &r->ev_join, &r->ev_join_alt, &r->ev_table}) TRY_OR_FAIL(hipEventCreateWithFlags(e, hipEventDisableTiming));
       TRY_OR_FAIL(hipStreamCreateWithFlags(&r->query_stream, hipStreamNonBlocking));
       for (hipEvent_t *e : {&r->ev_part, &r->ev_warn}) TRY_OR_FAIL(hipEventCreateWithFlags(e, hipEventDisableTiming));
       for (int q = 0; q < mdh_renderer::TAB_RING; ++q)
@@ -1605,9 +1606,11 @@ extern "C" int32_t mdh_frame_begin(mdh_renderer *r)
          HIP_TRY(hipEventRecord(r->ev_join, r->stream));
          HIP_TRY(hipStreamWaitEvent(r->probe_stream, r->ev_join, 0));
          HIP_TRY(hipStreamWaitEvent(r->alt_stream, r->ev_join, 0));
+         HIP_TRY(hipStreamWaitEvent(r->query_stream, r->ev_join, 0)); // (the volumetric passes of pipelined frames: frame_end_passes)
          r->main_dirty = false;
       } else if (r->opt_mode == 0 && r->ev_screen_valid[cur]) { // the last screen pass that read atlas set cur
          HIP_TRY(hipStreamWaitEvent(r->probe_stream, r->ev_screen[cur], 0));
+         if (r->vol.enabled) HIP_TRY(hipStreamWaitEvent(r->query_stream, r->ev_screen[cur], 0)); // (it read the froxels of set cur as well)
       }
       r->frame_cur = cur;
    }
@@ -1621,6 +1624,7 @@ static int abandon_frame(mdh_renderer *r, int rc)
    r->in_frame = false;
    r->main_dirty = true;
    if (r->probe_stream) (void)hipStreamSynchronize(r->probe_stream);
+   if (r->query_stream) (void)hipStreamSynchronize(r->query_stream);
    return rc;
 }
 extern "C" int32_t mdh_frame_probe_pass(mdh_renderer *r, int32_t pass)
@@ -1631,6 +1635,9 @@ extern "C" int32_t mdh_frame_probe_pass(mdh_renderer *r, int32_t pass)
    if (r->opt_mode != 0) return MDH_OK; // modes 1 and 2 draw without probes (renderers.adb:302-321 runs them anyway; nothing reads them)
    return run_pass(r, pass, frame_probe_stream(r), r->last, r->frame_cur);
 }
+#ifndef MDH_VOL_OWN_STREAM
+#define MDH_VOL_OWN_STREAM 1
+#endif
 static int frame_end_passes(mdh_renderer *r);
 extern "C" int32_t mdh_frame_end(mdh_renderer *r)
 {
@@ -1659,9 +1666,16 @@ static int frame_end_passes(mdh_renderer *r)
    r->scr_parity = dual ? r->scr_parity ^ 1 : 0;
    hipStream_t screen_stream = r->scr_parity ? r->alt_stream : r->stream;
    const int fbix = r->scr_parity;
-   if (r->opt_mode == 0 && r->vol.enabled) { // camera-only passes into this frame's set, beside the previous screen pass
-      if ((rc = run_pass(r, MDH_PASS_VISIBILITY, r->probe_stream, cur, cur)) != MDH_OK) return rc;
-      if ((rc = run_pass(r, MDH_PASS_SCATTERING, r->probe_stream, cur, cur)) != MDH_OK) return rc;
+   if (r->opt_mode == 0 && r->vol.enabled) {
+      // camera-only passes into this frame's set: on a stream of their own (the query stream), beside this frame's probe
+      // passes and the previous screen pass -- they are a few hundred wavefronts each and wait for nothing the probes make
+      hipStream_t vs = MDH_VOL_OWN_STREAM ? r->query_stream : r->probe_stream;
+      if ((rc = run_pass(r, MDH_PASS_VISIBILITY, vs, cur, cur)) != MDH_OK) return rc;
+      if ((rc = run_pass(r, MDH_PASS_SCATTERING, vs, cur, cur)) != MDH_OK) return rc;
+      if (vs != r->probe_stream) {
+         HIP_TRY(hipEventRecord(r->ev_vol[cur], vs));
+         HIP_TRY(hipStreamWaitEvent(screen_stream, r->ev_vol[cur], 0));
+      }
    }
    HIP_TRY(hipEventRecord(r->ev_probe[cur], r->probe_stream));
    HIP_TRY(hipStreamWaitEvent(screen_stream, r->ev_probe[cur], 0));
