@@ -1181,6 +1181,13 @@ static JitModule *jit_module(mdh_renderer *r, const std::vector<std::string> &ex
    g_jit_cache[key] = m;
    return m;
 }
+// Does the radiance pass of this renderer's slice leave most wavefront slots empty (k_radiance's SMALL variant)?
+static bool rad_small_launch(const mdh_renderer *r)
+{
+   const KProbes p = make_probes(r);
+   const long waves = ((long)(p.probe_end - p.probe_begin) * p.rres * p.rres + 63) / 64;
+   return waves <= (long)r->n_cus * 4 * MDH_RAD_SMALL_WAVES_PER_SIMD;
+}
 // The workgroups of the radiance pass the chip holds at once, when the launch is that and a remainder smaller than
 // it (k_radiance, mdh_kernels.h: the remainder runs at a raised issue priority); 0 otherwise.
 #ifndef MDH_RAD_RESORT
@@ -1370,7 +1377,7 @@ static int run_pass(mdh_renderer *r, int pass, hipStream_t st, int src, int dst,
    JitModule *jm = nullptr;
    if (jit) {
       switch (pass) {
-      case MDH_PASS_RADIANCE: snprintf(kname, sizeof kname, "k_radiance<%d>", pf | (pow2 ? MDH_PF_POW2 : 0)); break;
+      case MDH_PASS_RADIANCE: snprintf(kname, sizeof kname, "k_radiance<%d, %s>", pf | (pow2 ? MDH_PF_POW2 : 0), rad_small_launch(r) ? "true" : "false"); break;
       case MDH_PASS_VISIBILITY: snprintf(kname, sizeof kname, "k_visibility<%d>", pf); break;
       case MDH_PASS_SCATTERING: snprintf(kname, sizeof kname, "k_scattering<%d>", pf); break;
       case MDH_PASS_SCREEN: {
@@ -1431,17 +1438,19 @@ static int run_pass(mdh_renderer *r, int pass, hipStream_t st, int src, int dst,
             int rc = jit_launch(jm->fn[kname], blocks, MDH_BLOCK, lds, st, args);
             if (rc != MDH_OK) return rc;
          } else {
-#define MDH_LAUNCH_RAD(K) hipLaunchKernelGGL(K, dim3(blocks), dim3(MDH_BLOCK), lds, st, r->ks, pr, rad_first_round(r, (const void *)K, nullptr, lds, blocks), ro)
+#define MDH_LAUNCH_RAD_(...) hipLaunchKernelGGL((__VA_ARGS__), dim3(blocks), dim3(MDH_BLOCK), lds, st, r->ks, pr, rad_first_round(r, (const void *)(__VA_ARGS__), nullptr, lds, blocks), ro)
+#define MDH_LAUNCH_RAD(P) do { if (rad_small_launch(r)) MDH_LAUNCH_RAD_(k_radiance<P, true>); else MDH_LAUNCH_RAD_(k_radiance<P, false>); } while (0)
             if (pow2 && !has_custom) {
-               if (pf & MDH_PF_PART) MDH_LAUNCH_RAD(k_radiance<MDH_PF_PART | MDH_PF_POW2>);
-               else MDH_LAUNCH_RAD(k_radiance<MDH_PF_POW2>);
+               if (pf & MDH_PF_PART) MDH_LAUNCH_RAD(MDH_PF_PART | MDH_PF_POW2);
+               else MDH_LAUNCH_RAD(MDH_PF_POW2);
             } else
                switch (pf) {
-               case 0: MDH_LAUNCH_RAD(k_radiance<0>); break;
-               case 1: MDH_LAUNCH_RAD(k_radiance<1>); break;
-               case 2: MDH_LAUNCH_RAD(k_radiance<2>); break;
-               default: MDH_LAUNCH_RAD(k_radiance<3>); break;
+               case 0: MDH_LAUNCH_RAD(0); break;
+               case 1: MDH_LAUNCH_RAD(1); break;
+               case 2: MDH_LAUNCH_RAD(2); break;
+               default: MDH_LAUNCH_RAD(3); break;
                }
+#undef MDH_LAUNCH_RAD_
 #undef MDH_LAUNCH_RAD
          }
          if (ro.steps) { // the next pass's order from this pass's step counts

@@ -43,10 +43,18 @@
 #ifndef MDH_RAD_WAVES_PER_SIMD
 #define MDH_RAD_WAVES_PER_SIMD 7
 #endif
+// A launch that leaves most wavefront slots empty anyway (the reference's default 36 probes; a rank's slice of a sharded
+// frame) gains nothing from a small register budget: its kernel variant (SMALL) is built for five wavefronts per SIMD --
+// 86 VGPRs, 16 instead of 96 bytes of scratch (the radiance pass of a rank's slice -2 %, light_shafts +0.6 to +1.3 %:
+// profiles/r02_x_radiance_small_launch.log).
+#ifndef MDH_RAD_SMALL_WAVES_PER_SIMD
+#define MDH_RAD_SMALL_WAVES_PER_SIMD 5
+#endif
+#define MDH_OCC_RAD_BUILTIN(SMALL) ((SMALL) ? MDH_RAD_SMALL_WAVES_PER_SIMD : MDH_RAD_WAVES_PER_SIMD)
 #ifdef MDH_JIT
-#define MDH_OCC_RAD(PART) MDH_RAD_WAVES_PER_SIMD
+#define MDH_OCC_RAD(PART, SMALL) MDH_OCC_RAD_BUILTIN(SMALL)
 #else
-#define MDH_OCC_RAD(PART) (((PART) & MDH_PF_CUSTOM) ? 2 : MDH_RAD_WAVES_PER_SIMD)
+#define MDH_OCC_RAD(PART, SMALL) (((PART) & MDH_PF_CUSTOM) ? 2 : MDH_OCC_RAD_BUILTIN(SMALL))
 #endif
 #ifndef MDH_RAD_QVIS
 #define MDH_RAD_QVIS 1 // probe-visibility rays through the wave's ray queue (mdh_march.h: queued_visibility)
@@ -209,7 +217,7 @@ struct RadOrder {
 // starts 35-65 us late in slots between six older wavefronts, would finish last by far: it raises its issue priority
 // instead and runs at the speed of a wavefront alone (radiance pass 0.165 -> 0.147 ms).
 // `ro`: the rays of the pass in the order of the PREVIOUS pass's primary-march lengths (RadOrder below), or no order.
-template <int PART> __global__ __launch_bounds__(MDH_BLOCK, MDH_OCC_RAD(PART)) void k_radiance(KScene sc, KProbes pr, int first_round, RadOrder ro)
+template <int PART, bool SMALL = false> __global__ __launch_bounds__(MDH_BLOCK, MDH_OCC_RAD(PART, SMALL)) void k_radiance(KScene sc, KProbes pr, int first_round, RadOrder ro)
 {
    if (first_round > 0 && (int)blockIdx.x >= first_round) __builtin_amdgcn_s_setprio(3);
    stage_table(sc);
