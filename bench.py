@@ -8,15 +8,19 @@ BASELINE.json's metric and config 3, on N MI355X of one node.
 A step = one frame.  The scene, atlases and tables are resident in HBM before the timed
 region; frame read-back is excluded.  N > 1: image tiles and probe slices are split over
 the ranks (fixed frame => strong scaling) with one in-place RCCL all-gather per frame (the
-radiance slices; every rank folds the irradiance itself, MDH_OPT_IRRADIANCE_ALL; probe counts
-the world size does not divide go through the host exchange) -- madarch_amd/sharding.py.
+radiance slices; every rank folds the irradiance itself, MDH_OPT_IRRADIANCE_ALL) issued by
+libmadarch_hip.so itself: the ranks' renderers join a communicator (mdh_comm_init) and
+Renderers.Render is the sharded frame.  torch.distributed (gloo, CPU tensors) is the control
+plane only -- the communicator id, barriers, max over ranks -- and, should the communicator not
+form, the fall-back exchange through host memory (config.parallelism says which ran).
 Prints one JSON line on rank 0.
 
 `value` is the throughput of the library's default schedule (consecutive frames in flight,
 MDH_OPT_FRAME_OVERLAP); `value_serial` / `ms_per_step_serial` beside it are SURVEY.md section
 8(d)'s metric to the letter: the wall time of one device-synchronised Renderers.Render, all
-passes, nothing else in flight.  `roofline` is computed from the dominant kernel's duration
-with the chip to itself (the serial schedule).
+passes, nothing else in flight.  `roofline` prices the dominant kernel on its duration inside the
+timed region (as BENCH_r01 did), `roofline_serial` on its duration with the chip to itself (what
+BENCH_r02's `roofline` held): "schema": 3 marks lines with this meaning.
 """
 import argparse
 import json
@@ -166,50 +170,6 @@ def cpu_baseline_exprs():
             "sample": "%d frames of 256x256 simple_scene, screen mode 1 (primary rays, normal colour), space partition on (%.1f s) after 1 warm-up frame" % (frames, dt)}
 
 
-def rehearse_cpu(args, rank, world):
-    """The N-rank control flow of main() on the CPU: process group (gloo), ShardedFrame with the exchange make_exchange
-    picks for the host, barrier + max-over-ranks timing, rank 0 printing one line.  The engine is the oracle and the
-    frame is tiny: the line carries "rehearsal": true and no throughput claim."""
-    import torch
-    import torch.distributed as dist
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from madarch_amd import _binding as B
-    from madarch_amd import sharding
-    from oracle_engine import ORC_OPT_THREADS, oracle_binding
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29533")
-    if world > 1:
-        dist.init_process_group("gloo")
-    R = make_renderer("rehearsal_small", oracle_binding())
-    R.Set_Option(ORC_OPT_THREADS, 2)
-    frame = sharding.ShardedFrame(R, rank, world, sharding.HostExchange(dist) if world > 1 else None)
-
-    def sync():
-        R.Finish()
-        if world > 1:
-            dist.barrier()
-    for _ in range(args.warmup):
-        frame.Render()
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        frame.Render()
-    sync()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    img = frame.Gather_Framebuffer(dist if world > 1 else None)
-    if rank == 0:
-        import hashlib
-        print(json.dumps({"rehearsal": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-                          "frame_sha1": hashlib.sha1(img.tobytes()).hexdigest(), "engine": "CPU oracle over gloo (control flow only)"}), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -225,13 +185,10 @@ def main():
     ap.add_argument("--no-serial-segment", action="store_true", help="skip the untimed serial frames that give clean per-kernel durations")
     ap.add_argument("--swap-buffers", action="store_true", help="Swap_Buffers after every frame and fetch the window's RGBA8 pixels of the frame before (the PCIe-inclusive rate; never the default)")
     ap.add_argument("--animate-light", action="store_true", help="set the light anew before every frame, as the example's main loop does (global_illumination/main.adb:219-232)")
-    ap.add_argument("--rehearse-rccl", action="store_true", help="one rank, but through the RCCL exchange path of the sharded frame (rehearsal of the N > 1 code path on one GPU)")
+    ap.add_argument("--rehearse-rccl", action="store_true", help="one rank, but with a (one-rank) communicator: every frame runs the library's RCCL exchange (rehearsal of the N > 1 code path on one GPU)")
     ap.add_argument("--rehearse-cpu", action="store_true", help="TEST ONLY: this file's N-rank control flow on the CPU -- gloo, the oracle as the engine, a tiny frame; prints a line marked as a rehearsal, never a result")
+    ap.add_argument("--comm-timeout-s", type=float, default=120.0, help="watchdog of the communicator's join and trial frames (N > 1)")
     args = ap.parse_args()
-
-    import torch
-    from madarch_amd import _binding as B
-    from madarch_amd import sharding
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -240,22 +197,39 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
         args.gpus = world
-    if args.rehearse_cpu:
-        return rehearse_cpu(args, rank, world)
-    torch.cuda.set_device(local_rank)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL's peer-to-peer setup needs on this pool
+
+    # The CONTROL plane of an N-rank run: torch.distributed over gloo, CPU tensors only (hands the communicator id
+    # round, agrees on the fall-back, barriers, max over ranks).  The DATA plane -- the all-gather of the atlas slices --
+    # is RCCL inside libmadarch_hip.so (mdh_comm_init): torch never sees a device pointer or a stream, and a one-rank run
+    # does not import it at all.  (torch is imported BEFORE the library is loaded: INTEGRATION.md section 5.)
     dist = None
-    if world > 1 or args.rehearse_rccl:
+    if world > 1:
+        import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        # (no device_id: a communicator bound eagerly to the device runs its collectives 70 us per frame slower
-        #  beside the renderer's streams -- measured with scripts/rccl_host_cost.py; the device is set above)
-        if world > 1:
-            dist.init_process_group("nccl")
-        else:
-            dist.init_process_group("nccl", rank=0, world_size=1)
+        dist.init_process_group("gloo")
 
-    R = make_renderer(args.workload, B.hip_binding(), device=local_rank)
+    def vmax(x):  # the same value on every rank
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    from madarch_amd import _binding as B
+    from madarch_amd import sharding
+
+    rehearsal = args.rehearse_cpu
+    if rehearsal:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from oracle_engine import ORC_OPT_THREADS, oracle_binding
+        args.workload, args.no_cpu_baseline, args.prewarm_s = "rehearsal_small", True, 0.0
+        R = make_renderer(args.workload, oracle_binding())
+        R.Set_Option(ORC_OPT_THREADS, 2)
+    else:
+        R = make_renderer(args.workload, B.hip_binding(), device=local_rank)
     R.Set_Option(B.OPT_ATLAS_FORMAT, 0 if args.atlas == "rgb8" else 1)
     if args.mode is not None:
         R.Set_Option(B.OPT_SCREEN_MODE, args.mode)
@@ -263,14 +237,23 @@ def main():
         R.Set_Option(B.OPT_FRAME_OVERLAP, 0)
     elif args.overlap is not None:
         R.Set_Option(B.OPT_FRAME_OVERLAP, args.overlap)
-    exchange = sharding.make_exchange(dist, R, torch.device("cuda", local_rank), world) if dist is not None else None
+
+    # N ranks: the renderers join a communicator inside the library and Renderers.Render of every rank becomes one frame
+    # of the sharded schedule; if that fails anywhere, every rank falls back to the exchange through host memory over the
+    # control plane -- in this process, and the line says so.
+    exchange, how = None, "single rank"
+    if world > 1:
+        exchange, how = sharding.establish(R, rank, world, dist, timeout_s=args.comm_timeout_s,
+                                           log=lambda m: print(m, file=sys.stderr, flush=True))
+    elif args.rehearse_rccl:
+        R.Comm_Init(R.Comm_Unique_Id(), 0, 1)
+        how = "rccl"
     frame = sharding.ShardedFrame(R, rank, world, exchange)
 
-    def sync():
+    def sync():  # barrier + device synchronisation: every pass this rank has enqueued is done, then every rank is here
         R.Finish()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier(device_ids=[local_rank])
+        if dist is not None:
+            dist.barrier()
 
     animate = None
     if args.animate_light and WORKLOADS[args.workload][0] == "global_illumination":
@@ -285,12 +268,15 @@ def main():
         R.Set_Option(B.OPT_WINDOW, 1)
     # untimed pre-warm: the clocks of a box that has just been handed over ramp up over the first few hundred
     # milliseconds of load (the driver's 5 warm-up frames are ~3 ms of GPU work), so frames run for at least
-    # 0.4 s before the official warm-up starts
+    # 0.4 s before the official warm-up starts.  Every frame of a sharded run is a collective: the ranks agree on
+    # the elapsed time after each block (max over ranks), so all of them run the same number of blocks.
     t_pre = time.perf_counter()
-    while time.perf_counter() - t_pre < args.prewarm_s:
-        for _ in range(25):
+    while True:
+        for _ in range(2 if rehearsal else 25):
             frame.Render()
         R.Finish()
+        if vmax(time.perf_counter() - t_pre) >= args.prewarm_s:
+            break
     for _ in range(args.warmup):
         frame.Render()
     sync()
@@ -308,15 +294,8 @@ def main():
             R.Swap_Buffers()
     if args.swap_buffers:
         R.Front_Buffer(copy=False)
-    R.Finish()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier(device_ids=[local_rank])
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    sync()
+    dt = vmax(time.perf_counter() - t0)
 
     def pass_times():
         out = {}
@@ -329,63 +308,75 @@ def main():
     passes = pass_times()
     overlap = R.Get_Option(B.OPT_FRAME_OVERLAP)
     passes_serial, serial_dt = None, None
-    if overlap and not args.no_serial_segment:
+    if (overlap or rehearsal) and not args.no_serial_segment:  # (the oracle has no schedule; the rehearsal walks the segment's control flow all the same)
         # Pipelined frames share the chip between kernels, which stretches every launch.  A short
         # untimed run of the strictly serial schedule gives each kernel's duration on its own.
         R.Set_Option(B.OPT_FRAME_OVERLAP, 0)
-        for _ in range(3):
+        for _ in range(1 if rehearsal else 3):
             frame.Render()
         sync()
         R.Reset_Pass_Times()
-        for _ in range(10):
+        for _ in range(1 if rehearsal else 10):
             frame.Render()
         sync()
         passes_serial = pass_times()
         # wall time of ONE device-synchronised Renderers.Render (all passes), nothing else in flight
         R.Set_Option(B.OPT_TIMING, 0)
-        n_serial = max(10, min(args.steps, 50))
+        n_serial = 2 if rehearsal else max(10, min(args.steps, 50))
         sync()
         ts = time.perf_counter()
         for _ in range(n_serial):
             frame.Render()
             R.Finish()
-        serial_dt = (time.perf_counter() - ts) / n_serial
-        if world > 1:
-            tt = torch.tensor([serial_dt], dtype=torch.float64, device="cuda")
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            serial_dt = float(tt.item())
+        serial_dt = vmax((time.perf_counter() - ts) / n_serial)
         R.Set_Option(B.OPT_FRAME_OVERLAP, overlap)
 
-    if rank == 0:
+    parallelism = "tiles+probes/%d" % world
+    if how == "rccl":
+        parallelism += ", RCCL all-gather inside libmadarch_hip" + (" (one-rank rehearsal)" if world == 1 else "")
+    elif world > 1:
+        parallelism += ", HOST EXCHANGE FALL-BACK over gloo (%s)" % how
+    if rehearsal:
+        img = frame.Gather_Framebuffer(dist)
+        if rank == 0:
+            import hashlib
+            print(json.dumps({"rehearsal": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+                              "frame_sha1": hashlib.sha1(img.tobytes()).hexdigest(), "parallelism": parallelism,
+                              "serial_segment": passes_serial is not None, "engine": "CPU oracle over gloo (control flow only)"}), flush=True)
+    elif rank == 0:
         W, H = R.Width, R.Height
         scene, _, _, probes, mode = WORKLOADS[args.workload]
         value = W * H * args.steps / dt / 1e6
         alg_bytes, per_px, tables = algorithmic_bytes_screen(R)
         screen_ms_piped = passes.get("screen", {}).get("ms_avg", float("nan"))
-        # the roofline of the dominant kernel is priced on its duration with the chip to itself (serial schedule);
+        # `roofline` prices the dominant kernel on its average duration inside the TIMED region (the schedule `value`
+        # is measured on); `roofline_serial` on its duration with the chip to itself (the untimed serial segment):
         # inside pipelined frames two screen passes and the probe passes share the chip and every launch stretches
-        screen_ms = passes_serial["screen"]["ms_avg"] if passes_serial else screen_ms_piped
-        achieved = alg_bytes / (screen_ms * 1e-3) / 1e9
+        screen_ms_serial = passes_serial["screen"]["ms_avg"] if passes_serial else None
+        achieved = alg_bytes / (screen_ms_piped * 1e-3) / 1e9
         traffic, traffic_src = measured_traffic(args.workload, world) if args.atlas == "rgb8" and args.mode is None else (None, None)
         out = {
             "metric": "Mpixels/sec at %dx%d %s scene (one Renderers.Render frame: every pass of renderers.adb:302-321)" % (W, H, scene),
             "value": round(value, 3), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic", "schema": 3,
             "config": {"workload": args.workload, "scene": scene, "width": W, "height": H,
                        "probe_grid": "8x8x8" if probes == "gi8" else "4x3x3", "atlas": args.atlas,
-                       "screen_mode": mode, "parallelism": "tiles+probes/%d" % world + (" (RCCL rehearsal)" if args.rehearse_rccl else ""),
+                       "screen_mode": mode, "parallelism": parallelism, "exchange": how,
                        "frame_overlap": overlap, "animated_light": bool(animate), "swap_buffers": bool(args.swap_buffers),
                        "radiance_order": int(R.Get_Option(B.OPT_RADIANCE_ORDER))},
             "roofline": {"bound": "hbm", "kernel": "k_screen", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": int(alg_bytes), "bytes_per_pixel": per_px,
-                         "kernel_ms_avg": screen_ms, "kernel_ms_source": "serial schedule, HIP events on the kernel's stream" if passes_serial else "timed region",
-                         "kernel_ms_pipelined": screen_ms_piped,
-                         "note": "the path is fp32-VALU bound (sphere tracing), not HBM bound; see DESIGN.md 'Roofline' and valu_issue below; achieved = algorithmic bytes of one k_screen launch / its average duration with the chip to itself (the untimed serial segment after the timed region); kernel_ms_pipelined is the same kernel inside the timed region, where kernels of neighbouring frames share the chip"},
+                         "kernel_ms_avg": screen_ms_piped, "kernel_ms_source": "timed region, HIP events on the kernel's stream",
+                         "note": "the path is fp32-VALU bound (sphere tracing), not HBM bound; see DESIGN.md 'Roofline' and valu_issue below; achieved = algorithmic bytes of one k_screen launch / its average duration in the timed region, where kernels of neighbouring frames share the chip (roofline_serial: the same kernel with the chip to itself)"},
             "passes": passes,
         }
         if passes_serial:
+            ach_s = alg_bytes / (screen_ms_serial * 1e-3) / 1e9
+            out["roofline_serial"] = {"bound": "hbm", "kernel": "k_screen", "achieved": round(ach_s, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                      "frac": round(ach_s / HBM_PEAK_GBS, 6), "kernel_ms_avg": screen_ms_serial,
+                                      "kernel_ms_source": "untimed serial segment after the timed region (MDH_OPT_FRAME_OVERLAP = 0), HIP events on the kernel's stream"}
             out["passes_serial"] = passes_serial
             out["value_serial"] = round(W * H / serial_dt / 1e6, 3)
             out["ms_per_step_serial"] = round(serial_dt * 1e3, 4)
@@ -398,7 +389,7 @@ def main():
             out["cpu_baseline_exprs"] = cpu_baseline_exprs()
         print(json.dumps(out), flush=True)
     if dist is not None:
-        dist.barrier(device_ids=[local_rank])
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -1,21 +1,43 @@
 // examples/global_illumination.cpp -- the reference program examples/global_illumination/main.adb
 // (lines 29-74 and 149-161) restated with the C++ mirror of Madarch's packages: same scene data,
 // same call order, minus the window loop.  Usage: global_illumination W H FRAMES [out.f32 [out.ppm]]
+//                                                  [--rank R --world N --id-file PATH [--device D]]
+// With --world N the program is one of N processes, one per GPU of a node (device = rank unless --device says
+// otherwise): the renderers join a communicator inside libmadarch_hip.so, every Render is one frame of the sharded
+// schedule (probe slices + RCCL all-gather + interleaved screen tiles), and rank 0 gathers the tiles of the last
+// frame before it writes the image.  No other runtime is involved: the 128-byte id travels through --id-file.
 #include "madarch.hpp"
 
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 
 using namespace Madarch;
 
 int main(int argc, char **argv)
 {
+   int rank = 0, world = 1, device = -1;
+   std::string id_file;
+   int nargs = argc;
+   for (int i = 1; i < argc; ++i) // the options go last: everything before them is positional
+      if (argv[i][0] == '-' && argv[i][1] == '-') { nargs = i; break; }
+   for (int i = nargs; i + 1 < argc; i += 2) {
+      const std::string o = argv[i];
+      if (o == "--rank") rank = atoi(argv[i + 1]);
+      else if (o == "--world") world = atoi(argv[i + 1]);
+      else if (o == "--device") device = atoi(argv[i + 1]);
+      else if (o == "--id-file") id_file = argv[i + 1];
+      else { fprintf(stderr, "unknown option %s\n", argv[i]); return 2; }
+   }
+   argc = nargs;
+   if (world > 1 && id_file.empty()) { fprintf(stderr, "--world needs --id-file\n"); return 2; }
    const int W = argc > 1 ? atoi(argv[1]) : 1000, H = argc > 2 ? atoi(argv[2]) : 1000, frames = argc > 3 ? atoi(argv[3]) : 1;
    try {
       Scenes::Scene Scene = Scenes::Compile({{Primitives::Spheres::Sphere, 20}, {Primitives::Planes::Plane, 10}, {Primitives::Boxes::Box, 10}},
                                             {{Lights::Spot_Lights::Spot_Light, 4}}, Scenes::Partitioning_Settings{false});
       Windows::Window Window = Windows::Open(W, H, "Global_Illumination");
-      Renderers::Renderer Renderer = Renderers::Create(Window, Scene, {}, Renderers::No_Volumetrics);
+      Renderers::Renderer Renderer = Renderers::Create(Window, Scene, {}, Renderers::No_Volumetrics, device >= 0 ? device : rank);
+      if (!id_file.empty()) Renderer.Join_Node(rank, world, id_file);
 
       Entities::Entity Spot_Light_Instance = Lights::Spot_Lights::Create({3.5f, 5.0f, 2.0f}, {1.0f, 0.0f, 0.0f}, 3.1415f / 4.0f, {0.9f, 0.9f, 0.8f});
       Materials::Id Wall_Mat_1 = Renderer.Add_Material(Materials::Create({0.0f, 0.0f, 0.0f}, 0.0f, 0.6f));
@@ -38,6 +60,10 @@ int main(int argc, char **argv)
          Renderer.Render();
          Renderer.Swap_Buffers(); // renderers.adb:320, here into pinned host memory; no wait
       }
+      if (!id_file.empty()) {
+         Renderer.Gather_Frame(0); // every rank's tiles into rank 0's framebuffer
+         if (rank != 0) { Renderer.Barrier(); Renderer.Leave_Node(); return 0; }
+      }
       std::vector<float> image = Renderer.Read_Framebuffer();
       if (argc > 4) {
          FILE *out = fopen(argv[4], "wb");
@@ -45,7 +71,7 @@ int main(int argc, char **argv)
          fwrite(image.data(), sizeof(float), image.size(), out);
          fclose(out);
       }
-      if (argc > 5) { // the window's pixels of the last frame as a binary PPM
+      if (argc > 5 && world == 1) { // the window's pixels of the last frame as a binary PPM (a rank's window holds its own tiles only)
          const uint8_t *px = Renderer.Front_Buffer();
          FILE *out = fopen(argv[5], "wb");
          if (!out) return 2;
@@ -55,7 +81,8 @@ int main(int argc, char **argv)
       }
       double sum = 0;
       for (float v : image) sum += (v == v) ? v : 0;
-      printf("global_illumination %dx%d frames %d mean %.6f\n", W, H, frames, sum / image.size());
+      printf("global_illumination %dx%d frames %d ranks %d mean %.6f\n", W, H, frames, world, sum / image.size());
+      if (!id_file.empty()) { Renderer.Barrier(); Renderer.Leave_Node(); }
    } catch (const std::exception &e) {
       fprintf(stderr, "error: %s\n", e.what());
       return 1;

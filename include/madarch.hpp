@@ -13,11 +13,14 @@
 #include "madarch_hip.h"
 
 #include <array>
+#include <chrono>
+#include <cstdio>
 #include <cstring>
 #include <functional>
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -353,6 +356,37 @@ class Renderer {
       return p;
    }
    void Set_Option(int32_t Option, int32_t Value) const { Check(mdh_set_option(h_.get(), Option, Value)); }
+   // ---- one frame on the N GPUs of a node, one process per GPU (include/madarch_hip.h, mdh_comm_*): after Join_Node,
+   // Render of every rank is one frame of the sharded schedule.  The 128-byte communicator id travels from rank 0 to
+   // the others through `Id_File` (written under a temporary name and renamed, so a reader never sees half of it).
+   void Join_Node(int Rank, int World, const std::string &Id_File, double Timeout_S = 120.0) const
+   {
+      uint8_t id[MDH_COMM_ID_BYTES];
+      if (Rank == 0) {
+         Check(mdh_comm_unique_id(id));
+         const std::string tmp = Id_File + ".tmp";
+         FILE *f = fopen(tmp.c_str(), "wb");
+         if (!f || fwrite(id, 1, sizeof id, f) != sizeof id) throw Program_Error("cannot write the communicator id file");
+         fclose(f);
+         if (rename(tmp.c_str(), Id_File.c_str()) != 0) throw Program_Error("cannot publish the communicator id file");
+      } else {
+         const auto t0 = std::chrono::steady_clock::now();
+         for (;;) {
+            FILE *f = fopen(Id_File.c_str(), "rb");
+            const size_t n = f ? fread(id, 1, sizeof id, f) : 0;
+            if (f) fclose(f);
+            if (n == sizeof id) break;
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > Timeout_S) throw Program_Error("rank 0 never published the communicator id file");
+            std::this_thread::sleep_for(std::chrono::milliseconds(20));
+         }
+      }
+      Check(mdh_comm_init(h_.get(), id, Rank, World));
+   }
+   void Leave_Node() const { Check(mdh_comm_destroy(h_.get())); }
+   void Barrier() const { Check(mdh_comm_barrier(h_.get())); }
+   double Max_Over_Ranks(double V) const { Check(mdh_comm_max_f64(h_.get(), &V)); return V; }
+   // the ranks' tiles of the last frame summed into Root's framebuffer: what Root's window shows
+   void Gather_Frame(int Root = 0) const { Check(mdh_comm_reduce_framebuffer(h_.get(), Root)); }
    mdh_renderer *Handle() const { return h_.get(); }
    const Windows::Window &Window() const { return window_; }
  private:

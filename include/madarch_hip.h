@@ -45,7 +45,8 @@ enum {
    MDH_E_DEVICE = 5,           /* a HIP call failed (text in mdh_last_error)                  */
    MDH_E_NO_DEVICE = 6,        /* no gfx950 device visible: the library never falls back to
                                   the CPU                                                     */
-   MDH_E_STATE = 7             /* call not valid in this state (e.g. partitioning disabled)   */
+   MDH_E_STATE = 7,            /* call not valid in this state (e.g. partitioning disabled)   */
+   MDH_E_COMM = 8              /* librccl missing, or an RCCL call failed (text in mdh_last_error) */
 };
 
 /* = Madarch.Values.Value_Kind order (madarch-values.ads:8) */
@@ -183,7 +184,8 @@ enum {
    /* 1 = also write the primary-ray geometry buffer (hit index, t, steps) */
    MDH_OPT_GBUFFER = 3,
    /* image/probe sharding for one-process-per-GPU runs: this renderer draws the
-    * screen tiles and probe slices of `rank` out of `world` (default 0 / 1) */
+    * screen tiles and probe slices of `rank` out of `world` (default 0 / 1).  mdh_comm_init sets
+    * both; setting them by hand is for callers that bring their own exchange (mdh_frame_*) */
    MDH_OPT_RANK = 4,
    MDH_OPT_WORLD = 5,
    /* 1 = record HIP events around every pass (read with mdh_pass_time) */
@@ -245,7 +247,9 @@ enum {
    MDH_PASS_VISIBILITY = 2, /* compute_frustrum_visibility.glsl   */
    MDH_PASS_SCATTERING = 3, /* accumulate_scattering.glsl         */
    MDH_PASS_SCREEN = 4,     /* draw_screen.glsl                   */
-   MDH_PASS_COUNT = 5
+   MDH_PASS_EXCHANGE = 5,   /* no pass of the reference: the all-gather of a sharded frame's atlas slices
+                               (mdh_frame_exchange), timed like a pass (mdh_pass_time)                     */
+   MDH_PASS_COUNT = 6
 };
 
 /* atlases / textures of the renderer (texture units 0-3, renderers.adb:239-279) */
@@ -254,7 +258,10 @@ enum { MDH_TEX_RADIANCE = 0, MDH_TEX_IRRADIANCE = 1, MDH_TEX_VISIBILITY = 2, MDH
 /* Renderers.Create (madarch-renderers.adb:91-300) together with Scenes.Compile
  * (madarch-scenes.adb:1378-1421).  `width`/`height` replace the window size
  * (Windows.Open; the build is headless).  `device` is the HIP device ordinal
- * (one process per GPU: pass LOCAL_RANK). */
+ * (one process per GPU: pass LOCAL_RANK).  SURVEY.md section 8(b) sketches this argument as
+ * `n_devices`; with one process per GPU -- the execution model of this build -- a renderer owns ONE
+ * device, and the N-device frame is formed by the renderers of N processes joining a communicator
+ * (mdh_comm_init below): `n_devices` is that call's `world`. */
 int32_t mdh_create(int32_t width, int32_t height, const mdh_scene_desc *scene,
                    const mdh_probe_settings *probes, const mdh_volumetrics *volumetrics,
                    int32_t device, mdh_renderer **out);
@@ -309,8 +316,48 @@ int32_t mdh_render_pass(mdh_renderer *r, int32_t pass);
  * ordered on the stream mdh_probe_stream names. */
 int32_t mdh_frame_begin(mdh_renderer *r);
 int32_t mdh_frame_probe_pass(mdh_renderer *r, int32_t pass);
+/* the exchange step of an open frame of a renderer that has a communicator (mdh_comm_init): all-gather of
+ * the ranks' slices of atlas `tex` (MDH_TEX_RADIANCE / MDH_TEX_IRRADIANCE), in place on the open frame's atlas
+ * set, enqueued on the probe stream.  Without a communicator: nothing (MDH_OK). */
+int32_t mdh_frame_exchange(mdh_renderer *r, int32_t tex);
 int32_t mdh_frame_end(mdh_renderer *r);
 int32_t mdh_finish(mdh_renderer *r);
+
+/* ---- one frame on the N GPUs of a node: one process (and one renderer) per GPU.
+ *
+ * The reference draws a frame with ONE call on one GPU (Renderers.Render, madarch-renderers.adb:302-321).
+ * SURVEY.md section 8(b)/(e) asks for the same call to draw it on N: every process creates its renderer on its
+ * own device, the processes join a communicator (RCCL over xGMI; librccl is opened on first use, the
+ * library does not link it), and from then on mdh_render of every rank IS one frame of the sharded schedule:
+ *    radiance pass for the rank's probe slice -> all-gather of the slices, in place on the probe-major atlas,
+ *    on the probe stream -> irradiance pass (all probes on every rank, MDH_OPT_IRRADIANCE_ALL; own slice +
+ *    a second all-gather otherwise) -> volumetric passes (replicated) -> screen pass for the 8x8 tiles
+ *    t = rank (mod world).
+ * Frames stay in flight exactly as on one GPU (MDH_OPT_FRAME_OVERLAP).  No caller-side collective, no other
+ * runtime in the process: a host written in Ada or C needs only these calls and a way to hand 128 bytes from
+ * rank 0 to the others (a file, a pipe, an environment variable).
+ *
+ *   mdh_comm_unique_id   rank 0 only: the 128-byte id of a new communicator (ncclGetUniqueId)
+ *   mdh_comm_init        every rank, collectively: joins (ncclCommInitRank on the renderer's device) and sets
+ *                        MDH_OPT_RANK / MDH_OPT_WORLD, which cannot be set by hand while the communicator lives
+ *   mdh_comm_destroy     leaves; the renderer is rank 0 of 1 again
+ *   mdh_comm_abort       tears the communicator down WITHOUT waiting for collectives in flight
+ *                        (ncclCommAbort): what a host's watchdog calls when a peer never arrives
+ *   mdh_comm_barrier     mdh_finish + a collective every rank has to reach + host wait
+ *   mdh_comm_max_f64     *value = max over the ranks (timing: the slowest rank's wall time)
+ *   mdh_comm_reduce_framebuffer
+ *                        the ranks' tiles of the last frame summed into `root`'s framebuffer (every pixel is
+ *                        non-zero on one rank only, so the sum is the whole frame bit for bit up to the sign of
+ *                        zeros): what mdh_read_framebuffer / the window of rank `root` then shows.  Not part of
+ *                        a frame; a host that presents the image calls it, a benchmark does not. */
+#define MDH_COMM_ID_BYTES 128
+int32_t mdh_comm_unique_id(uint8_t id_out[MDH_COMM_ID_BYTES]);
+int32_t mdh_comm_init(mdh_renderer *r, const uint8_t id[MDH_COMM_ID_BYTES], int32_t rank, int32_t world);
+int32_t mdh_comm_destroy(mdh_renderer *r);
+int32_t mdh_comm_abort(mdh_renderer *r);
+int32_t mdh_comm_barrier(mdh_renderer *r);
+int32_t mdh_comm_max_f64(mdh_renderer *r, double *value);
+int32_t mdh_comm_reduce_framebuffer(mdh_renderer *r, int32_t root);
 
 /* replaces Swap_Buffers (renderers.adb:320): linear RGB floats, H*W*3, row 0 = top.
  * In a sharded run only this rank's tiles are written, the rest is 0. */
@@ -348,7 +395,7 @@ int32_t mdh_read_atlas_slice(mdh_renderer *r, int32_t tex, int32_t probe_begin, 
 int32_t mdh_write_atlas_slice(mdh_renderer *r, int32_t tex, int32_t probe_begin, int32_t n_probes,
                               const float *in);
 
-/* device-resident atlas slices for the RCCL all-gather of a sharded run:
+/* device-resident atlas slices for callers that bring an exchange of their own (mdh_comm_init needs none of this):
  * pointer to the probe-major atlas, its total byte size and the byte range
  * [offset, offset+bytes) this rank owns */
 int32_t mdh_atlas_device_ptr(mdh_renderer *r, int32_t tex, void **dptr, int64_t *total_bytes,

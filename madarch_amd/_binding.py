@@ -15,7 +15,7 @@ HIP_LIBRARY = os.environ.get("MADARCH_HIP_LIBRARY") or os.path.join(_HERE, "csrc
 
 # status codes (include/madarch_hip.h)
 MDH_OK, MDH_E_INVALID, MDH_E_PROBE_MISMATCH, MDH_E_UNSUPPORTED_KIND = 0, 1, 2, 3
-MDH_E_INDEX, MDH_E_DEVICE, MDH_E_NO_DEVICE, MDH_E_STATE = 4, 5, 6, 7
+MDH_E_INDEX, MDH_E_DEVICE, MDH_E_NO_DEVICE, MDH_E_STATE, MDH_E_COMM = 4, 5, 6, 7, 8
 
 MDH_VEC3, MDH_FLOAT, MDH_INT = 0, 1, 2
 
@@ -23,8 +23,9 @@ OPT_ATLAS_FORMAT, OPT_SCREEN_MODE, OPT_AO_STEPS, OPT_GBUFFER = 0, 1, 2, 3
 OPT_RANK, OPT_WORLD, OPT_TIMING, OPT_ADA_EVAL_DIV, OPT_FRAME_OVERLAP, OPT_JIT, OPT_IRRADIANCE_ALL, OPT_WINDOW = 4, 5, 6, 7, 8, 9, 10, 11
 OPT_INDIRECT_SPECULAR, OPT_HYSTERESIS_PERMILLE, OPT_RADIANCE_ORDER = 12, 13, 14
 
-PASS_RADIANCE, PASS_IRRADIANCE, PASS_VISIBILITY, PASS_SCATTERING, PASS_SCREEN = range(5)
-PASS_NAMES = ("radiance", "irradiance", "visibility", "scattering", "screen")
+PASS_RADIANCE, PASS_IRRADIANCE, PASS_VISIBILITY, PASS_SCATTERING, PASS_SCREEN, PASS_EXCHANGE = range(6)
+PASS_NAMES = ("radiance", "irradiance", "visibility", "scattering", "screen", "exchange")
+COMM_ID_BYTES = 128
 TEX_RADIANCE, TEX_IRRADIANCE, TEX_VISIBILITY, TEX_SCATTERING = range(4)
 
 
@@ -119,8 +120,17 @@ ABI = {
     "last_error": (C.c_char_p, []),
     "version": (C.c_char_p, []),
 }
-# exports only the HIP library has (device pointers for the RCCL exchange)
+# exports only the HIP library has: the communicator of a sharded run (RCCL inside the library), and
+# device pointers / streams for callers that bring an exchange of their own
 HIP_ONLY_ABI = {
+    "frame_exchange": (_I, [_P, _I]),
+    "comm_unique_id": (_I, [_P]),
+    "comm_init": (_I, [_P, _P, _I, _I]),
+    "comm_destroy": (_I, [_P]),
+    "comm_abort": (_I, [_P]),
+    "comm_barrier": (_I, [_P]),
+    "comm_max_f64": (_I, [_P, C.POINTER(C.c_double)]),
+    "comm_reduce_framebuffer": (_I, [_P, _I]),
     "atlas_device_ptr": (_I, [_P, _I, C.POINTER(_P), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
                               C.POINTER(C.c_int64)]),
     "stream": (_I, [_P, C.POINTER(_P)]),

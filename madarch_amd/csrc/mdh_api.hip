@@ -11,6 +11,7 @@
 
 #include <dlfcn.h>
 #include <hip/hiprtc.h> // types only: the library is opened on first use (no link-time dependency)
+#include <rccl/rccl.h>  // types only, likewise: librccl is opened by the first mdh_comm_* call
 
 #include <cmath>
 #include <cstdio>
@@ -188,12 +189,12 @@ struct mdh_renderer {
    float4 *d_table_ring[TAB_RING] = {nullptr, nullptr, nullptr, nullptr};
    float4 *h_table_ring[TAB_RING] = {nullptr, nullptr, nullptr, nullptr}; // pinned
    int tab_slot = 0;
-   static const int NSTREAMS = 4; // main, probe, alternate, query (stream_index)
+   static const int NSTREAMS = 5; // main, probe, alternate, query, volumetric (stream_index)
    hipEvent_t tab_done[TAB_RING][NSTREAMS] = {{nullptr}};
    bool tab_used[TAB_RING][NSTREAMS] = {{false}};
    hipEvent_t ev_table = nullptr;       // recorded after the last upload, on table_stream
    hipStream_t table_stream = nullptr;
-   unsigned long long table_version = 0, tab_seen[NSTREAMS] = {0, 0, 0, 0}; // per stream: has it waited for ev_table
+   unsigned long long table_version = 0, tab_seen[NSTREAMS] = {0, 0, 0, 0, 0}; // per stream: has it waited for ev_table
    size_t table_cap = 0;
    bool table_dirty = true;
    // The space-partition table, in a ring like the scene table: Update_Partitioning builds into the next buffer
@@ -207,10 +208,11 @@ struct mdh_renderer {
    bool part_used[PART_RING][NSTREAMS] = {{false}};
    hipEvent_t ev_part = nullptr, ev_warn = nullptr; // the last build, the last read-back of its warning count
    hipStream_t part_stream = nullptr;
-   unsigned long long part_version = 0, part_seen[NSTREAMS] = {0, 0, 0, 0};
+   unsigned long long part_version = 0, part_seen[NSTREAMS] = {0, 0, 0, 0, 0};
    int *d_warn = nullptr, *h_warn = nullptr;
    bool warn_pending = false;
    hipStream_t query_stream = nullptr; // Eval_Distance_To: beside the frames in flight, not behind them
+   hipStream_t vol_stream = nullptr;   // the camera-only volumetric passes of pipelined frames, beside their probe passes
    float *d_query = nullptr; // Eval_Distance_To: points, normals, distances of the largest batch so far
    size_t query_cap = 0;
    // Two sets of probe atlases.  `last` is the set the most recent frame wrote: every read, write and
@@ -236,7 +238,7 @@ struct mdh_renderer {
    hipStream_t probe_stream = nullptr;   // radiance + irradiance passes of pipelined frames
    hipStream_t alt_stream = nullptr;     // screen pass of every other pipelined frame
    hipEvent_t ev_screen[2] = {nullptr, nullptr}, ev_probe[2] = {nullptr, nullptr}, ev_join = nullptr, ev_join_alt = nullptr;
-   hipEvent_t ev_vol[2] = {nullptr, nullptr}; // the camera-only volumetric passes of a pipelined frame (on the query stream, beside its probe passes)
+   hipEvent_t ev_vol[2] = {nullptr, nullptr}; // the camera-only volumetric passes of a pipelined frame (on vol_stream, beside its probe passes)
    bool ev_screen_valid[2] = {false, false};
    bool alt_pending = false; // work on alt_stream that `stream` has not been ordered after yet
    // an open frame (mdh_frame_begin .. mdh_frame_end)
@@ -283,6 +285,10 @@ struct mdh_renderer {
    double pass_ms[MDH_PASS_COUNT] = {0};
    long long pass_n[MDH_PASS_COUNT] = {0};
    hipStream_t own_stream = nullptr;
+   // the communicator of a sharded run (mdh_comm_init): one rank per process and GPU.  With it mdh_render runs the
+   // exchange of the atlas slices itself, on the probe stream, between the probe passes.
+   ncclComm_t comm = nullptr;
+   double *d_comm_scratch = nullptr; // barrier / max reductions
    bool irr_lds_granted = false; // k_irradiance may use up to 160 KiB of dynamic LDS on this renderer's device
 };
 
@@ -294,6 +300,14 @@ static int join_main(mdh_renderer *r)
    HIP_TRY(hipEventRecord(r->ev_join_alt, r->alt_stream));
    HIP_TRY(hipStreamWaitEvent(r->stream, r->ev_join_alt, 0));
    r->alt_pending = false;
+   return MDH_OK;
+}
+// host wait for everything this renderer has enqueued anywhere (its own streams only: other renderers of the process run on)
+static int drain_streams(mdh_renderer *r)
+{
+   for (hipStream_t st : {r->probe_stream, r->alt_stream, r->query_stream, r->vol_stream, r->own_stream})
+      if (st) HIP_TRY(hipStreamSynchronize(st));
+   if (r->stream && r->stream != r->own_stream) HIP_TRY(hipStreamSynchronize(r->stream));
    return MDH_OK;
 }
 static hipEvent_t get_event(mdh_renderer *r)
@@ -314,6 +328,7 @@ static int resolve_timing(mdh_renderer *r, bool wait = true)
       { int jr = join_main(r); if (jr != MDH_OK) return jr; }
       if (r->probe_stream) HIP_TRY(hipStreamSynchronize(r->probe_stream));
       if (r->alt_stream) HIP_TRY(hipStreamSynchronize(r->alt_stream));
+      if (r->vol_stream) HIP_TRY(hipStreamSynchronize(r->vol_stream)); // (timed volumetric passes of pipelined frames)
       if (r->own_stream && r->own_stream != r->stream) HIP_TRY(hipStreamSynchronize(r->own_stream));
       HIP_TRY(hipStreamSynchronize(r->stream));
    }
@@ -365,7 +380,7 @@ static float i_as_f(int i) { float f; memcpy(&f, &i, 4); return f; }
 
 // Repack the std140 images into the float4 table the kernels stage into LDS
 // (layout in mdh_device.h) and refresh the SGPR header.
-static int stream_index(const mdh_renderer *r, hipStream_t st) { return st == r->probe_stream ? 1 : (st == r->alt_stream ? 2 : (st == r->query_stream ? 3 : 0)); }
+static int stream_index(const mdh_renderer *r, hipStream_t st) { return st == r->probe_stream ? 1 : (st == r->alt_stream ? 2 : (st == r->query_stream ? 3 : (st == r->vol_stream ? 4 : 0))); }
 // before a kernel that stages the table is launched on `st`: order `st` after the table's upload
 static int table_acquire(mdh_renderer *r, hipStream_t st)
 {
@@ -567,7 +582,7 @@ static int commit_scene(mdh_renderer *r, hipStream_t up)
    if ((size_t)s.table_f4 * 16 + (size_t)MDH_SCR_PARK_ROWS * MDH_BLOCK * sizeof(float) > 64 * 1024)
       return seterr(MDH_E_INVALID, "scene tables exceed the 64 KiB LDS budget of a workgroup");
    if (t.size() > r->table_cap) { // grow the whole ring (rare: the table only grows with the primitive counts)
-      HIP_TRY(hipDeviceSynchronize());
+      { int dr = drain_streams(r); if (dr != MDH_OK) return dr; }
       r->table_cap = t.size() + 256;
       for (int q = 0; q < mdh_renderer::TAB_RING; ++q) {
          if (r->d_table_ring[q]) HIP_TRY(hipFree(r->d_table_ring[q]));
@@ -671,6 +686,7 @@ static int alloc_atlases(mdh_renderer *r)
    return MDH_OK;
 }
 
+static int rccl_api_destroy(ncclComm_t c); // (mdh_comm_* below)
 extern "C" int32_t mdh_destroy(mdh_renderer *r)
 {
    if (!r) return MDH_OK;
@@ -679,6 +695,9 @@ extern "C" int32_t mdh_destroy(mdh_renderer *r)
    if (r->alt_stream) (void)hipStreamSynchronize(r->alt_stream);
    if (r->stream) (void)hipStreamSynchronize(r->stream);
    if (r->query_stream) (void)hipStreamSynchronize(r->query_stream);
+   if (r->vol_stream) (void)hipStreamSynchronize(r->vol_stream);
+   if (r->comm) { ncclComm_t c = r->comm; r->comm = nullptr; (void)rccl_api_destroy(c); }
+   if (r->d_comm_scratch) (void)hipFree(r->d_comm_scratch);
    void *ptrs[] = {r->d_table_ring[0], r->d_table_ring[1], r->d_table_ring[2], r->d_table_ring[3], r->d_part_ring[0], r->d_part_ring[1], r->d_part_ring[2], r->d_part_ring[3], r->d_warn, r->d_query, r->d_rad_steps, r->d_rad_order, r->d_rad_hist, r->d_rad2[0], r->d_irr2[0], r->d_rad2[1], r->d_irr2[1], r->d_vis2[0], r->d_scat2[0], r->d_vis2[1], r->d_scat2[1], r->d_fb2[0], r->d_fb2[1], r->d_gb2[0][0], r->d_gb2[0][1], r->d_gb2[0][2], r->d_gb2[1][0], r->d_gb2[1][1], r->d_gb2[1][2]};
    for (void *p : ptrs)
       if (p) (void)hipFree(p);
@@ -698,6 +717,7 @@ extern "C" int32_t mdh_destroy(mdh_renderer *r)
    if (r->ev_warn) (void)hipEventDestroy(r->ev_warn);
    if (r->h_warn) (void)hipHostFree(r->h_warn);
    if (r->query_stream) (void)hipStreamDestroy(r->query_stream);
+   if (r->vol_stream) (void)hipStreamDestroy(r->vol_stream);
    for (int q = 0; q < mdh_renderer::WIN_RING; ++q) {
       if (r->h_win[q]) (void)hipHostFree(r->h_win[q]);
       if (r->ev_win[q]) (void)hipEventDestroy(r->ev_win[q]);
@@ -795,6 +815,7 @@ extern "C" int32_t mdh_create(int32_t width, int32_t height, const mdh_scene_des
       TRY_OR_FAIL(hipStreamCreateWithFlags(&r->alt_stream, hipStreamNonBlocking));
       for (hipEvent_t *e : {&r->ev_screen[0], &r->ev_screen[1], &r->ev_probe[0], &r->ev_probe[1], &r->ev_vol[0], &r->ev_vol[1], &r->ev_join, &r->ev_join_alt, &r->ev_table}) TRY_OR_FAIL(hipEventCreateWithFlags(e, hipEventDisableTiming));
       TRY_OR_FAIL(hipStreamCreateWithFlags(&r->query_stream, hipStreamNonBlocking));
+      TRY_OR_FAIL(hipStreamCreateWithFlags(&r->vol_stream, hipStreamNonBlocking));
       for (hipEvent_t *e : {&r->ev_part, &r->ev_warn}) TRY_OR_FAIL(hipEventCreateWithFlags(e, hipEventDisableTiming));
       for (int q = 0; q < mdh_renderer::TAB_RING; ++q)
          for (int si = 0; si < mdh_renderer::NSTREAMS; ++si) TRY_OR_FAIL(hipEventCreateWithFlags(&r->tab_done[q][si], hipEventDisableTiming));
@@ -841,6 +862,7 @@ extern "C" int32_t mdh_set_option(mdh_renderer *r, int32_t option, int32_t value
    if (r->in_frame && (option == MDH_OPT_ATLAS_FORMAT || option == MDH_OPT_RANK || option == MDH_OPT_WORLD || option == MDH_OPT_FRAME_OVERLAP ||
                        option == MDH_OPT_SCREEN_MODE))
       return seterr(MDH_E_STATE, "a frame is open");
+   if (r->comm && (option == MDH_OPT_RANK || option == MDH_OPT_WORLD)) return seterr(MDH_E_STATE, "rank and world belong to the communicator (mdh_comm_init)");
    switch (option) {
    case MDH_OPT_ATLAS_FORMAT:
       if (value != 0 && value != 1) return seterr(MDH_E_INVALID, "atlas format is 0 (RGB8) or 1 (fp32)");
@@ -1412,10 +1434,14 @@ static int run_pass(mdh_renderer *r, int pass, hipStream_t st, int src, int dst,
          const int ro_chunks = (int)((rays + ro_chunk - 1) / ro_chunk);
          if (r->opt_rad_order && rays >= 8192 && rays < (1l << 31)) {
             if (rays > r->rad_rays_cap) {
-               HIP_TRY(hipDeviceSynchronize());
-               for (void *q : {(void *)r->d_rad_steps, (void *)r->d_rad_order, (void *)r->d_rad_hist})
-                  if (q) HIP_TRY(hipFree(q));
-               r->d_rad_steps = nullptr; r->d_rad_order = r->d_rad_hist = nullptr;
+               // (the buffers are only ever used by radiance passes, on the probe stream or the main stream)
+               if (r->probe_stream) HIP_TRY(hipStreamSynchronize(r->probe_stream));
+               HIP_TRY(hipStreamSynchronize(r->stream));
+               r->rad_rays_cap = 0;
+               r->rad_order_rays = 0;
+               { void *q = r->d_rad_steps; r->d_rad_steps = nullptr; if (q) HIP_TRY(hipFree(q)); }
+               { void *q = r->d_rad_order; r->d_rad_order = nullptr; if (q) HIP_TRY(hipFree(q)); }
+               { void *q = r->d_rad_hist; r->d_rad_hist = nullptr; if (q) HIP_TRY(hipFree(q)); }
                HIP_TRY(hipMalloc(&r->d_rad_steps, rays));
                HIP_TRY(hipMalloc(&r->d_rad_order, rays * sizeof(unsigned)));
                HIP_TRY(hipMalloc(&r->d_rad_hist, 256 * MDH_RO_MAX_CHUNKS * sizeof(unsigned)));
@@ -1615,11 +1641,11 @@ extern "C" int32_t mdh_frame_begin(mdh_renderer *r)
          HIP_TRY(hipEventRecord(r->ev_join, r->stream));
          HIP_TRY(hipStreamWaitEvent(r->probe_stream, r->ev_join, 0));
          HIP_TRY(hipStreamWaitEvent(r->alt_stream, r->ev_join, 0));
-         HIP_TRY(hipStreamWaitEvent(r->query_stream, r->ev_join, 0)); // (the volumetric passes of pipelined frames: frame_end_passes)
+         HIP_TRY(hipStreamWaitEvent(r->vol_stream, r->ev_join, 0)); // (the volumetric passes of pipelined frames: frame_end_passes)
          r->main_dirty = false;
       } else if (r->opt_mode == 0 && r->ev_screen_valid[cur]) { // the last screen pass that read atlas set cur
          HIP_TRY(hipStreamWaitEvent(r->probe_stream, r->ev_screen[cur], 0));
-         if (r->vol.enabled) HIP_TRY(hipStreamWaitEvent(r->query_stream, r->ev_screen[cur], 0)); // (it read the froxels of set cur as well)
+         if (r->vol.enabled) HIP_TRY(hipStreamWaitEvent(r->vol_stream, r->ev_screen[cur], 0)); // (it read the froxels of set cur as well)
       }
       r->frame_cur = cur;
    }
@@ -1633,7 +1659,7 @@ static int abandon_frame(mdh_renderer *r, int rc)
    r->in_frame = false;
    r->main_dirty = true;
    if (r->probe_stream) (void)hipStreamSynchronize(r->probe_stream);
-   if (r->query_stream) (void)hipStreamSynchronize(r->query_stream);
+   if (r->vol_stream) (void)hipStreamSynchronize(r->vol_stream);
    return rc;
 }
 extern "C" int32_t mdh_frame_probe_pass(mdh_renderer *r, int32_t pass)
@@ -1676,9 +1702,9 @@ static int frame_end_passes(mdh_renderer *r)
    hipStream_t screen_stream = r->scr_parity ? r->alt_stream : r->stream;
    const int fbix = r->scr_parity;
    if (r->opt_mode == 0 && r->vol.enabled) {
-      // camera-only passes into this frame's set: on a stream of their own (the query stream), beside this frame's probe
+      // camera-only passes into this frame's set: on a stream of their own, beside this frame's probe
       // passes and the previous screen pass -- they are a few hundred wavefronts each and wait for nothing the probes make
-      hipStream_t vs = MDH_VOL_OWN_STREAM ? r->query_stream : r->probe_stream;
+      hipStream_t vs = MDH_VOL_OWN_STREAM ? r->vol_stream : r->probe_stream;
       if ((rc = run_pass(r, MDH_PASS_VISIBILITY, vs, cur, cur)) != MDH_OK) return rc;
       if ((rc = run_pass(r, MDH_PASS_SCATTERING, vs, cur, cur)) != MDH_OK) return rc;
       if (vs != r->probe_stream) {
@@ -1701,9 +1727,232 @@ extern "C" int32_t mdh_render(mdh_renderer *r)
    if (!r) return seterr(MDH_E_INVALID, "null renderer");
    int rc;
    if ((rc = mdh_frame_begin(r)) != MDH_OK) return rc;
-   if ((rc = mdh_frame_probe_pass(r, MDH_PASS_RADIANCE)) != MDH_OK || (rc = mdh_frame_probe_pass(r, MDH_PASS_IRRADIANCE)) != MDH_OK) return abandon_frame(r, rc);
+   // (with a communicator: the exchanges of the sharded schedule between the probe passes, mdh_frame_exchange)
+   if ((rc = mdh_frame_probe_pass(r, MDH_PASS_RADIANCE)) != MDH_OK || (rc = mdh_frame_exchange(r, MDH_TEX_RADIANCE)) != MDH_OK ||
+       (rc = mdh_frame_probe_pass(r, MDH_PASS_IRRADIANCE)) != MDH_OK ||
+       (!r->opt_irr_all && (rc = mdh_frame_exchange(r, MDH_TEX_IRRADIANCE)) != MDH_OK))
+      return abandon_frame(r, rc);
    return mdh_frame_end(r);
 }
+
+// ------------------------------------------------------------------ one frame on N GPUs: the communicator
+// One process per GPU; the processes' renderers join an RCCL communicator and mdh_render of every rank is then one
+// frame of the sharded schedule (include/madarch_hip.h "one frame on the N GPUs of a node").  librccl is opened on
+// first use: a process that already holds one (a PyTorch process: the wheel carries its own, same SONAME) gets that
+// one, any other the system's.
+struct RcclApi {
+   decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+   decltype(&ncclCommInitRank) CommInitRank = nullptr;
+   decltype(&ncclCommDestroy) CommDestroy = nullptr;
+   decltype(&ncclCommAbort) CommAbort = nullptr;
+   decltype(&ncclCommGetAsyncError) CommGetAsyncError = nullptr;
+   decltype(&ncclAllGather) AllGather = nullptr;
+   decltype(&ncclBroadcast) Broadcast = nullptr;
+   decltype(&ncclAllReduce) AllReduce = nullptr;
+   decltype(&ncclReduce) Reduce = nullptr;
+   decltype(&ncclGroupStart) GroupStart = nullptr;
+   decltype(&ncclGroupEnd) GroupEnd = nullptr;
+   decltype(&ncclGetErrorString) GetErrorString = nullptr;
+   bool ok = false;
+};
+static const RcclApi &rccl_api()
+{
+   static RcclApi api;
+   static std::once_flag once;
+   std::call_once(once, [] {
+      void *h = nullptr;
+      const char *env = getenv("MADARCH_HIP_RCCL_LIBRARY");
+      if (env && *env) h = dlopen(env, RTLD_NOW | RTLD_GLOBAL);
+      for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+         if (!h) h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (!h) return;
+#define MDH_RCCL_SYM(field, sym) api.field = (decltype(api.field))dlsym(h, #sym)
+      MDH_RCCL_SYM(GetUniqueId, ncclGetUniqueId); MDH_RCCL_SYM(CommInitRank, ncclCommInitRank); MDH_RCCL_SYM(CommDestroy, ncclCommDestroy);
+      MDH_RCCL_SYM(CommAbort, ncclCommAbort); MDH_RCCL_SYM(CommGetAsyncError, ncclCommGetAsyncError); MDH_RCCL_SYM(AllGather, ncclAllGather);
+      MDH_RCCL_SYM(Broadcast, ncclBroadcast); MDH_RCCL_SYM(AllReduce, ncclAllReduce); MDH_RCCL_SYM(Reduce, ncclReduce);
+      MDH_RCCL_SYM(GroupStart, ncclGroupStart); MDH_RCCL_SYM(GroupEnd, ncclGroupEnd); MDH_RCCL_SYM(GetErrorString, ncclGetErrorString);
+#undef MDH_RCCL_SYM
+      api.ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.CommAbort && api.CommGetAsyncError && api.AllGather && api.Broadcast &&
+               api.AllReduce && api.Reduce && api.GroupStart && api.GroupEnd && api.GetErrorString;
+   });
+   return api;
+}
+#define RCCL_TRY(expr)                                                                                             \
+   do {                                                                                                            \
+      ncclResult_t e_ = (expr);                                                                                    \
+      if (e_ != ncclSuccess) {                                                                                     \
+         snprintf(g_err, sizeof g_err, "%s failed: %s (%s:%d)", #expr, rccl_api().GetErrorString(e_), __FILE__, __LINE__); \
+         return MDH_E_COMM;                                                                                        \
+      }                                                                                                            \
+   } while (0)
+static int rccl_api_destroy(ncclComm_t c) { return rccl_api().ok && rccl_api().CommDestroy(c) == ncclSuccess ? MDH_OK : MDH_E_COMM; }
+static int rccl_ready()
+{
+   return rccl_api().ok ? MDH_OK : seterr(MDH_E_COMM, "librccl.so.1 cannot be loaded (or lacks a symbol): no communicator; MADARCH_HIP_RCCL_LIBRARY names another file");
+}
+
+extern "C" int32_t mdh_comm_unique_id(uint8_t id_out[MDH_COMM_ID_BYTES])
+{
+   static_assert(sizeof(ncclUniqueId) == MDH_COMM_ID_BYTES, "MDH_COMM_ID_BYTES is the size of ncclUniqueId");
+   if (!id_out) return seterr(MDH_E_INVALID, "bad argument");
+   int rc = rccl_ready();
+   if (rc != MDH_OK) return rc;
+   ncclUniqueId id;
+   RCCL_TRY(rccl_api().GetUniqueId(&id));
+   memcpy(id_out, &id, sizeof id);
+   return MDH_OK;
+}
+extern "C" int32_t mdh_comm_init(mdh_renderer *r, const uint8_t id_in[MDH_COMM_ID_BYTES], int32_t rank, int32_t world)
+{
+   if (!r || !id_in) return seterr(MDH_E_INVALID, "bad argument");
+   if (world < 1 || rank < 0 || rank >= world) return seterr(MDH_E_INVALID, "rank is not below world");
+   if (r->in_frame) return seterr(MDH_E_STATE, "a frame is open");
+   if (r->comm) return seterr(MDH_E_STATE, "the renderer already has a communicator");
+   int rc = rccl_ready();
+   if (rc != MDH_OK) return rc;
+   HIP_TRY(hipSetDevice(r->device)); // (the communicator binds to the current device)
+   if ((rc = join_main(r)) != MDH_OK) return rc;
+   ncclUniqueId id;
+   memcpy(&id, id_in, sizeof id);
+   ncclComm_t comm = nullptr;
+   RCCL_TRY(rccl_api().CommInitRank(&comm, world, id, rank));
+   if (!r->d_comm_scratch && hipMalloc(&r->d_comm_scratch, 2 * sizeof(double)) != hipSuccess) {
+      (void)rccl_api().CommAbort(comm);
+      return seterr(MDH_E_DEVICE, "hipMalloc failed");
+   }
+   r->comm = comm;
+   r->opt_rank = rank;
+   r->opt_world = world;
+   r->rad_order_rays = 0; // (the stored ray order is of another slice)
+   return MDH_OK;
+}
+static int comm_drop(mdh_renderer *r, bool abort)
+{
+   if (!r->comm) return MDH_OK;
+   ncclComm_t c = r->comm;
+   r->comm = nullptr;
+   r->opt_rank = 0;
+   r->opt_world = 1;
+   r->rad_order_rays = 0;
+   r->fb_owner[0][0] = r->fb_owner[1][0] = -1; // (the framebuffers hold a rank's tiles: cleared before they are drawn whole)
+   if (abort) RCCL_TRY(rccl_api().CommAbort(c));
+   else RCCL_TRY(rccl_api().CommDestroy(c));
+   return MDH_OK;
+}
+extern "C" int32_t mdh_comm_destroy(mdh_renderer *r)
+{
+   if (!r) return seterr(MDH_E_INVALID, "null renderer");
+   if (r->in_frame) return seterr(MDH_E_STATE, "a frame is open");
+   HIP_TRY(hipSetDevice(r->device));
+   { int dr = drain_streams(r); if (dr != MDH_OK) return dr; } // collectives in flight end first
+   return comm_drop(r, false);
+}
+// what a watchdog of the host calls (from any thread) when a collective never returns: no wait for anything
+extern "C" int32_t mdh_comm_abort(mdh_renderer *r)
+{
+   if (!r) return seterr(MDH_E_INVALID, "null renderer");
+   (void)hipSetDevice(r->device);
+   if (r->in_frame) { r->in_frame = false; r->main_dirty = true; }
+   return comm_drop(r, true);
+}
+// an asynchronous failure of the communicator (a peer died, a transport error) surfaces here
+static int comm_check(mdh_renderer *r)
+{
+   ncclResult_t ae = ncclSuccess;
+   RCCL_TRY(rccl_api().CommGetAsyncError(r->comm, &ae));
+   if (ae != ncclSuccess && ae != ncclInProgress) {
+      snprintf(g_err, sizeof g_err, "the communicator reports an asynchronous error: %s", rccl_api().GetErrorString(ae));
+      return MDH_E_COMM;
+   }
+   return MDH_OK;
+}
+// The exchange step of an open frame: every rank's slice of the atlas the open frame is producing goes to every other
+// rank, in place (the atlases are probe-major: a slice is one byte range, and a rank's input is its slice where it
+// lies in the output -- the in-place form of ncclAllGather, no staging copy), on the stream of the frame's probe
+// passes: the screen pass of the previous frame keeps running beside it.  Probe counts the world size does not
+// divide (the reference's default 36 probes on 8 ranks) go as one group of broadcasts, a slice each, which RCCL
+// fuses into one launch as well.
+extern "C" int32_t mdh_frame_exchange(mdh_renderer *r, int32_t tex)
+{
+   if (!r) return seterr(MDH_E_INVALID, "null renderer");
+   if (tex != MDH_TEX_RADIANCE && tex != MDH_TEX_IRRADIANCE) return seterr(MDH_E_INVALID, "not an atlas");
+   if (!r->in_frame) return seterr(MDH_E_STATE, "no open frame");
+   if (!r->comm || r->opt_mode != 0) return MDH_OK;
+   const RcclApi &n = rccl_api();
+   hipStream_t st = frame_probe_stream(r);
+   char *buf = (char *)(tex == MDH_TEX_RADIANCE ? r->d_rad2[r->frame_cur] : r->d_irr2[r->frame_cur]);
+   const int res = tex == MDH_TEX_RADIANCE ? r->probes.radiance_resolution : r->probes.irradiance_resolution;
+   const size_t per = (size_t)res * res * texel_bytes(r);
+   const long long P = probe_total(r), world = r->opt_world;
+   hipEvent_t e0 = nullptr, e1 = nullptr;
+   if (r->opt_timing) {
+      e0 = get_event(r);
+      e1 = get_event(r);
+      if (!e0 || !e1) return seterr(MDH_E_DEVICE, "hipEventCreate failed");
+      HIP_TRY(hipEventRecord(e0, st));
+   }
+   static const bool force_bcast = [] { const char *e = getenv("MADARCH_HIP_EXCHANGE"); return e && strcmp(e, "broadcast") == 0; }();
+   if (P % world == 0 && !force_bcast) {
+      const size_t count = per * (size_t)(P / world);
+      RCCL_TRY(n.AllGather(buf + count * (size_t)r->opt_rank, buf, count, ncclChar, r->comm, st));
+   } else {
+      RCCL_TRY(n.GroupStart());
+      for (long long q = 0; q < world; ++q) {
+         const long long b = P * q / world, e = P * (q + 1) / world; // own_probes () of rank q
+         if (e > b) {
+            ncclResult_t br = n.Broadcast(buf + per * (size_t)b, buf + per * (size_t)b, per * (size_t)(e - b), ncclChar, (int)q, r->comm, st);
+            if (br != ncclSuccess) { (void)n.GroupEnd(); snprintf(g_err, sizeof g_err, "ncclBroadcast failed: %s", n.GetErrorString(br)); return MDH_E_COMM; }
+         }
+      }
+      RCCL_TRY(n.GroupEnd());
+   }
+   if (r->opt_timing) {
+      HIP_TRY(hipEventRecord(e1, st));
+      r->pending.push_back({MDH_PASS_EXCHANGE, e0, e1});
+   }
+   return MDH_OK;
+}
+extern "C" int32_t mdh_comm_barrier(mdh_renderer *r)
+{
+   if (!r) return seterr(MDH_E_INVALID, "null renderer");
+   if (r->in_frame) return seterr(MDH_E_STATE, "a frame is open");
+   int rc = mdh_finish(r);
+   if (rc != MDH_OK || !r->comm) return rc;
+   HIP_TRY(hipMemsetAsync(r->d_comm_scratch, 0, sizeof(double), r->stream));
+   RCCL_TRY(rccl_api().AllReduce(r->d_comm_scratch, r->d_comm_scratch, 1, ncclFloat64, ncclSum, r->comm, r->stream));
+   HIP_TRY(hipStreamSynchronize(r->stream));
+   return comm_check(r);
+}
+extern "C" int32_t mdh_comm_max_f64(mdh_renderer *r, double *value)
+{
+   if (!r || !value) return seterr(MDH_E_INVALID, "bad argument");
+   if (r->in_frame) return seterr(MDH_E_STATE, "a frame is open");
+   if (!r->comm) return MDH_OK;
+   HIP_TRY(hipSetDevice(r->device));
+   { int jr = join_main(r); if (jr != MDH_OK) return jr; }
+   HIP_TRY(hipMemcpyAsync(r->d_comm_scratch + 1, value, sizeof(double), hipMemcpyHostToDevice, r->stream));
+   RCCL_TRY(rccl_api().AllReduce(r->d_comm_scratch + 1, r->d_comm_scratch + 1, 1, ncclFloat64, ncclMax, r->comm, r->stream));
+   HIP_TRY(hipMemcpyAsync(value, r->d_comm_scratch + 1, sizeof(double), hipMemcpyDeviceToHost, r->stream));
+   HIP_TRY(hipStreamSynchronize(r->stream));
+   return comm_check(r);
+}
+extern "C" int32_t mdh_comm_reduce_framebuffer(mdh_renderer *r, int32_t root)
+{
+   if (!r) return seterr(MDH_E_INVALID, "null renderer");
+   if (r->in_frame) return seterr(MDH_E_STATE, "a frame is open");
+   if (!r->comm) return MDH_OK;
+   if (root < 0 || root >= r->opt_world) return seterr(MDH_E_INVALID, "root is not a rank");
+   HIP_TRY(hipSetDevice(r->device));
+   { int jr = join_main(r); if (jr != MDH_OK) return jr; }
+   r->main_dirty = true;
+   float4 *fb = r->d_fb2[r->fb_last];
+   RCCL_TRY(rccl_api().Reduce(fb, fb, (size_t)r->W * r->H * 4, ncclFloat32, ncclSum, root, r->comm, r->stream));
+   // the root's buffer now holds every rank's tiles: its next sharded screen pass clears it first
+   if (r->opt_rank == root) r->fb_owner[r->fb_last][0] = -1;
+   HIP_TRY(hipStreamSynchronize(r->stream));
+   return comm_check(r);
+}
+
 // the stream the probe passes of the open frame run on (what a caller's collectives must be ordered on)
 extern "C" int32_t mdh_probe_stream(mdh_renderer *r, void **stream)
 {
@@ -1983,6 +2232,7 @@ extern "C" int32_t mdh_set_stream(mdh_renderer *r, void *stream)
    if (r->probe_stream) HIP_TRY(hipStreamSynchronize(r->probe_stream));
    if (r->alt_stream) HIP_TRY(hipStreamSynchronize(r->alt_stream));
    if (r->query_stream) HIP_TRY(hipStreamSynchronize(r->query_stream));
+   if (r->vol_stream) HIP_TRY(hipStreamSynchronize(r->vol_stream));
    r->stream = stream ? (hipStream_t)stream : r->own_stream;
    // the new main stream has not waited for anything: uploads and earlier work are complete (synchronised above)
    for (int si = 0; si < mdh_renderer::NSTREAMS; ++si) { r->tab_seen[si] = r->table_version; r->part_seen[si] = r->part_version; }

@@ -124,8 +124,43 @@ class Renderer:
     def Frame_Probe_Pass(self, Pass):
         self._b.check(self._b.frame_probe_pass(self._h, int(Pass)))
 
+    def Frame_Exchange(self, Tex):
+        """all-gather of the ranks' slices of an atlas, inside the library (needs Comm_Init; nothing without)"""
+        self._b.check(self._b.frame_exchange(self._h, int(Tex)))
+
     def Frame_End(self):
         self._b.check(self._b.frame_end(self._h))
+
+    # ---- one frame on N GPUs, one process per GPU: the communicator lives inside the library (RCCL)
+    def Comm_Unique_Id(self):
+        """rank 0: the 128 bytes every rank hands to Comm_Init"""
+        buf = (C.c_uint8 * B.COMM_ID_BYTES)()
+        self._b.check(self._b.comm_unique_id(buf))
+        return bytes(buf)
+
+    def Comm_Init(self, Id, Rank, World):
+        """collective: from here on Render of every rank is one frame of the sharded schedule"""
+        if len(Id) != B.COMM_ID_BYTES:
+            raise ValueError("a communicator id is %d bytes" % B.COMM_ID_BYTES)
+        buf = (C.c_uint8 * B.COMM_ID_BYTES).from_buffer_copy(Id)
+        self._b.check(self._b.comm_init(self._h, buf, int(Rank), int(World)))
+
+    def Comm_Destroy(self):
+        self._b.check(self._b.comm_destroy(self._h))
+
+    def Comm_Abort(self):
+        self._b.check(self._b.comm_abort(self._h))
+
+    def Comm_Barrier(self):
+        self._b.check(self._b.comm_barrier(self._h))
+
+    def Comm_Max(self, Value):
+        v = C.c_double(float(Value))
+        self._b.check(self._b.comm_max_f64(self._h, C.byref(v)))
+        return v.value
+
+    def Comm_Reduce_Framebuffer(self, Root=0):
+        self._b.check(self._b.comm_reduce_framebuffer(self._h, int(Root)))
 
     def Finish(self):
         self._b.check(self._b.finish(self._h))

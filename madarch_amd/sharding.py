@@ -6,7 +6,7 @@ its passes back to back); what follows is the build's own design (DESIGN.md
 
   0. Frame_Begin: the library picks the atlas set of this frame (frames are kept in flight)
   1. radiance pass for the probes [r P/N, (r+1) P/N)        -- no communication
-  2. all-gather of the radiance atlas slices                 -- RCCL over xGMI
+  2. all-gather of the radiance atlas slices                 -- RCCL over xGMI, INSIDE the library
   3. irradiance pass -- by default for ALL probes on every rank (one workgroup per probe: it
      takes as long for 512 probes as for 64, and step 4 disappears; MDH_OPT_IRRADIANCE_ALL); it
      needs the whole radiance atlas anyway (corner-sample bleed, update_probe_irradiance.glsl:26-31)
@@ -16,6 +16,14 @@ its passes back to back); what follows is the build's own design (DESIGN.md
 
 The atlases are probe-major in HBM, so a rank's slice is one contiguous byte
 range and the all-gather runs in place on the atlas itself.
+
+The exchange lives behind the C ABI: the ranks' renderers join a communicator (mdh_comm_unique_id /
+mdh_comm_init, librccl opened by the library) and Renderers.Render of every rank is then the whole
+schedule above -- `establish` below is all a host does.  torch.distributed appears here only as the
+CONTROL plane of a run (gloo, CPU tensors: handing the 128-byte id round, agreeing on a fall-back,
+barriers) and in the fall-back exchange through host memory (HostExchange) that a run takes when the
+communicator cannot be formed.  DeviceExchange (the collective issued from torch on the library's
+stream) is the earlier form, kept for callers that already own an RCCL process group.
 """
 import ctypes as C
 
@@ -32,6 +40,8 @@ class HostExchange:
 
     def __init__(self, dist, group=None, device=None):
         self.dist, self.group, self.device = dist, group, device
+
+    name = "host exchange"
 
     def all_gather(self, renderer, tex, rank, world):
         import torch
@@ -138,17 +148,128 @@ class DeviceExchange:
             self.dist.all_gather_into_tensor(full, mine, group=self.group)
 
 
+def establish(renderer, rank, world, dist, group=None, trial_frames=2, timeout_s=120.0, log=None):
+    """Form the communicator of a `world`-rank run INSIDE the library and prove it on a few frames; fall back to the
+    exchange through host memory -- in this same process, on every rank together -- when that fails anywhere.
+
+    `dist` is the control plane: a torch.distributed module whose `group` works on CPU tensors (gloo).  Returns
+    (exchange, how): (None, "rccl") when Renderers.Render now carries the exchange itself, or (HostExchange, reason).
+    A rank whose collective never returns is cut loose by a watchdog (Comm_Abort, after `timeout_s`) instead of hanging
+    the run; a rank whose renderer stays stuck even then raises."""
+    import threading
+
+    import torch
+
+    def agree(ok):  # True only if every rank says so
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+        return bool(t.item())
+
+    say = log or (lambda msg: None)
+    if world == 1:
+        return None, "single rank"
+    reason = None
+    has_comm = hasattr(renderer._b, "comm_init")
+    # 1. the id: 128 bytes from rank 0 (all zeros = rank 0 could not make one)
+    # (every rank makes one: that call is also the proof that this rank can load librccl at all -- a rank that
+    #  cannot must say so BEFORE the others enter the collective join and wait for it)
+    ident = torch.zeros(B.COMM_ID_BYTES, dtype=torch.uint8)
+    ok = has_comm
+    if has_comm:
+        try:
+            mine = renderer.Comm_Unique_Id()
+            if rank == 0:
+                ident = torch.frombuffer(bytearray(mine), dtype=torch.uint8).clone()
+        except B.MadarchError as e:
+            ok, reason = False, str(e)
+    else:
+        reason = "the engine has no communicator"
+    dist.broadcast(ident, src=0, group=group)
+    # 2. join (collective inside RCCL: only entered when every rank is going to)
+    if agree(ok):
+        joined = []
+
+        def join():
+            try:
+                renderer.Comm_Init(ident.numpy().tobytes(), rank, world)
+                joined.append(None)
+            except B.MadarchError as e:
+                joined.append(str(e))
+
+        th = threading.Thread(target=join, daemon=True)
+        th.start()
+        th.join(timeout_s)
+        if th.is_alive():
+            raise RuntimeError("rank %d: ncclCommInitRank did not return within %.0f s" % (rank, timeout_s))
+        if joined[0] is not None:
+            ok, reason = False, joined[0]
+        if not agree(ok):
+            if ok:
+                renderer.Comm_Abort()
+            ok, reason = False, reason or "a peer could not join the communicator"
+    else:
+        ok, reason = False, reason or "a peer has no communicator"
+    # 3. trial frames behind a watchdog
+    tried_frames = ok
+    if ok:
+        err = []
+
+        def trial():
+            try:
+                for _ in range(trial_frames):
+                    renderer.Render()
+                renderer.Comm_Barrier()
+            except B.MadarchError as e:
+                err.append(str(e))
+
+        th = threading.Thread(target=trial, daemon=True)
+        th.start()
+        th.join(timeout_s)
+        if th.is_alive():
+            say("rank %d: the trial frames did not return within %.0f s: aborting the communicator" % (rank, timeout_s))
+            renderer.Comm_Abort()
+            th.join(30.0)
+            if th.is_alive():
+                raise RuntimeError("rank %d: the renderer is stuck in a collective that ncclCommAbort did not release" % rank)
+            err.append("a collective did not return within %.0f s" % timeout_s)
+        if err:
+            ok, reason = False, err[0]
+            try:
+                renderer.Comm_Abort()
+            except B.MadarchError:
+                pass
+        if not agree(ok):
+            if ok:
+                renderer.Comm_Abort()
+            ok, reason = False, reason or "a peer's trial frames failed"
+    if ok:
+        return None, "rccl"
+    # the fall-back: slices through host memory over the control plane's group
+    try:
+        renderer.Finish()
+        if tried_frames:  # whatever the trial left in the atlases differs from rank to rank: start from the empty state again
+            for tex in (B.TEX_RADIANCE, B.TEX_IRRADIANCE):
+                renderer.Write_Texture(tex, np.zeros(renderer.Texture_Shape(tex), dtype=np.float32))
+    except B.MadarchError:
+        pass
+    renderer.Set_Option(B.OPT_WORLD, world)
+    renderer.Set_Option(B.OPT_RANK, rank)
+    say("rank %d: falling back to the host exchange: %s" % (rank, reason))
+    return HostExchange(dist, group), reason or "a peer fell back"
+
+
 class ShardedFrame:
     """Drives one renderer per rank through the six steps above."""
 
     def __init__(self, renderer, rank, world, exchange):
         self.R, self.rank, self.world, self.exchange = renderer, rank, world, exchange
-        renderer.Set_Option(B.OPT_WORLD, world)
-        renderer.Set_Option(B.OPT_RANK, rank)
+        if (renderer.Get_Option(B.OPT_RANK), renderer.Get_Option(B.OPT_WORLD)) != (rank, world):  # (a communicator has set them already)
+            renderer.Set_Option(B.OPT_WORLD, world)
+            renderer.Set_Option(B.OPT_RANK, rank)
 
     def Render(self):
         R = self.R
-        if self.world == 1 and self.exchange is None:  # the library's own frame
+        if self.exchange is None:  # the library's own frame: with a communicator (Comm_Init) it runs the exchanges itself
             R.Render()
             return
         # the same frame with the exchanges between its probe passes; the library keeps such frames

@@ -29,3 +29,8 @@ def test_bench_control_flow_with_n_ranks(n):
     many = _run(n, 29540 + n + (os.getpid() % 500))
     assert many["rehearsal"] and many["n_gpus"] == n and many["steps"] == 2
     assert many["frame_sha1"] == one["frame_sha1"]  # tiles and probe slices of n ranks = the whole frame
+    # the oracle has no communicator: every rank agrees on the exchange through host memory, in the same process,
+    # and the line says so; the pre-warm blocks and the serial segment ran with the same frame count on every rank
+    # (or the ranks' collectives would have paired wrongly and the frames differed)
+    assert "HOST EXCHANGE FALL-BACK" in many["parallelism"] and "no communicator" in many["parallelism"]
+    assert many["serial_segment"] and one["serial_segment"]
