@@ -144,6 +144,32 @@ package Madarch_HIP is
       N_Kinds : int; Normals_Out, Dist_Out : System.Address) return Status
      with Import, Convention => C, External_Name => "mdh_eval_distance_to";
 
+   --  One frame on the N GPUs of a node, one process per GPU (madarch_hip.h, mdh_comm_*):
+   --  every process creates its Renderer on its own device, rank 0 makes a 128-byte id and
+   --  hands it to the others (a file, an environment variable), all call Comm_Init, and
+   --  from then on Render of every rank is one frame of the sharded schedule -- probe
+   --  slices, RCCL all-gather inside the library, interleaved screen tiles.
+   Comm_Id_Bytes : constant := 128;
+   type Comm_Id is array (0 .. Comm_Id_Bytes - 1) of Interfaces.C.unsigned_char
+     with Convention => C;
+
+   function Comm_Unique_Id (Id_Out : access Comm_Id) return Status
+     with Import, Convention => C, External_Name => "mdh_comm_unique_id";
+
+   function Comm_Init
+     (R : Handle; Id : access constant Comm_Id; Rank, World : int) return Status
+     with Import, Convention => C, External_Name => "mdh_comm_init";
+
+   function Comm_Destroy (R : Handle) return Status
+     with Import, Convention => C, External_Name => "mdh_comm_destroy";
+
+   function Comm_Barrier (R : Handle) return Status
+     with Import, Convention => C, External_Name => "mdh_comm_barrier";
+
+   --  the ranks' tiles of the last frame summed into Root's framebuffer (what its window shows)
+   function Comm_Reduce_Framebuffer (R : Handle; Root : int) return Status
+     with Import, Convention => C, External_Name => "mdh_comm_reduce_framebuffer";
+
    function Last_Error return Strings.chars_ptr
      with Import, Convention => C, External_Name => "mdh_last_error";
 end Madarch_HIP;

@@ -237,7 +237,12 @@ enum {
    /* Scheduling only, no effect on any texel: 1 (default) = the radiance pass records every probe ray's primary-march
     * length and the next frame's pass takes the rays sorted by it (a wavefront pays the longest march among its 64
     * rays); 0 = rays in probe order. */
-   MDH_OPT_RADIANCE_ORDER = 14
+   MDH_OPT_RADIANCE_ORDER = 14,
+   /* Scheduling only, no effect on any pixel: 1 (default) = a screen pass records how long every 8x8 tile's wavefront
+    * took, and later passes start the tiles in that order, slowest first (a pass ends with its slowest wavefront: in
+    * image order the passes of the reference's scenes spend 15 - 45 % of their time waiting for a few late, long
+    * tiles); re-sorted after camera moves and geometry edits; 0 = tiles in image order. */
+   MDH_OPT_SCREEN_ORDER = 15
 };
 
 /* passes of Renderers.Render (madarch-renderers.adb:302-321) */

@@ -229,6 +229,18 @@ struct mdh_renderer {
    int rad_order_age = 0;                  // radiance passes since the rays were sorted
    unsigned long rad_order_scene = 0, geometry_edits = 0; // primitives set or added when the rays were sorted / so far
    int opt_rad_order = MDH_RAD_ORDER_DEFAULT;
+   // MDH_OPT_SCREEN_ORDER (ScreenArgs, mdh_kernels.h): the screen pass's tiles in the order of their wavefronts' durations
+   unsigned char *d_scr_cost = nullptr;          // [tiles] sort keys, written by the pass that is followed by a sort
+   unsigned *d_scr_order[2] = {nullptr, nullptr}; // [tiles] two buffers: passes in flight keep reading the one they were launched with
+   unsigned *d_scr_hist = nullptr;
+   int scr_order_cur = -1;                       // the buffer that holds the order (-1: none)
+   int scr_order_n = 0, scr_order_rank = -1, scr_order_world = -1; // what that order is of
+   int scr_order_age = 0;                        // screen passes since the tiles were sorted
+   unsigned long scr_order_geom = 0;             // geometry_edits when they were
+   float scr_order_cam[12] = {0};                // the camera then
+   hipEvent_t ev_scr_sort = nullptr, ev_scr_other = nullptr;
+   unsigned long long scr_sort_version = 0, scr_sort_seen[NSTREAMS] = {0, 0, 0, 0, 0};
+   int opt_scr_order = 1;
    std::map<std::pair<const void *, size_t>, int> resident; // workgroups per CU of (kernel, LDS bytes): rad_first_round
    int last = 0;
    int opt_overlap = 2;
@@ -243,6 +255,7 @@ struct mdh_renderer {
    bool alt_pending = false; // work on alt_stream that `stream` has not been ordered after yet
    // an open frame (mdh_frame_begin .. mdh_frame_end)
    bool in_frame = false, frame_pipelined = false;
+   bool in_frame_passes = false; // run_pass is called for the passes that end an open frame (frame_end_passes)
    int frame_cur = 0;
    int scr_parity = 0; // which screen stream / framebuffer the last pipelined frame drew on
    bool main_dirty = true; // work went to `stream` outside a pipelined frame since the probe stream last joined it
@@ -372,6 +385,26 @@ static void own_probes(const mdh_renderer *r, int *b, int *e)
    *e = (int)(P * (rank + 1) / r->opt_world);
 }
 
+// the partition table of a renderer: [cell][kinds + Index_Count] ints (what the reference's SSBO holds, mdh_read_partitioning),
+// then the same candidate sets as bits, [cell][words] (partitioning_closest_bits, mdh_device.h)
+// (the bits start on a 16-byte boundary and are a whole number of float4: workgroups stage them into LDS 16 bytes at a time)
+static size_t part_table_ints(const mdh_renderer *r) { return ((size_t)r->part_cells * (r->npk + r->part.index_count) + 3) / 4 * 4; }
+static int part_mask_words(const mdh_renderer *r)
+{
+   int declared = 0;
+   for (int k = 0; k < r->npk; ++k) declared += r->pk[k].max_count;
+   return declared > 0 ? (declared + 31) / 32 : 1;
+}
+static size_t part_bits_ints(const mdh_renderer *r) { return ((size_t)r->part_cells * part_mask_words(r) + 3) / 4 * 4; }
+static size_t part_buffer_ints(const mdh_renderer *r) { return part_table_ints(r) + part_bits_ints(r); }
+// The bits of the whole grid are staged into LDS by every workgroup when they are small (the reference's simple_scene:
+// 2000 cells x 2 words = 16 KB): a march step then reads no memory at all.  Larger grids read their cells' words from
+// memory (L1 / L2).
+#ifndef MDH_PART_BITS_LDS_MAX
+#define MDH_PART_BITS_LDS_MAX 0 // (measured: off.  Staged, simple_scene's 16 KB leave room for five workgroups per CU instead of seven and
+                                // its screen pass takes 0.78 instead of 0.70 ms, although no march step reads memory any more)
+#endif
+static int part_bits_f4(const mdh_renderer *r) { return r->part.enable && part_bits_ints(r) * 4 <= MDH_PART_BITS_LDS_MAX ? (int)(part_bits_ints(r) / 4) : 0; }
 static float rd_f(const mdh_renderer *r, int off) { float f; memcpy(&f, r->scene_ubo.data() + off, 4); return f; }
 static int rd_i(const mdh_renderer *r, int off) { int32_t i; memcpy(&i, r->scene_ubo.data() + off, 4); return i; }
 static float4 mk4(float x, float y, float z, float w) { float4 v; v.x = x; v.y = y; v.z = z; v.w = w; return v; }
@@ -576,10 +609,11 @@ static int commit_scene(mdh_renderer *r, hipStream_t up)
    s.u8_slot = (int)t.size();
    for (int k = 0; k < 256; k += 4) t.push_back(mk4((float)k / 255.0f, (float)(k + 1) / 255.0f, (float)(k + 2) / 255.0f, (float)(k + 3) / 255.0f));
 #endif
+   for (int k = 0; k < r->npk; ++k) { H[H_KQUAD + 4 * k] = H[H_KTYPE + k]; H[H_KQUAD + 4 * k + 1] = H[H_KSLOT + k]; H[H_KQUAD + 4 * k + 2] = H[H_KBASE + k]; H[H_KQUAD + 4 * k + 3] = H[H_KMAX + k]; }
    memcpy(t.data(), H, sizeof H);
    s.table_f4 = (int)t.size();
    // (the march kernels park MDH_PARK_DWORDS floats per thread behind the table, lds_bytes_march)
-   if ((size_t)s.table_f4 * 16 + (size_t)MDH_SCR_PARK_ROWS * MDH_BLOCK * sizeof(float) > 64 * 1024)
+   if ((size_t)(s.table_f4 + part_bits_f4(r)) * 16 + (size_t)MDH_SCR_PARK_ROWS * MDH_BLOCK * sizeof(float) > 64 * 1024)
       return seterr(MDH_E_INVALID, "scene tables exceed the 64 KiB LDS budget of a workgroup");
    if (t.size() > r->table_cap) { // grow the whole ring (rare: the table only grows with the primitive counts)
       { int dr = drain_streams(r); if (dr != MDH_OK) return dr; }
@@ -617,6 +651,9 @@ static int commit_scene(mdh_renderer *r, hipStream_t up)
       if (!pow2) s.part_sp_pow2 = 0;
    }
    s.part_table = r->d_part_ring[r->part_slot];
+   s.part_mask_off = (int)part_table_ints(r);
+   s.part_mask_words = part_mask_words(r);
+   s.part_bits_f4 = part_bits_f4(r);
    r->table_dirty = false;
    return MDH_OK;
 }
@@ -698,7 +735,7 @@ extern "C" int32_t mdh_destroy(mdh_renderer *r)
    if (r->vol_stream) (void)hipStreamSynchronize(r->vol_stream);
    if (r->comm) { ncclComm_t c = r->comm; r->comm = nullptr; (void)rccl_api_destroy(c); }
    if (r->d_comm_scratch) (void)hipFree(r->d_comm_scratch);
-   void *ptrs[] = {r->d_table_ring[0], r->d_table_ring[1], r->d_table_ring[2], r->d_table_ring[3], r->d_part_ring[0], r->d_part_ring[1], r->d_part_ring[2], r->d_part_ring[3], r->d_warn, r->d_query, r->d_rad_steps, r->d_rad_order, r->d_rad_hist, r->d_rad2[0], r->d_irr2[0], r->d_rad2[1], r->d_irr2[1], r->d_vis2[0], r->d_scat2[0], r->d_vis2[1], r->d_scat2[1], r->d_fb2[0], r->d_fb2[1], r->d_gb2[0][0], r->d_gb2[0][1], r->d_gb2[0][2], r->d_gb2[1][0], r->d_gb2[1][1], r->d_gb2[1][2]};
+   void *ptrs[] = {r->d_table_ring[0], r->d_table_ring[1], r->d_table_ring[2], r->d_table_ring[3], r->d_part_ring[0], r->d_part_ring[1], r->d_part_ring[2], r->d_part_ring[3], r->d_warn, r->d_query, r->d_rad_steps, r->d_rad_order, r->d_rad_hist, r->d_scr_cost, r->d_scr_order[0], r->d_scr_order[1], r->d_scr_hist, r->d_rad2[0], r->d_irr2[0], r->d_rad2[1], r->d_irr2[1], r->d_vis2[0], r->d_scat2[0], r->d_vis2[1], r->d_scat2[1], r->d_fb2[0], r->d_fb2[1], r->d_gb2[0][0], r->d_gb2[0][1], r->d_gb2[0][2], r->d_gb2[1][0], r->d_gb2[1][1], r->d_gb2[1][2]};
    for (void *p : ptrs)
       if (p) (void)hipFree(p);
    for (auto &p : r->pending) { (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1); }
@@ -713,6 +750,8 @@ extern "C" int32_t mdh_destroy(mdh_renderer *r)
    for (int q = 0; q < mdh_renderer::PART_RING; ++q)
       for (int si = 0; si < mdh_renderer::NSTREAMS; ++si)
          if (r->part_done[q][si]) (void)hipEventDestroy(r->part_done[q][si]);
+   if (r->ev_scr_sort) (void)hipEventDestroy(r->ev_scr_sort);
+   if (r->ev_scr_other) (void)hipEventDestroy(r->ev_scr_other);
    if (r->ev_part) (void)hipEventDestroy(r->ev_part);
    if (r->ev_warn) (void)hipEventDestroy(r->ev_warn);
    if (r->h_warn) (void)hipHostFree(r->h_warn);
@@ -814,8 +853,10 @@ extern "C" int32_t mdh_create(int32_t width, int32_t height, const mdh_scene_des
       TRY_OR_FAIL(hipStreamCreateWithPriority(&r->probe_stream, hipStreamNonBlocking, prio));
       TRY_OR_FAIL(hipStreamCreateWithFlags(&r->alt_stream, hipStreamNonBlocking));
       for (hipEvent_t *e : {&r->ev_screen[0], &r->ev_screen[1], &r->ev_probe[0], &r->ev_probe[1], &r->ev_vol[0], &r->ev_vol[1], &r->ev_join, &r->ev_join_alt, &r->ev_table}) TRY_OR_FAIL(hipEventCreateWithFlags(e, hipEventDisableTiming));
-      TRY_OR_FAIL(hipStreamCreateWithFlags(&r->query_stream, hipStreamNonBlocking));
-      TRY_OR_FAIL(hipStreamCreateWithFlags(&r->vol_stream, hipStreamNonBlocking));
+      // (HIP maps a process's streams onto a few hardware queues, four by default: a fifth stream shares one with another
+      //  and their work serialises -- measured: light_shafts lost a fifth of its frame rate.  So the volumetric stream exists
+      //  only with volumetrics, and the query stream from the first Eval_Distance_To on.)
+      if (vol->enabled) TRY_OR_FAIL(hipStreamCreateWithFlags(&r->vol_stream, hipStreamNonBlocking));
       for (hipEvent_t *e : {&r->ev_part, &r->ev_warn}) TRY_OR_FAIL(hipEventCreateWithFlags(e, hipEventDisableTiming));
       for (int q = 0; q < mdh_renderer::TAB_RING; ++q)
          for (int si = 0; si < mdh_renderer::NSTREAMS; ++si) TRY_OR_FAIL(hipEventCreateWithFlags(&r->tab_done[q][si], hipEventDisableTiming));
@@ -843,7 +884,8 @@ extern "C" int32_t mdh_create(int32_t width, int32_t height, const mdh_scene_des
       TRY_OR_FAIL(hipMemsetAsync(r->d_scat2[s], 0, (scat_n ? scat_n : 1) * sizeof(float4), r->stream));
    }
    if (r->part.enable) {
-      size_t n = (size_t)r->part_cells * (r->npk + r->part.index_count);
+      if (part_buffer_ints(r) >= (1ull << 31)) { seterr(MDH_E_INVALID, "a partition table of 2^31 ints or more"); return fail(MDH_E_INVALID); }
+      size_t n = part_buffer_ints(r);
       for (int q = 0; q < mdh_renderer::PART_RING; ++q) {
          TRY_OR_FAIL(hipMalloc(&r->d_part_ring[q], n * 4));
          TRY_OR_FAIL(hipMemsetAsync(r->d_part_ring[q], 0, n * 4, r->stream));
@@ -892,6 +934,7 @@ extern "C" int32_t mdh_set_option(mdh_renderer *r, int32_t option, int32_t value
    case MDH_OPT_INDIRECT_SPECULAR: if (value < 0 || value > 3) return seterr(MDH_E_INVALID, "indirect specular mode is 0 .. 3"); r->opt_spec = value; break;
    case MDH_OPT_HYSTERESIS_PERMILLE: if (value < 0 || value > 999) return seterr(MDH_E_INVALID, "hysteresis is 0 .. 999 per mille"); r->opt_hyst = value; break;
    case MDH_OPT_RADIANCE_ORDER: r->opt_rad_order = value ? 1 : 0; r->rad_order_rays = 0; break;
+   case MDH_OPT_SCREEN_ORDER: r->opt_scr_order = value ? 1 : 0; r->scr_order_cur = -1; break;
    default: return seterr(MDH_E_INVALID, "unknown option");
    }
    return MDH_OK;
@@ -915,6 +958,7 @@ extern "C" int32_t mdh_get_option(mdh_renderer *r, int32_t option, int32_t *valu
    case MDH_OPT_INDIRECT_SPECULAR: *value = r->opt_spec; break;
    case MDH_OPT_HYSTERESIS_PERMILLE: *value = r->opt_hyst; break;
    case MDH_OPT_RADIANCE_ORDER: *value = r->opt_rad_order; break;
+   case MDH_OPT_SCREEN_ORDER: *value = r->opt_scr_order; break;
    default: return seterr(MDH_E_INVALID, "unknown option");
    }
    return MDH_OK;
@@ -1004,7 +1048,9 @@ static int ensure_committed(mdh_renderer *r, hipStream_t up = nullptr)
    if (r->table_dirty) return commit_scene(r, up ? up : r->stream);
    return MDH_OK;
 }
-static size_t lds_bytes(const mdh_renderer *r) { return (size_t)r->ks.table_f4 * sizeof(float4); }
+// for kernels that never look a cell up (the builders, the distance query): no bits staged behind the scene table
+static KScene ks_no_bits(const mdh_renderer *r) { KScene k = r->ks; k.part_bits_f4 = 0; return k; }
+static size_t lds_bytes(const mdh_renderer *r) { return (size_t)(r->ks.table_f4 + r->ks.part_bits_f4) * sizeof(float4); }
 // the march kernels park MDH_PARK_DWORDS floats per thread behind the table (mdh_march.h)
 static size_t lds_bytes_march(const mdh_renderer *r) { return lds_bytes(r) + (size_t)MDH_PARK_DWORDS * MDH_BLOCK * sizeof(float); }
 // the screen pass runs without the visibility queue, whose entries, first steps and result words are the park
@@ -1288,15 +1334,18 @@ extern "C" int32_t mdh_update_partitioning(mdh_renderer *r, int32_t method)
    // The builders write a cell's counts and the candidates it found, nothing else: entries behind them and cells
    // outside the builder's grid (GPU_Fast on odd dimensions) keep what the table held before, in the
    // reference's single buffer.  So the next buffer starts as a copy of the current one (tens of KiB).
-   const size_t total = (size_t)r->part_cells * (r->npk + r->part.index_count);
+   const size_t total = part_buffer_ints(r); // (the lists and their bits)
    const int cells = a.gx * a.gy * a.gz;
    if ((rc = table_acquire(r, up)) != MDH_OK) return rc; // (also orders `up` after the previous build)
    HIP_TRY(hipMemcpyAsync(r->d_part_ring[ns], r->d_part_ring[r->part_slot], total * 4, hipMemcpyDeviceToDevice, up));
    HIP_TRY(hipMemsetAsync(r->d_warn, 0, 4, up));
    if (cells > 0) {
-      hipLaunchKernelGGL(k_partition_build, dim3((cells + 63) / 64), dim3(64), lds_bytes(r), up, r->ks, a);
+      hipLaunchKernelGGL(k_partition_build, dim3((cells + 63) / 64), dim3(64), lds_bytes(r), up, ks_no_bits(r), a);
       HIP_TRY(hipGetLastError());
    }
+   // the lists once more as bits, for every cell (cells the builder left alone keep their lists, and so their bits)
+   hipLaunchKernelGGL(k_partition_bits, dim3((r->part_cells + 63) / 64), dim3(64), lds_bytes(r), up, ks_no_bits(r), r->d_part_ring[ns]);
+   HIP_TRY(hipGetLastError());
    if ((rc = table_release(r, up)) != MDH_OK) return rc; // (the copy read the current buffer)
    HIP_TRY(hipMemcpyAsync(r->h_warn, r->d_warn, 4, hipMemcpyDeviceToHost, up));
    HIP_TRY(hipEventRecord(r->ev_warn, up));
@@ -1556,6 +1605,41 @@ static int run_pass(mdh_renderer *r, int pass, hipStream_t st, int src, int dst,
          HIP_TRY(hipMemsetAsync(r->d_fb2[fbix], 0, (size_t)r->W * r->H * sizeof(float4), st));
       r->fb_owner[fbix][0] = a.rank; r->fb_owner[fbix][1] = a.world;
       int own_tiles = (a.n_tiles - a.rank + a.world - 1) / a.world;
+      a.n_own = own_tiles;
+      a.order = nullptr;
+      a.cost = nullptr;
+      // MDH_OPT_SCREEN_ORDER: the tiles in the order of an earlier pass's wavefront durations, slowest first
+      bool sort_after = false;
+      const int si_st = stream_index(r, st);
+      if (r->opt_scr_order && own_tiles >= 2048) {
+         if (!r->d_scr_cost) {
+            HIP_TRY(hipMalloc(&r->d_scr_cost, a.n_tiles));
+            for (int q = 0; q < 2; ++q) HIP_TRY(hipMalloc(&r->d_scr_order[q], (size_t)a.n_tiles * sizeof(unsigned)));
+            HIP_TRY(hipMalloc(&r->d_scr_hist, 256 * MDH_RO_MAX_CHUNKS * sizeof(unsigned)));
+            HIP_TRY(hipEventCreateWithFlags(&r->ev_scr_sort, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&r->ev_scr_other, hipEventDisableTiming));
+         }
+         float cam_now[12];
+         memcpy(cam_now, r->cam_pos, 12); memcpy(cam_now + 3, r->cam_m, 36);
+         const bool have = r->scr_order_cur >= 0 && r->scr_order_n == own_tiles && r->scr_order_rank == a.rank && r->scr_order_world == a.world;
+         if (have) {
+            a.order = r->d_scr_order[r->scr_order_cur];
+            if (r->scr_sort_seen[si_st] != r->scr_sort_version) { // the sort ran on another stream
+               HIP_TRY(hipStreamWaitEvent(st, r->ev_scr_sort, 0));
+               r->scr_sort_seen[si_st] = r->scr_sort_version;
+            }
+         }
+         // which tiles are slow follows the camera and the geometry: sorted again when either changed since (at most every
+         // MDH_RAD_RESORT_MOVING passes: a stale order costs speed only) and every MDH_RAD_RESORT passes besides
+         ++r->scr_order_age;
+         const bool moved = memcmp(cam_now, r->scr_order_cam, sizeof cam_now) != 0 || r->scr_order_geom != r->geometry_edits;
+         if (!have || r->scr_order_age >= MDH_RAD_RESORT || (moved && r->scr_order_age >= MDH_RAD_RESORT_MOVING)) {
+            sort_after = true;
+            a.cost = r->d_scr_cost;
+            memcpy(r->scr_order_cam, cam_now, sizeof cam_now);
+         }
+      } else
+         r->scr_order_cur = -1;
       if (own_tiles > 0) {
          int blocks = (own_tiles + (MDH_BLOCK / 64) - 1) / (MDH_BLOCK / 64);
          if (jit) {
@@ -1569,6 +1653,46 @@ static int run_pass(mdh_renderer *r, int pass, hipStream_t st, int src, int dst,
          case 2: launch_screen_m<2>(r, st, pr, vol, cam, a, blocks, pow2); break;
          default: launch_screen_m<3>(r, st, pr, vol, cam, a, blocks, pow2); break;
          }
+      }
+      if (sort_after) { // later passes' order from this pass's durations, into the buffer no pass in flight reads
+         HIP_TRY(hipGetLastError());
+         const int nb = r->scr_order_cur == 0 ? 1 : 0;
+         // (passes that read that buffer were launched before the previous sort; on the other screen stream nothing
+         //  orders them against this stream when no probe passes run: wait for what that stream holds)
+         hipStream_t other = st == r->alt_stream ? r->stream : r->alt_stream;
+         if (other && other != st && r->scr_order_cur >= 0) {
+            HIP_TRY(hipEventRecord(r->ev_scr_other, other));
+            HIP_TRY(hipStreamWaitEvent(st, r->ev_scr_other, 0));
+         }
+         const long chunk = std::max(2048l, (((long)own_tiles + MDH_RO_MAX_CHUNKS - 1) / MDH_RO_MAX_CHUNKS + 1023) / 1024 * 1024);
+         const int chunks = (int)((own_tiles + chunk - 1) / chunk);
+         // Sorted as a whole every screen pass measured is faster on its own (BASELINE config 3: +4.5 %, config 2: +59 %,
+         // config 5's frame on one GPU: +7 %) and, with frames in flight, every frame but one kind: where the probe passes
+         // are a large share of the frame (config 3 at 1080p: 524 288 probe rays for 2 M pixels), a screen pass that
+         // holds every wavefront slot to its very end keeps the NEXT frame's probe passes -- the head of that frame's
+         // dependency chain -- waiting for slots that the thin tail of an image-order pass hands over early: -3 %.
+         // There only the tiles that took twice the median and more go to the front (the ones that make the tail) and
+         // all others keep their place: +-0 in flight (profiles/r03_x_screen_tile_order.log).
+         // MADARCH_HIP_ORDER_FLOOR (thousandths of the median) overrides, for experiments.
+         static const int floor_env = [] { const char *e = getenv("MADARCH_HIP_ORDER_FLOOR"); return e ? atoi(e) : -1; }();
+         const long probe_rays = r->opt_mode == 0 ? (long)(pr.probe_end - pr.probe_begin) * pr.rres * pr.rres : 0;
+         const bool probe_heavy = probe_rays * 10 >= (long)own_tiles * 64;
+         const int floor_permille = floor_env >= 0 ? floor_env : (r->frame_pipelined && r->in_frame_passes && probe_heavy ? 2000 : 0);
+         hipLaunchKernelGGL(k_rad_hist, dim3(chunks), dim3(256), 0, st, (const unsigned char *)r->d_scr_cost, own_tiles, (int)chunk, r->d_scr_hist);
+         if (floor_permille > 0) {
+            hipLaunchKernelGGL(k_order_floor, dim3(chunks), dim3(256), 0, st, r->d_scr_cost, own_tiles, (int)chunk, (const unsigned *)r->d_scr_hist, chunks, floor_permille);
+            hipLaunchKernelGGL(k_rad_hist, dim3(chunks), dim3(256), 0, st, (const unsigned char *)r->d_scr_cost, own_tiles, (int)chunk, r->d_scr_hist);
+         }
+         hipLaunchKernelGGL(k_rad_scan, dim3(1), dim3(256), 0, st, r->d_scr_hist, chunks);
+         hipLaunchKernelGGL(k_order_scatter_stable, dim3(chunks), dim3(256), 0, st, (const unsigned char *)r->d_scr_cost, own_tiles, (int)chunk, (const unsigned *)r->d_scr_hist, r->d_scr_order[nb]);
+         HIP_TRY(hipGetLastError());
+         HIP_TRY(hipEventRecord(r->ev_scr_sort, st));
+         ++r->scr_sort_version;
+         r->scr_sort_seen[si_st] = r->scr_sort_version;
+         r->scr_order_cur = nb;
+         r->scr_order_n = own_tiles; r->scr_order_rank = a.rank; r->scr_order_world = a.world;
+         r->scr_order_age = 0;
+         r->scr_order_geom = r->geometry_edits;
       }
       break;
    }
@@ -1641,11 +1765,11 @@ extern "C" int32_t mdh_frame_begin(mdh_renderer *r)
          HIP_TRY(hipEventRecord(r->ev_join, r->stream));
          HIP_TRY(hipStreamWaitEvent(r->probe_stream, r->ev_join, 0));
          HIP_TRY(hipStreamWaitEvent(r->alt_stream, r->ev_join, 0));
-         HIP_TRY(hipStreamWaitEvent(r->vol_stream, r->ev_join, 0)); // (the volumetric passes of pipelined frames: frame_end_passes)
+         if (r->vol_stream) HIP_TRY(hipStreamWaitEvent(r->vol_stream, r->ev_join, 0)); // (the volumetric passes of pipelined frames: frame_end_passes)
          r->main_dirty = false;
       } else if (r->opt_mode == 0 && r->ev_screen_valid[cur]) { // the last screen pass that read atlas set cur
          HIP_TRY(hipStreamWaitEvent(r->probe_stream, r->ev_screen[cur], 0));
-         if (r->vol.enabled) HIP_TRY(hipStreamWaitEvent(r->vol_stream, r->ev_screen[cur], 0)); // (it read the froxels of set cur as well)
+         if (r->vol_stream) HIP_TRY(hipStreamWaitEvent(r->vol_stream, r->ev_screen[cur], 0)); // (it read the froxels of set cur as well)
       }
       r->frame_cur = cur;
    }
@@ -1679,7 +1803,9 @@ extern "C" int32_t mdh_frame_end(mdh_renderer *r)
    if (!r) return seterr(MDH_E_INVALID, "null renderer");
    if (!r->in_frame) return seterr(MDH_E_STATE, "no open frame");
    r->in_frame = false;
+   r->in_frame_passes = true;
    const int rc = frame_end_passes(r);
+   r->in_frame_passes = false;
    return rc == MDH_OK ? bound_timing(r) : abandon_frame(r, rc);
 }
 static int frame_end_passes(mdh_renderer *r)
@@ -1704,7 +1830,7 @@ static int frame_end_passes(mdh_renderer *r)
    if (r->opt_mode == 0 && r->vol.enabled) {
       // camera-only passes into this frame's set: on a stream of their own, beside this frame's probe
       // passes and the previous screen pass -- they are a few hundred wavefronts each and wait for nothing the probes make
-      hipStream_t vs = MDH_VOL_OWN_STREAM ? r->vol_stream : r->probe_stream;
+      hipStream_t vs = MDH_VOL_OWN_STREAM && r->vol_stream ? r->vol_stream : r->probe_stream;
       if ((rc = run_pass(r, MDH_PASS_VISIBILITY, vs, cur, cur)) != MDH_OK) return rc;
       if ((rc = run_pass(r, MDH_PASS_SCATTERING, vs, cur, cur)) != MDH_OK) return rc;
       if (vs != r->probe_stream) {
@@ -2056,11 +2182,13 @@ extern "C" int32_t mdh_read_gbuffer(mdh_renderer *r, int32_t *index_out, float *
 static int atlas_set(const mdh_renderer *r) { return r->in_frame ? r->frame_cur : r->last; }
 static hipStream_t atlas_stream(const mdh_renderer *r) { return r->in_frame ? frame_probe_stream(r) : r->stream; }
 // host copies of the probe-major atlases as float RGB per texel
-static int atlas_to_host(mdh_renderer *r, int tex, std::vector<float> &rgb)
+// (texels [first, first + n) of the probe-major atlas; n = 0: all of it)
+static int atlas_to_host(mdh_renderer *r, int tex, std::vector<float> &rgb, size_t first = 0, size_t n = 0)
 {
    int res = tex == MDH_TEX_RADIANCE ? r->probes.radiance_resolution : r->probes.irradiance_resolution;
-   size_t n = (size_t)probe_total(r) * res * res;
-   void *src = tex == MDH_TEX_RADIANCE ? r->d_rad2[atlas_set(r)] : r->d_irr2[atlas_set(r)];
+   if (n == 0 && first == 0) n = (size_t)probe_total(r) * res * res;
+   const char *src = (const char *)(tex == MDH_TEX_RADIANCE ? r->d_rad2[atlas_set(r)] : r->d_irr2[atlas_set(r)]) + first * texel_bytes(r);
+   if (n == 0) { rgb.clear(); return MDH_OK; }
    hipStream_t st = atlas_stream(r);
    if (!r->in_frame) { int jr = join_main(r); if (jr != MDH_OK) return jr; }
    rgb.resize(n * 3);
@@ -2178,12 +2306,13 @@ extern "C" int32_t mdh_read_atlas_slice(mdh_renderer *r, int32_t tex, int32_t pr
    if (!r || (tex != MDH_TEX_RADIANCE && tex != MDH_TEX_IRRADIANCE) || !out) return seterr(MDH_E_INVALID, "bad argument");
    if (probe_begin < 0 || n_probes < 0 || probe_begin + n_probes > probe_total(r)) return seterr(MDH_E_INDEX, "probe range");
    HIP_TRY(hipSetDevice(r->device));
-   std::vector<float> rgb;
-   int rc = atlas_to_host(r, tex, rgb);
-   if (rc != MDH_OK) return rc;
+   if (n_probes == 0) return MDH_OK;
+   // the slice only: one device-to-host copy of its bytes (a sharded run's host exchange reads its own slice every frame)
    int res = tex == MDH_TEX_RADIANCE ? r->probes.radiance_resolution : r->probes.irradiance_resolution;
-   size_t per = (size_t)res * res * 3;
-   memcpy(out, &rgb[(size_t)probe_begin * per], (size_t)n_probes * per * 4);
+   std::vector<float> rgb;
+   int rc = atlas_to_host(r, tex, rgb, (size_t)probe_begin * res * res, (size_t)n_probes * res * res);
+   if (rc != MDH_OK) return rc;
+   memcpy(out, rgb.data(), rgb.size() * sizeof(float));
    return MDH_OK;
 }
 extern "C" int32_t mdh_write_atlas_slice(mdh_renderer *r, int32_t tex, int32_t probe_begin, int32_t n_probes, const float *in)
@@ -2248,6 +2377,8 @@ extern "C" int32_t mdh_eval_distance_to(mdh_renderer *r, int32_t n, const float 
       if (kind_ixs[i] < 0 || kind_ixs[i] >= r->npk) return seterr(MDH_E_INVALID, "bad kind index");
    if (n == 0) return MDH_OK;
    // on a stream of its own: the query waits for the table it reads, not for the frames in flight
+   HIP_TRY(hipSetDevice(r->device));
+   if (!r->query_stream) HIP_TRY(hipStreamCreateWithFlags(&r->query_stream, hipStreamNonBlocking));
    hipStream_t qs = r->query_stream;
    int rc = ensure_committed(r, qs);
    if (rc != MDH_OK) return rc;
@@ -2263,8 +2394,8 @@ extern "C" int32_t mdh_eval_distance_to(mdh_renderer *r, int32_t n, const float 
    for (int i = 0; i < MDH_MAX_KINDS; ++i) { a.kinds[i] = i < n_kinds ? kind_ixs[i] : 0; a.host_count[i] = r->host_count[i]; }
    a.pts = d_pts; a.normals = d_n; a.dist = d_d;
    if ((rc = table_acquire(r, qs)) != MDH_OK) return rc;
-   if (r->opt_ada_div) hipLaunchKernelGGL(k_eval_distance<true>, dim3((n + 63) / 64), dim3(64), lds_bytes(r), qs, r->ks, a);
-   else hipLaunchKernelGGL(k_eval_distance<false>, dim3((n + 63) / 64), dim3(64), lds_bytes(r), qs, r->ks, a);
+   if (r->opt_ada_div) hipLaunchKernelGGL(k_eval_distance<true>, dim3((n + 63) / 64), dim3(64), lds_bytes(r), qs, ks_no_bits(r), a);
+   else hipLaunchKernelGGL(k_eval_distance<false>, dim3((n + 63) / 64), dim3(64), lds_bytes(r), qs, ks_no_bits(r), a);
    HIP_TRY(hipGetLastError());
    if ((rc = table_release(r, qs)) != MDH_OK) return rc;
    HIP_TRY(hipMemcpyAsync(dist_out, d_d, (size_t)n * 4, hipMemcpyDeviceToHost, qs));

@@ -61,7 +61,9 @@ struct KScene {
    int part_sp_pow2; // all three spacings are powers of two: part_inv_sp holds their exact reciprocals (x / 2^k == x * 2^-k)
    float part_inv_sp[3];
    const float4 *table;   // HBM image of the table (staged to LDS by every workgroup)
-   const int *part_table; // [cell][nk + index_count]
+   const int *part_table; // [cell][nk + index_count], then the same lists as bits: [cell][part_mask_words] at int part_mask_off
+   int part_mask_off, part_mask_words; // (partitioning_closest_bits below)
+   int part_bits_f4; // float4 count of the bits when every workgroup stages them into LDS behind the scene table (0: read from memory)
 };
 // int block at table[0..]: per-kind data in SCENE order (the order the flat primitive index
 // and the arg-min tie-break follow, scenes.adb:656-666) and the light kinds
@@ -86,7 +88,10 @@ enum {
    // the typed arg-min (closest_primitive_info): flat index of the plane behind each folded axis offset (-1: none),
    // flat index base of each built-in TYPE, and whether the scene allows it
    H_AXIS_IDX = 144, H_TBASE = 150, H_FASTINFO = 154,
-   H_INTS = 156    // 39 float4
+   // per kind {type, first float4, flat index base, declared count}: what the space partition's lookup needs of a kind,
+   // in one 16-byte LDS read
+   H_KQUAD = 156,  // [8][4]
+   H_INTS = 188    // 47 float4
 };
 
 struct KProbes {
@@ -137,6 +142,21 @@ MDH_DEV int lane_index_fresh()
    return l;
 }
 
+// -DMDH_DIAG: per loop type, count SDF evaluations (wave level) and the lanes alive in them
+#ifdef MDH_DIAG
+__device__ unsigned long long g_diag[16];
+
+#define MDH_DIAG_STEP(type)                                                                 \
+   do {                                                                                     \
+      unsigned long long m_ = __ballot(1);                                                  \
+      if ((threadIdx.x & 63) == __ffsll((long long)m_) - 1) {                               \
+         atomicAdd(&g_diag[2 * (type)], 1ull);                                              \
+         atomicAdd(&g_diag[2 * (type) + 1], (unsigned long long)__popcll(m_));              \
+      }                                                                                     \
+   } while (0)
+#else
+#define MDH_DIAG_STEP(type) do { } while (0)
+#endif
 // ------------------------------------------------------------------------------ vec math
 struct f3 { float x, y, z; };
 struct f2 { float x, y; };
@@ -369,6 +389,10 @@ extern __shared__ float4 s_tab[];
 MDH_DEV void stage_table(const KScene &sc)
 {
    for (int i = threadIdx.x; i < sc.table_f4; i += blockDim.x) s_tab[i] = sc.table[i];
+   if (sc.part_bits_f4 > 0) { // the space partition's candidate bits of every cell (partitioning_closest_bits), when they are small enough
+      const float4 *bits = (const float4 *)(sc.part_table + sc.part_mask_off);
+      for (int i = threadIdx.x; i < sc.part_bits_f4; i += blockDim.x) s_tab[sc.table_f4 + i] = bits[i];
+   }
    __syncthreads();
 }
 MDH_DEV int prim_slots(int type) { return type == PK_TRIANGLE ? 3 : (type == PK_BOX ? 2 : 1); }
@@ -376,6 +400,12 @@ MDH_DEV int tab_int(int int_index) { return ((const int *)s_tab)[int_index]; }
 MDH_DEV float tab_float(int float_index) { return ((const float *)s_tab)[float_index]; }
 // header ints: wave-uniform LDS reads, moved to SGPRs
 MDH_DEV int hdr(int i) { return __builtin_amdgcn_readfirstlane(tab_int(i)); }
+// four consecutive header ints (i a multiple of 4): one LDS read
+MDH_DEV int4 hdr4(int i)
+{
+   const int4 v = ((const int4 *)s_tab)[i >> 2];
+   return make_int4(__builtin_amdgcn_readfirstlane(v.x), __builtin_amdgcn_readfirstlane(v.y), __builtin_amdgcn_readfirstlane(v.z), __builtin_amdgcn_readfirstlane(v.w));
+}
 
 // ---------------------------------------------------------------------------- the SDFs
 // madarch-primitives-spheres.ads:13-14
@@ -574,6 +604,9 @@ MDH_DEV float prim_dist(int type, int slot, f3 x)
 #endif
 #ifndef MDH_FAST_INFO
 #define MDH_FAST_INFO 1
+#endif
+#ifndef MDH_PART_BITS
+#define MDH_PART_BITS 1 // the distance-only partition lookup walks a cell's candidates as bits (partitioning_closest_bits)
 #endif
 #ifndef MDH_SDF_UNROLL
 #define MDH_SDF_UNROLL 2
@@ -836,6 +869,98 @@ template <bool INFO, bool CUSTOM> MDH_DEV float partitioning_lookup(const KScene
 #endif
    return closest;
 }
+// partitioning_closest (scenes.adb:839-958) from the cell's candidates as BITS.
+//
+// A cell's record names its candidates as indices, kind by kind (scenes.adb:875-941): a lane that walks it pays one
+// dependent L2 / L1 round trip per candidate before it can even gather the primitive from LDS, 23 ints per cell in the
+// reference's simple_scene.  The minimum over the candidates does not depend on their order or on repetitions, so for
+// the distance-only lookup -- every march step; the arg-min at hit points keeps the lists and their order -- the same
+// set is stored once more as one bit per DECLARED primitive (bit = flat index, scenes.adb:656-666; k_partition_bits
+// derives it from the lists exactly as the walk above reads them, cut at Index_Count included): 50 bits = two dwords
+// per cell for simple_scene, 16 KB for the whole grid instead of 184 KB.  A lane loads its cell's dwords (one or two
+// loads per step) and walks its set bits; the loop over kinds stays wave-uniform, so the type dispatch is scalar and
+// lanes in the same cell gather the same primitive (an LDS broadcast).
+template <bool CUSTOM> MDH_DEV float partitioning_closest_bits(const KScene &sc, f3 x)
+{
+   bool fb;
+   const int cell = partition_cell(sc, x, fb);
+   if (fb) return closest_primitive<CUSTOM>(sc, x);
+   float closest = sc.max_dist;
+   if (cell < 0 || cell >= sc.part_cells) return closest;
+   MDH_DIAG_STEP(5); // lookups that reach a cell
+   typedef const unsigned __attribute__((address_space(1))) *GlobalWords;
+   const int nk = hdr(H_NK), nw = sc.part_mask_words;
+   const bool in_lds = sc.part_bits_f4 > 0; // (wave-uniform: the whole grid's bits are staged behind the scene table)
+   GlobalWords gwords = (GlobalWords)(sc.part_table + sc.part_mask_off) + (size_t)cell * nw;
+   const unsigned *lwords = (const unsigned *)(s_tab + sc.table_f4) + cell * nw;
+   auto word = [&](int dw) -> unsigned { return in_lds ? lwords[dw] : gwords[dw]; };
+   // two consecutive dwords of the cell's bits at a time: a kind's bits start anywhere in the first
+   int cur = 0;
+   unsigned wlo = word(0), whi = nw > 1 ? word(1) : 0u;
+#pragma unroll 1
+   for (int k = 0; k < nk; ++k) {
+      const int4 kq = hdr4(H_KQUAD + 4 * k); // type, first float4, flat base, declared count
+      const int type = kq.x, s0 = kq.y, kmax = kq.w;
+#pragma unroll 1
+      for (int c = 0; c < kmax; c += 32) { // 32 of the kind's instances at a time, as ONE word whatever dwords they lie in
+         const int bit0 = kq.z + c, dw = bit0 >> 5;
+         if (dw != cur) { // (wave-uniform)
+            wlo = dw == cur + 1 ? whi : word(dw);
+            whi = dw + 1 < nw ? word(dw + 1) : 0u;
+            cur = dw;
+         }
+         unsigned w = __builtin_amdgcn_alignbit(whi, wlo, (unsigned)(bit0 & 31));
+         if (kmax - c < 32) w &= (1u << (kmax - c)) - 1u;
+#ifdef MDH_DIAG
+         { // candidates of all lanes (slot 7: lane-candidates; its wave count = kind visits)
+            unsigned long long m_ = __ballot(1);
+            int pc_ = __popc(w);
+            for (int o_ = 32; o_ > 0; o_ >>= 1) pc_ += __shfl_xor(pc_, o_);
+            if ((threadIdx.x & 63) == __ffsll((long long)m_) - 1) { atomicAdd(&g_diag[14], 1ull); atomicAdd(&g_diag[15], (unsigned long long)pc_); }
+         }
+#endif
+         // the type is wave-uniform: one loop per type, each lane walking its own set bits, two at a time: both gathers
+         // are in flight before either distance is computed (a lane's last odd candidate is evaluated twice -- the minimum
+         // does not change, and the wave waits for its longest list anyway).  Lanes whose rays are in the same cell --
+         // most of an 8 x 8 tile's -- gather the same primitive at the same time (an LDS broadcast).
+#define MDH_BITS_PAIR(p0_, p1_)                                                              \
+         MDH_DIAG_STEP(6);                                                                   \
+         const int p0_ = __builtin_ctz(w);                                                   \
+         w &= w - 1u;                                                                        \
+         const int p1_ = w ? __builtin_ctz(w) : p0_;                                         \
+         w &= w - 1u /* (0 & 0xffffffff = 0) */
+         if (CUSTOM && type == PK_CUSTOM) {
+            while (w) { const int pi = c + __builtin_ctz(w); w &= w - 1u; closest = min_raw(closest, xdist<false>(k, pi, x)); }
+         } else if (type == PK_SPHERE) {
+            const float4 *t = s_tab + s0 + c;
+            while (w) {
+               MDH_BITS_PAIR(p0, p1);
+               const float4 a0 = t[p0], a1 = t[p1];
+               closest = min_raw(min_raw(closest, sd_sphere(a0, x)), sd_sphere(a1, x));
+            }
+         } else if (type == PK_PLANE) {
+            const float4 *t = s_tab + s0 + c;
+            while (w) {
+               MDH_BITS_PAIR(p0, p1);
+               const float4 a0 = t[p0], a1 = t[p1];
+               closest = min_raw(min_raw(closest, sd_plane(a0, x)), sd_plane(a1, x));
+            }
+         } else if (type == PK_BOX) {
+            const float4 *t = s_tab + s0 + 2 * c;
+            while (w) {
+               MDH_BITS_PAIR(p0, p1);
+               const float4 a0 = t[2 * p0], b0 = t[2 * p0 + 1], a1 = t[2 * p1], b1 = t[2 * p1 + 1];
+               closest = min_raw(min_raw(closest, sd_box(a0, b0, x)), sd_box(a1, b1, x));
+            }
+         } else {
+            const float4 *t = s_tab + s0 + 3 * c;
+            while (w) { const int pi = __builtin_ctz(w); w &= w - 1u; closest = min_raw(closest, sd_triangle<false>(xyz(t[3 * pi]), xyz(t[3 * pi + 1]), xyz(t[3 * pi + 2]), x)); }
+         }
+#undef MDH_BITS_PAIR
+      }
+   }
+   return closest;
+}
 // PART is a set of flags: bit 0 = the space partition is on, bit 1 = the scene has user-defined kinds,
 #define MDH_PF_PART 1
 #define MDH_PF_CUSTOM 2
@@ -843,14 +968,16 @@ template <bool INFO, bool CUSTOM> MDH_DEV float partitioning_lookup(const KScene
 template <int PART> MDH_DEV float sdf(const KScene &sc, f3 x)
 {
    int dummy;
-   if (PART & MDH_PF_PART) return partitioning_lookup<false, (PART & MDH_PF_CUSTOM) != 0>(sc, x, dummy);
+   (void)dummy;
+   if (PART & MDH_PF_PART) return MDH_PART_BITS ? partitioning_closest_bits<(PART & MDH_PF_CUSTOM) != 0>(sc, x) : partitioning_lookup<false, (PART & MDH_PF_CUSTOM) != 0>(sc, x, dummy);
    return closest_primitive<(PART & MDH_PF_CUSTOM) != 0>(sc, x);
 }
 // the same with the first sphere and box already in registers (sdf_regs)
 template <int PART> MDH_DEV float sdf(const KScene &sc, f3 x, const SdfRegs &regs)
 {
    int dummy;
-   if (PART & MDH_PF_PART) return partitioning_lookup<false, (PART & MDH_PF_CUSTOM) != 0>(sc, x, dummy);
+   (void)dummy;
+   if (PART & MDH_PF_PART) return MDH_PART_BITS ? partitioning_closest_bits<(PART & MDH_PF_CUSTOM) != 0>(sc, x) : partitioning_lookup<false, (PART & MDH_PF_CUSTOM) != 0>(sc, x, dummy);
    return closest_primitive<(PART & MDH_PF_CUSTOM) != 0>(sc, x, &regs);
 }
 template <int PART> MDH_DEV float sdf_info(const KScene &sc, f3 x, int &index)

@@ -87,7 +87,18 @@ struct ScreenArgs {
    float *gb_t;
    int *gb_steps;
    unsigned *window; // MDH_OPT_WINDOW: the window's RGBA8 pixels (pinned host memory, written over PCIe), or null
+   // MDH_OPT_SCREEN_ORDER: the launch's tiles in the order of an earlier pass's wavefront durations, slowest first.  A
+   // pass ends with its slowest wavefront; in image order the long tiles (rays that graze surfaces for hundreds of
+   // steps) start anywhere, and the pass of simple_scene spent 45 % of its time with a few of them on an empty chip.
+   int n_own;             // tiles this launch draws: own index 0 .. n_own - 1, tile = rank + own * world
+   const unsigned *order; // [n_own] the own index at every place of the launch, or null: image order
+   unsigned char *cost;   // [n_own] written by the pass when not null: the tile's wavefront duration as a sort key
 };
+// a wavefront's duration in shader clocks as a key of the counting sort (k_rad_hist ...)
+#ifndef MDH_TILE_COST_SHIFT
+#define MDH_TILE_COST_SHIFT 12
+#endif
+MDH_DEV unsigned char tile_cost_key(unsigned cycles) { return (unsigned char)min(cycles >> MDH_TILE_COST_SHIFT, 255u); }
 
 // draw_screen.glsl:20-30.  One wavefront per 8x8 pixel tile: lane = (y & 7) * 8 + (x & 7);
 // the tile's 64 pixels walk the structured pixel program of mdh_march.h together.
@@ -110,10 +121,13 @@ __global__ __launch_bounds__(MDH_BLOCK, MDH_OCC(PART, MODE)) void k_screen(KScen
 {
    stage_table(sc);
    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-   const int own = blockIdx.x * (MDH_BLOCK / 64) + wave;
+   const int place = blockIdx.x * (MDH_BLOCK / 64) + wave;
+   if (place >= a.n_own) return; // wave-uniform
+   const unsigned t_begin = (unsigned)__builtin_amdgcn_s_memtime();
+   const int own = a.order ? (int)a.order[place] : place;
    const int tile = a.rank + own * a.world;
-   if (tile >= a.n_tiles) return; // wave-uniform
    PH_KERNEL_BEGIN();
+   MDH_DIAG_WAVE(own);
    f3 c;
    PrimaryHit ph;
    bool hit;
@@ -160,8 +174,12 @@ __global__ __launch_bounds__(MDH_BLOCK, MDH_OCC(PART, MODE)) void k_screen(KScen
    {
       int wave2 = wave;
       asm volatile("" : "+s"(wave2));
-      const int tile2 = a.rank + ((int)blockIdx.x * (MDH_BLOCK / 64) + wave2) * a.world;
+      const int place2 = (int)blockIdx.x * (MDH_BLOCK / 64) + wave2;
+      const int own2 = a.order ? (int)a.order[place2] : place2;
+      const int tile2 = a.rank + own2 * a.world;
       tile_pixel(a, tile2, lane_index_fresh(), i, j, u, v);
+      // (everything but the tone map and the stores is behind the wavefront: what it took decides its place in later passes)
+      if (a.cost && lane_index_fresh() == 0) a.cost[own2] = tile_cost_key((unsigned)__builtin_amdgcn_s_memtime() - t_begin);
    }
    const bool valid = i < a.W && j < a.H;
 #ifdef MDH_PHASES
@@ -348,6 +366,61 @@ __global__ __launch_bounds__(256) void k_rad_scatter(const unsigned char *steps,
          for (int q = 0; q < 4; ++q)
             if (base + i + q < n) order[atomicAdd(&place[steps[base + i + q]], 1u)] = (unsigned)(base + i + q);
    }
+}
+
+// The same scatter, STABLE: elements with equal keys keep their order.  The screen pass's tiles are sorted with it: tiles
+// that took about as long stay in image order, where neighbours tap the same probes' texels (the unstable scatter above
+// shuffles the tiles of a chunk: 3 % slower screen passes at equal keys).  Rounds of 256 elements; an element's place =
+// the key's next place + the equal keys in front of it in its round.
+__global__ __launch_bounds__(256) void k_order_scatter_stable(const unsigned char *keys, int n, int chunk, const unsigned *hist, unsigned *order)
+{
+   __shared__ unsigned place[256], cnt[256];
+   __shared__ short kk[256];
+   const int tid = threadIdx.x;
+   place[tid] = hist[blockIdx.x * 256 + tid];
+   const int base = blockIdx.x * chunk;
+   for (int r0 = 0; r0 < chunk; r0 += 256) {
+      const int i = base + r0 + tid;
+      const bool in = r0 + tid < chunk && i < n;
+      const int k = in ? (int)keys[i] : -1;
+      kk[tid] = (short)k;
+      cnt[tid] = 0u;
+      __syncthreads();
+      unsigned before = 0u;
+      if (in) {
+         for (int j = 0; j < tid; ++j) before += kk[j] == k ? 1u : 0u;
+         atomicAdd(&cnt[k], 1u);
+      }
+      __syncthreads();
+      if (in) order[place[k] + before] = (unsigned)i;
+      __syncthreads();
+      place[tid] += cnt[tid];
+      __syncthreads();
+   }
+}
+
+// Keys below `permille` thousandths of the MEDIAN key become 0 (behind k_rad_hist over the raw keys; the histogram is taken
+// again afterwards): only the tiles that took clearly longer than most are moved to the front of the launch, all others
+// stay in image order.  Every workgroup finds the median from the histogram by itself (256 keys x at most 128 chunks).
+__global__ __launch_bounds__(256) void k_order_floor(unsigned char *keys, int n, int chunk, const unsigned *hist, int chunks, int permille)
+{
+   __shared__ unsigned total[256];
+   __shared__ int floor_key;
+   const int tid = threadIdx.x;
+   unsigned sum = 0u;
+   for (int c = 0; c < chunks; ++c) sum += hist[c * 256 + tid];
+   total[tid] = sum;
+   __syncthreads();
+   if (tid == 0) {
+      unsigned acc = 0u;
+      int m = 0;
+      for (; m < 255; ++m) { acc += total[m]; if (2u * acc >= (unsigned)n) break; }
+      floor_key = (int)(((long)m * permille + 999) / 1000);
+   }
+   __syncthreads();
+   const int f = floor_key, base = blockIdx.x * chunk;
+   for (int i = tid; i < chunk; i += 256)
+      if (base + i < n && (int)keys[base + i] < f) keys[base + i] = 0;
 }
 
 // -------------------------------------------------------------------- irradiance pass
@@ -702,6 +775,30 @@ __global__ __launch_bounds__(64) void k_partition_build(KScene sc, PartBuildArgs
       }
       rec[k] = n;
       written += n;
+   }
+}
+
+// The candidate lists of every cell once more as one bit per declared primitive (partitioning_closest_bits,
+// mdh_device.h), derived from the lists exactly as the lookup walks them: kind by kind, a kind's entries up to its
+// count, the whole walk cut at Index_Count.  One lane per cell; runs behind every build on the build's stream.
+__global__ __launch_bounds__(64) void k_partition_bits(KScene sc, int *table)
+{
+   stage_table(sc);
+   const int cell = blockIdx.x * 64 + threadIdx.x;
+   if (cell >= sc.part_cells) return;
+   const int nk = hdr(H_NK);
+   const int *rec = table + (size_t)cell * (nk + sc.part_index_count);
+   unsigned *words = (unsigned *)(table + sc.part_mask_off) + (size_t)cell * sc.part_mask_words;
+   for (int q = 0; q < sc.part_mask_words; ++q) words[q] = 0u;
+   int i = 0;
+   for (int k = 0; k < nk; ++k) {
+      const int size = i + rec[k], base = hdr(H_KBASE + k), kmax = hdr(H_KMAX + k);
+      const int stop = min(size, sc.part_index_count);
+      for (; i < stop; ++i) {
+         const int pi = rec[nk + i];
+         if (pi >= 0 && pi < kmax) words[(base + pi) >> 5] |= 1u << ((base + pi) & 31);
+      }
+      i = size;
    }
 }
 

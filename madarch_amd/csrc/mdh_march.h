@@ -58,21 +58,6 @@ MDH_DEV i3 cage_probe(const KProbes &pr, i3 gp, int i)
 // and well under 128 VGPRs.
 // =============================================================================================
 
-// -DMDH_DIAG: per loop type, count SDF evaluations (wave level) and the lanes alive in them
-#ifdef MDH_DIAG
-__device__ unsigned long long g_diag[16];
-
-#define MDH_DIAG_STEP(type)                                                                 \
-   do {                                                                                     \
-      unsigned long long m_ = __ballot(1);                                                  \
-      if ((threadIdx.x & 63) == __ffsll((long long)m_) - 1) {                               \
-         atomicAdd(&g_diag[2 * (type)], 1ull);                                              \
-         atomicAdd(&g_diag[2 * (type) + 1], (unsigned long long)__popcll(m_));              \
-      }                                                                                     \
-   } while (0)
-#else
-#define MDH_DIAG_STEP(type) do { } while (0)
-#endif
 // -DMDH_PHASES: wall cycles (s_memtime) per wave spent in each region of the pixel program, summed over waves
 #ifdef MDH_PHASES
 __device__ unsigned long long g_phase[16];
@@ -147,7 +132,11 @@ template <int PART> MDH_DEV bool march_plain(const KScene &sc, f3 o, f3 d, float
 // mode 2 (direct light and occlusion only: no probes, no reflection) parks P, N, view direction, direct light and the
 // material id: 13 rows, so that eight of its workgroups fit a CU's LDS
 #define MDH_PARK_MAT_DIRECT 12
+#ifdef MDH_PHASES
+#define MDH_DIRECT_PARK_ROWS 20 // (room for the accumulators of the diagnostic, MDH_PH_SLOT)
+#else
 #define MDH_DIRECT_PARK_ROWS 13
+#endif
 #ifdef MDH_PHASES
 #define MDH_PARK_DWORDS 20
 #else
@@ -160,7 +149,7 @@ template <int PART> MDH_DEV bool march_plain(const KScene &sc, f3 o, f3 d, float
 #define MDH_PARK_ALPHA 12
 #define MDH_PARK_RIDN 15
 #define MDH_SCR_PARK_ROWS MDH_PARK_DWORDS
-MDH_DEV float *park_base(const KScene &sc) { return (float *)(s_tab + sc.table_f4); }
+MDH_DEV float *park_base(const KScene &sc) { return (float *)(s_tab + sc.table_f4 + sc.part_bits_f4); }
 // A thread's own column of the park rows is addressed WITHOUT an address register: ds_write_addtid_b32 /
 // ds_read_addtid_b32 take M0[15:0] + offset + 4 * lane (scripts/addtid_probe.hip checks that on the box), so a park
 // access costs one LDS instruction per dword and one scalar -- the LDS byte address of the wave's 64 columns in row 0

@@ -28,7 +28,7 @@ reverse select separate some subtype synchronized tagged task terminate then typ
 EXTERNAL = set(n.lower() for n in """
 Ada Containers Vectors Vector Append Length Hashed_Maps Count_Type Hash_Type Unchecked_Conversion Unchecked_Deallocation
 Strings Unbounded Unbounded_String To_Unbounded_String To_String Null_Unbounded_String
-Interfaces C int C_float size_t long chars_ptr New_String Value Free Unsigned_8 Unsigned_32 Integer_32 Shift_Left
+Interfaces C int C_float size_t long unsigned_char chars_ptr New_String Value Free Unsigned_8 Unsigned_32 Integer_32 Shift_Left
 System Address Null_Address
 Standard Natural Positive Integer Boolean True False String Character Float
 Constraint_Error Program_Error

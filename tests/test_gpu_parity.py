@@ -609,3 +609,38 @@ def test_radiance_ray_order_changes_no_texel(hip, probes, world):
     for a, b in zip(*outs):
         for key in ("radiance", "irradiance", "image"):
             assert same_bits(a[key], b[key]), key
+
+
+@pytest.mark.parametrize("scene,mode,world,overlap", [("global_illumination", 0, 1, 2), ("simple_scene", 2, 1, 2), ("global_illumination", 0, 3, 2),
+                                                     ("simple_scene", 2, 1, 0), ("light_shafts", 0, 1, 2)])
+def test_screen_tile_order_changes_no_pixel(hip, scene, mode, world, overlap):
+    """MDH_OPT_SCREEN_ORDER: the first screen pass records every tile's wavefront duration, later passes start the tiles
+    slowest first (image large enough for the option to engage: 2048 tiles and more; frames in flight on both screen
+    streams and serial; a rank's tiles; a camera that moves, so that the tiles are sorted again while frames are in
+    flight): WHERE in the launch a tile is drawn, never what it holds -- framebuffer, geometry buffer and window pixels
+    are those of the pass in image order, frame after frame."""
+    outs = []
+    for order in (1, 0):
+        # 65 x 41 = 2665 tiles, the last column and row partial (three ranks: 129 x 81 tiles, 3483 of them this rank's)
+        R = make(scene, 520 * (2 if world > 1 else 1) - (8 if world > 1 else 0), 328 * (2 if world > 1 else 1) - (8 if world > 1 else 0), hip, mode=mode, probes=SMALL_PROBES)
+        assert R.Get_Option(B.OPT_SCREEN_ORDER) == 1
+        R.Set_Option(B.OPT_SCREEN_ORDER, order)
+        R.Set_Option(B.OPT_FRAME_OVERLAP, overlap)
+        if world > 1:
+            R.Set_Option(B.OPT_WORLD, world)
+            R.Set_Option(B.OPT_RANK, 1)
+        frames = []
+        for f in range(22):
+            if f in (3, 12):
+                R.Set_Camera_Position((2.0 + 0.1 * f, 2.0, 0.0))
+            R.Render()
+            if f in (0, 1, 2, 11, 12, 20, 21):
+                R.Swap_Buffers()
+                frames.append((R.Read_Framebuffer(), R.Read_Gbuffer(), R.Front_Buffer()))
+        outs.append(frames)
+        R.Destroy()
+    for (img_a, gb_a, px_a), (img_b, gb_b, px_b) in zip(*outs):
+        assert same_bits(img_a, img_b)
+        if world == 1:  # (the geometry buffer of other ranks' tiles is never written, nor cleared)
+            assert all(same_bits(x, y) for x, y in zip(gb_a, gb_b))
+        assert (px_a == px_b).all()
