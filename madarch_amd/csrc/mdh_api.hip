@@ -1414,7 +1414,10 @@ static int run_pass(mdh_renderer *r, int pass, hipStream_t st, int src, int dst,
    bool has_custom = false;
    for (int k = 0; k < r->npk; ++k) has_custom = has_custom || r->pk[k].type == PK_CUSTOM;
    for (int k = 0; k < r->nlk; ++k) has_custom = has_custom || r->lk[k].type == LK_CUSTOM;
-   const int pf = (r->part.enable != 0 ? MDH_PF_PART : 0) | (has_custom ? MDH_PF_CUSTOM : 0);
+   // ... bit 3 = the space partition's border falls back to the full scan (built-in kinds: a variant of its own; with
+   // user-defined kinds the kernels test the setting at run time)
+   const int pf = (r->part.enable != 0 ? MDH_PF_PART : 0) | (has_custom ? MDH_PF_CUSTOM : 0) |
+                  (r->part.enable != 0 && r->part.border_behavior != 0 && !has_custom ? MDH_PF_FALLBACK : 0);
    // the probe-sampling kernels (radiance, mode-0 screen) have a variant for atlases whose every dimension is a power of two
    auto is_pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
    // (... and small enough for what those variants assume besides: probe ids within 24-bit products, RGBA8 byte offsets
@@ -1430,6 +1433,7 @@ static int run_pass(mdh_renderer *r, int pass, hipStream_t st, int src, int dst,
       case 0: hipLaunchKernelGGL(KERNEL<0>, GRID, BLOCK, LDS, st, __VA_ARGS__); break;                     \
       case 1: hipLaunchKernelGGL(KERNEL<1>, GRID, BLOCK, LDS, st, __VA_ARGS__); break;                     \
       case 2: hipLaunchKernelGGL(KERNEL<2>, GRID, BLOCK, LDS, st, __VA_ARGS__); break;                     \
+      case 9: hipLaunchKernelGGL(KERNEL<9>, GRID, BLOCK, LDS, st, __VA_ARGS__); break;                     \
       default: hipLaunchKernelGGL(KERNEL<3>, GRID, BLOCK, LDS, st, __VA_ARGS__); break;                    \
       }                                                                                                   \
    } while (0)
@@ -1516,13 +1520,15 @@ static int run_pass(mdh_renderer *r, int pass, hipStream_t st, int src, int dst,
 #define MDH_LAUNCH_RAD_(...) hipLaunchKernelGGL((__VA_ARGS__), dim3(blocks), dim3(MDH_BLOCK), lds, st, r->ks, pr, rad_first_round(r, (const void *)(__VA_ARGS__), nullptr, lds, blocks), ro)
 #define MDH_LAUNCH_RAD(P) do { if (rad_small_launch(r)) MDH_LAUNCH_RAD_(k_radiance<P, true>); else MDH_LAUNCH_RAD_(k_radiance<P, false>); } while (0)
             if (pow2 && !has_custom) {
-               if (pf & MDH_PF_PART) MDH_LAUNCH_RAD(MDH_PF_PART | MDH_PF_POW2);
+               if (pf & MDH_PF_FALLBACK) MDH_LAUNCH_RAD(MDH_PF_PART | MDH_PF_POW2 | MDH_PF_FALLBACK);
+               else if (pf & MDH_PF_PART) MDH_LAUNCH_RAD(MDH_PF_PART | MDH_PF_POW2);
                else MDH_LAUNCH_RAD(MDH_PF_POW2);
             } else
                switch (pf) {
                case 0: MDH_LAUNCH_RAD(0); break;
                case 1: MDH_LAUNCH_RAD(1); break;
                case 2: MDH_LAUNCH_RAD(2); break;
+               case 9: MDH_LAUNCH_RAD(9); break;
                default: MDH_LAUNCH_RAD(3); break;
                }
 #undef MDH_LAUNCH_RAD_
@@ -1651,6 +1657,7 @@ static int run_pass(mdh_renderer *r, int pass, hipStream_t st, int src, int dst,
          case 0: launch_screen_m<0>(r, st, pr, vol, cam, a, blocks, pow2); break;
          case 1: launch_screen_m<1>(r, st, pr, vol, cam, a, blocks, pow2); break;
          case 2: launch_screen_m<2>(r, st, pr, vol, cam, a, blocks, pow2); break;
+         case 9: launch_screen_m<9>(r, st, pr, vol, cam, a, blocks, pow2); break;
          default: launch_screen_m<3>(r, st, pr, vol, cam, a, blocks, pow2); break;
          }
       }

@@ -822,13 +822,22 @@ MDH_DEV int partition_cell(const KScene &sc, f3 x, bool &fallback)
    float yz = (float)(sc.part_dims[1] * sc.part_dims[2]), zz = (float)sc.part_dims[2];
    return (int)((fx.x * yz + fx.y * zz) + fx.z);
 }
+// (Border_Behavior = Clamp known when the kernel is built)
+MDH_DEV int partition_cell_clamped(const KScene &sc, f3 x)
+{
+   const f3 rel = x - F3(sc.part_off[0], sc.part_off[1], sc.part_off[2]);
+   const f3 fx = floor3(sc.part_sp_pow2 ? rel * F3(sc.part_inv_sp[0], sc.part_inv_sp[1], sc.part_inv_sp[2]) : rel / F3(sc.part_sp[0], sc.part_sp[1], sc.part_sp[2]));
+   const f3 cfx = F3(clamp_(fx.x, 0.0f, (float)sc.part_dims[0]), clamp_(fx.y, 0.0f, (float)sc.part_dims[1]), clamp_(fx.z, 0.0f, (float)sc.part_dims[2]));
+   const float yz = (float)(sc.part_dims[1] * sc.part_dims[2]), zz = (float)sc.part_dims[2];
+   return (int)((cfx.x * yz + cfx.y * zz) + cfx.z);
+}
 // partitioning_closest[_info] (scenes.adb:839-1118): per-lane cell record from HBM/L2,
 // per-lane primitive gather from LDS
-template <bool INFO, bool CUSTOM> MDH_DEV float partitioning_lookup(const KScene &sc, f3 x, int &index)
+template <bool INFO, bool CUSTOM, bool FALLBACK = true> MDH_DEV float partitioning_lookup(const KScene &sc, f3 x, int &index)
 {
-   bool fb;
-   int cell = partition_cell(sc, x, fb);
-   if (fb) return INFO ? closest_primitive_info<CUSTOM>(sc, x, index) : closest_primitive<CUSTOM>(sc, x);
+   bool fb = false;
+   int cell = FALLBACK ? partition_cell(sc, x, fb) : partition_cell_clamped(sc, x);
+   if (FALLBACK && fb) return INFO ? closest_primitive_info<CUSTOM>(sc, x, index) : closest_primitive<CUSTOM>(sc, x);
    float closest = sc.max_dist;
    if (cell < 0 || cell >= sc.part_cells) return closest;
    const int nk = hdr(H_NK);
@@ -880,11 +889,14 @@ template <bool INFO, bool CUSTOM> MDH_DEV float partitioning_lookup(const KScene
 // per cell for simple_scene, 16 KB for the whole grid instead of 184 KB.  A lane loads its cell's dwords (one or two
 // loads per step) and walks its set bits; the loop over kinds stays wave-uniform, so the type dispatch is scalar and
 // lanes in the same cell gather the same primitive (an LDS broadcast).
-template <bool CUSTOM> MDH_DEV float partitioning_closest_bits(const KScene &sc, f3 x)
+// FALLBACK: the kernel variant of scenes whose Border_Behavior is Fallback (a point outside the grid scans every
+// primitive, scenes.adb:943-957).  Scenes that clamp -- the reference's own -- run variants without that scan: inlined, its
+// loops sat in every march loop of the partition kernels (a quarter of their code).
+template <bool CUSTOM, bool FALLBACK> MDH_DEV float partitioning_closest_bits(const KScene &sc, f3 x)
 {
-   bool fb;
-   const int cell = partition_cell(sc, x, fb);
-   if (fb) return closest_primitive<CUSTOM>(sc, x);
+   bool fb = false;
+   const int cell = FALLBACK ? partition_cell(sc, x, fb) : partition_cell_clamped(sc, x);
+   if (FALLBACK && fb) return closest_primitive<CUSTOM>(sc, x);
    float closest = sc.max_dist;
    if (cell < 0 || cell >= sc.part_cells) return closest;
    MDH_DIAG_STEP(5); // lookups that reach a cell
@@ -965,11 +977,14 @@ template <bool CUSTOM> MDH_DEV float partitioning_closest_bits(const KScene &sc,
 #define MDH_PF_PART 1
 #define MDH_PF_CUSTOM 2
 #define MDH_PF_POW2 4 // bit 2 = the probe counts and both tile resolutions are powers of two (every atlas address is shifts and masks)
+#define MDH_PF_FALLBACK 8 // bit 3 = the space partition's Border_Behavior is Fallback (built-in kinds; scenes with user-defined kinds keep the run-time test)
+// does this variant carry the full scan of the Fallback border?
+#define MDH_PF_HAS_FALLBACK(PART) ((((PART) & MDH_PF_FALLBACK) != 0) || (((PART) & MDH_PF_CUSTOM) != 0))
 template <int PART> MDH_DEV float sdf(const KScene &sc, f3 x)
 {
    int dummy;
    (void)dummy;
-   if (PART & MDH_PF_PART) return MDH_PART_BITS ? partitioning_closest_bits<(PART & MDH_PF_CUSTOM) != 0>(sc, x) : partitioning_lookup<false, (PART & MDH_PF_CUSTOM) != 0>(sc, x, dummy);
+   if (PART & MDH_PF_PART) return MDH_PART_BITS ? partitioning_closest_bits<(PART & MDH_PF_CUSTOM) != 0, MDH_PF_HAS_FALLBACK(PART)>(sc, x) : partitioning_lookup<false, (PART & MDH_PF_CUSTOM) != 0, MDH_PF_HAS_FALLBACK(PART)>(sc, x, dummy);
    return closest_primitive<(PART & MDH_PF_CUSTOM) != 0>(sc, x);
 }
 // the same with the first sphere and box already in registers (sdf_regs)
@@ -977,12 +992,12 @@ template <int PART> MDH_DEV float sdf(const KScene &sc, f3 x, const SdfRegs &reg
 {
    int dummy;
    (void)dummy;
-   if (PART & MDH_PF_PART) return MDH_PART_BITS ? partitioning_closest_bits<(PART & MDH_PF_CUSTOM) != 0>(sc, x) : partitioning_lookup<false, (PART & MDH_PF_CUSTOM) != 0>(sc, x, dummy);
+   if (PART & MDH_PF_PART) return MDH_PART_BITS ? partitioning_closest_bits<(PART & MDH_PF_CUSTOM) != 0, MDH_PF_HAS_FALLBACK(PART)>(sc, x) : partitioning_lookup<false, (PART & MDH_PF_CUSTOM) != 0, MDH_PF_HAS_FALLBACK(PART)>(sc, x, dummy);
    return closest_primitive<(PART & MDH_PF_CUSTOM) != 0>(sc, x, &regs);
 }
 template <int PART> MDH_DEV float sdf_info(const KScene &sc, f3 x, int &index)
 {
-   if (PART & MDH_PF_PART) return partitioning_lookup<true, (PART & MDH_PF_CUSTOM) != 0>(sc, x, index);
+   if (PART & MDH_PF_PART) return partitioning_lookup<true, (PART & MDH_PF_CUSTOM) != 0, MDH_PF_HAS_FALLBACK(PART)>(sc, x, index);
    return closest_primitive_info<(PART & MDH_PF_CUSTOM) != 0>(sc, x, index);
 }
 

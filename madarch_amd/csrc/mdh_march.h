@@ -437,7 +437,7 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
                             PrimaryHit &ph, bool &hit, f3 &pos_out)
 {
    constexpr bool P2 = (PART & MDH_PF_POW2) != 0;
-   constexpr bool REFLECT = SPEC != 0;
+   constexpr bool REFLECT = SPEC != 0 && MODE == 0; // (modes 1 and 2 never shade a second point: no loop, and nothing kept for one)
    constexpr int PARK_MAT = MODE == 2 ? MDH_PARK_MAT_DIRECT : MDH_PARK_MAT; // (no probe rows in mode 2: MDH_DIRECT_PARK_ROWS)
    // the second point goes through the whole of pixel_color_probes' lighting (compute_indirect_specular) ...
    const bool full2 = SPEC == 2 && cfg.spec_mode == 3;

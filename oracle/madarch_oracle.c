@@ -1812,6 +1812,27 @@ int32_t orc_probe_sample_irradiance(orc_renderer *r, int32_t n, const float *pos
    }
    return MDH_OK;
 }
+/* the three indirect-specular bodies of render_probes.glsl:71-244 (mode 1, 2 or 3) at n points: pos, normal, the
+   REFLECTED direction and the shaded point's roughness (mode 1), from the current atlases */
+int32_t orc_probe_specular(orc_renderer *r, int32_t mode, int32_t n, const float *pos, const float *nrm, const float *dir, const float *roughness, float *out)
+{
+   for (int q = 0; q < n; ++q) {
+      v3 P = V3(pos[3 * q], pos[3 * q + 1], pos[3 * q + 2]), N = V3(nrm[3 * q], nrm[3 * q + 1], nrm[3 * q + 2]), D = V3(dir[3 * q], dir[3 * q + 1], dir[3 * q + 2]);
+      v3 c = mode == 1 ? sample_radiance_with_specular(r, P, N, D, roughness[q]) : (mode == 2 ? sample_radiance_no_specular(r, P, N, D) : compute_indirect_specular(r, P, N, D, 1));
+      out[3 * q] = c.x; out[3 * q + 1] = c.y; out[3 * q + 2] = c.z;
+   }
+   return MDH_OK;
+}
+/* render_volumetrics (volumetrics.glsl:34-54) on n pixels: surface colour, ray origin, hit position (hit != 0), fragment */
+int32_t orc_probe_render_volumetrics(orc_renderer *r, int32_t n, const float *L, const float *from, const float *to, const int32_t *hit, const float *frag, float *out)
+{
+   for (int q = 0; q < n; ++q) {
+      v3 c = render_volumetrics(r, V3(L[3 * q], L[3 * q + 1], L[3 * q + 2]), V3(from[3 * q], from[3 * q + 1], from[3 * q + 2]), V3(to[3 * q], to[3 * q + 1], to[3 * q + 2]), hit[q],
+                                V2(frag[2 * q], frag[2 * q + 1]));
+      out[3 * q] = c.x; out[3 * q + 1] = c.y; out[3 * q + 2] = c.z;
+   }
+   return MDH_OK;
+}
 /* single SDF / normal of a built-in kind from raw parameters (a: vec3, b: vec3 or scalar in b[0], c: vec3) */
 float orc_sdf(int32_t type, const float *a, const float *b, const float *c, const float *p)
 {

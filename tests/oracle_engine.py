@@ -9,7 +9,8 @@ from madarch_amd import _binding as B
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
-ORACLE_LIB = os.path.join(ORACLE_DIR, "libmadarch_oracle.so")
+# MADARCH_ORACLE_LIBRARY selects another build of the oracle (the sanitizer build, tests/test_oracle_asan.py)
+ORACLE_LIB = os.environ.get("MADARCH_ORACLE_LIBRARY") or os.path.join(ORACLE_DIR, "libmadarch_oracle.so")
 
 ORC_OPT_SDF_MODE, ORC_OPT_THREADS = 100, 101
 
@@ -21,6 +22,8 @@ def build_oracle():
 
 
 def oracle_lib():
+    if os.environ.get("MADARCH_ORACLE_LIBRARY"):
+        return C.CDLL(ORACLE_LIB)
     if not os.path.exists(ORACLE_LIB) or any(
             os.path.getmtime(os.path.join(ORACLE_DIR, f)) > os.path.getmtime(ORACLE_LIB)
             for f in os.listdir(ORACLE_DIR) if f.endswith((".c", ".h"))):

@@ -70,7 +70,7 @@ def test_radiance_tiles_beyond_the_lds(hip):
 
 @pytest.mark.parametrize("steps", [0, 1, 8])
 def test_ambient_occlusion_steps(hip, orc, steps):
-    """M_AO_STEPS (lighting.glsl:42-49) other than the default 5, including none."""
+    """M_AMBIENT_OCCLUSION_STEPS (lighting.glsl:51-69) other than the reference's 3 (madarch-renderers.adb:139), including none."""
     outs = []
     for b in (hip, orc):
         R = make("global_illumination", 48, 32, b, probes=SMALL_PROBES)
