@@ -157,6 +157,15 @@ static float image_roundtrip(float x)
 
 // -------------------------------------------------------------------- the renderer
 #define MAX_MATERIALS 20 // glsl/materials.glsl:9
+// how often the probe rays (MDH_OPT_RADIANCE_ORDER) and the screen tiles (MDH_OPT_SCREEN_ORDER) are sorted again: every
+// MDH_RAD_RESORT passes, and after MDH_RAD_RESORT_MOVING passes when the geometry (or, for the tiles, the camera) changed
+#ifndef MDH_RAD_RESORT
+#define MDH_RAD_RESORT 64
+#endif
+#ifndef MDH_RAD_RESORT_MOVING
+#define MDH_RAD_RESORT_MOVING 8
+#endif
+
 
 struct mdh_renderer {
    int W = 0, H = 0, device = 0;
@@ -930,7 +939,11 @@ extern "C" int32_t mdh_set_option(mdh_renderer *r, int32_t option, int32_t value
       if (value < 0 || value > 2) return seterr(MDH_E_INVALID, "bad value");
       r->opt_window = value; r->win_valid = false;
       break;
-   case MDH_OPT_FRAME_OVERLAP: if (value < 0 || value > 2) return seterr(MDH_E_INVALID, "frame overlap is 0, 1 or 2"); r->opt_overlap = value; break;
+   case MDH_OPT_FRAME_OVERLAP:
+      if (value < 0 || value > 2) return seterr(MDH_E_INVALID, "frame overlap is 0, 1 or 2");
+      if ((value != 0) != (r->opt_overlap != 0)) r->scr_order_age = MDH_RAD_RESORT; // (how much of the screen pass is sorted follows the schedule: sort again)
+      r->opt_overlap = value;
+      break;
    case MDH_OPT_INDIRECT_SPECULAR: if (value < 0 || value > 3) return seterr(MDH_E_INVALID, "indirect specular mode is 0 .. 3"); r->opt_spec = value; break;
    case MDH_OPT_HYSTERESIS_PERMILLE: if (value < 0 || value > 999) return seterr(MDH_E_INVALID, "hysteresis is 0 .. 999 per mille"); r->opt_hyst = value; break;
    case MDH_OPT_RADIANCE_ORDER: r->opt_rad_order = value ? 1 : 0; r->rad_order_rays = 0; break;
@@ -1258,12 +1271,6 @@ static bool rad_small_launch(const mdh_renderer *r)
 }
 // The workgroups of the radiance pass the chip holds at once, when the launch is that and a remainder smaller than
 // it (k_radiance, mdh_kernels.h: the remainder runs at a raised issue priority); 0 otherwise.
-#ifndef MDH_RAD_RESORT
-#define MDH_RAD_RESORT 64
-#endif
-#ifndef MDH_RAD_RESORT_MOVING
-#define MDH_RAD_RESORT_MOVING 8
-#endif
 #ifndef MDH_RAD_TAIL_PRIO
 #define MDH_RAD_TAIL_PRIO 1
 #endif

@@ -56,6 +56,9 @@
 #else
 #define MDH_OCC_RAD(PART, SMALL) (((PART) & MDH_PF_CUSTOM) ? 2 : MDH_OCC_RAD_BUILTIN(SMALL))
 #endif
+#ifndef MDH_RAD_REDERIVE
+#define MDH_RAD_REDERIVE 1 // k_radiance derives its texel again behind the pixel program instead of keeping it (see there)
+#endif
 #ifndef MDH_RAD_QVIS
 #define MDH_RAD_QVIS 1 // probe-visibility rays through the wave's ray queue (mdh_march.h: queued_visibility)
 #endif
@@ -235,18 +238,15 @@ struct RadOrder {
 // starts 35-65 us late in slots between six older wavefronts, would finish last by far: it raises its issue priority
 // instead and runs at the speed of a wavefront alone (radiance pass 0.165 -> 0.147 ms).
 // `ro`: the rays of the pass in the order of the PREVIOUS pass's primary-march lengths (RadOrder below), or no order.
-template <int PART, bool SMALL = false> __global__ __launch_bounds__(MDH_BLOCK, MDH_OCC_RAD(PART, SMALL)) void k_radiance(KScene sc, KProbes pr, int first_round, RadOrder ro)
+// The texel (x, y) of probe probe_raw that lane `lin` of the launch computes (probe_raw = pr.probe_end: none)
+MDH_DEV void radiance_texel(const KProbes &pr, const RadOrder &ro, long lin, int &x, int &y, int &probe_raw)
 {
-   if (first_round > 0 && (int)blockIdx.x >= first_round) __builtin_amdgcn_s_setprio(3);
-   stage_table(sc);
    const int per_probe = pr.rres * pr.rres;
-   const long lin = (long)blockIdx.x * MDH_BLOCK + threadIdx.x;
    // a wavefront = a TxT texel tile (T*T = 64 / G) of the octahedral maps of G consecutive probes:
    // G = 1 is one 8x8 tile of one probe, G = 64 the same ray direction from 64 probes
    constexpr int G = MDH_RAD_PROBES_PER_WAVE, T = (G == 1) ? 8 : (G == 4) ? 4 : (G == 16) ? 2 : 1;
    const int lane = (int)(lin & 63);
    const long wave_global = lin >> 6;
-   int x, y, probe_raw;
    if (ro.order) { // lane = the ray at this place of the order (a ray: probe of the slice * texels + texel)
       const unsigned ray = lin < ro.n_rays ? ro.order[lin] : 0xffffffffu;
       if (pr.rshift >= 0) {
@@ -273,28 +273,76 @@ template <int PART, bool SMALL = false> __global__ __launch_bounds__(MDH_BLOCK, 
       y = rem / pr.rres;
       x = rem - y * pr.rres;
    }
-   const bool valid = probe_raw < pr.probe_end;
-   MDH_DIAG_WAVE(wave_global);
-   PH_KERNEL_BEGIN();
-   const int probe = valid ? probe_raw : pr.probe_begin;
-   const int ty = probe / pr.pcx, tx = probe - ty * pr.pcx;
-   const int i = tx * pr.rres + x, j = ty * pr.rres + y; // texel of the reference's 2-D atlas image
-   const f2 nc = F2((centre(i, pr.pcx * pr.rres) + 1.0f) * 0.5f, (centre(j, pr.pcy * pr.rres) + 1.0f) * 0.5f);
-   // coord_to_probe_id / probe position (probe_utils.glsl:19-40)
-   const int probe_id = (int)(nc.y * (float)pr.pcy) * pr.pcx + (int)(nc.x * (float)pr.pcx);
-   const f3 world = grid_to_world(pr, probe_id_to_grid(pr, probe_id));
-   const f3 ray_dir = ray_id_to_ray_dir(F2(fract_(nc.x * (float)pr.pcx), fract_(nc.y * (float)pr.pcy)));
-   MachineCfg cfg; // renderers.adb:115-117: no specular; AO and volumetrics macros undefined
-   cfg.direct_specular = false;
-   cfg.spec_mode = 0;
-   cfg.ao_steps = 0;
+}
+template <int PART, bool SMALL = false> __global__ __launch_bounds__(MDH_BLOCK, MDH_OCC_RAD(PART, SMALL)) void k_radiance(KScene sc, KProbes pr, int first_round, RadOrder ro)
+{
+   if (first_round > 0 && (int)blockIdx.x >= first_round) __builtin_amdgcn_s_setprio(3);
+   stage_table(sc);
+   f3 c;
    PrimaryHit ph;
-   bool hit;
-   f3 pos;
-   f3 c = MDH_SHADE<PART, 0, 0, MDH_RAD_QVIS != 0>(sc, pr, cfg, valid, world, ray_dir, ph, hit, pos);
-   if (valid) atlas_store(pr.rad, pr.fmt, atlas_index(pr.pcx, pr.rres, pr.rshift, i, j), c);
-   if (valid && ro.steps) // the ray's sort key: the levels of its primary-march and soft-shadow step counts
-      ro.steps[(size_t)(probe_raw - pr.probe_begin) * per_probe + y * pr.rres + x] = (unsigned char)((rad_level(ph.steps & 0xffff) << 4) | rad_level(ph.steps >> 16));
+   {
+      const long lin = (long)blockIdx.x * MDH_BLOCK + threadIdx.x;
+      int x, y, probe_raw;
+      radiance_texel(pr, ro, lin, x, y, probe_raw);
+      const bool valid = probe_raw < pr.probe_end;
+      MDH_DIAG_WAVE(lin >> 6);
+      PH_KERNEL_BEGIN();
+      const int probe = valid ? probe_raw : pr.probe_begin;
+      const int ty = probe / pr.pcx, tx = probe - ty * pr.pcx;
+      const int i = tx * pr.rres + x, j = ty * pr.rres + y; // texel of the reference's 2-D atlas image
+      const f2 nc = F2((centre(i, pr.pcx * pr.rres) + 1.0f) * 0.5f, (centre(j, pr.pcy * pr.rres) + 1.0f) * 0.5f);
+      // coord_to_probe_id / probe position (probe_utils.glsl:19-40)
+      const int probe_id = (int)(nc.y * (float)pr.pcy) * pr.pcx + (int)(nc.x * (float)pr.pcx);
+      const f3 world = grid_to_world(pr, probe_id_to_grid(pr, probe_id));
+      const f3 ray_dir = ray_id_to_ray_dir(F2(fract_(nc.x * (float)pr.pcx), fract_(nc.y * (float)pr.pcy)));
+      MachineCfg cfg; // renderers.adb:115-117: no specular; AO and volumetrics macros undefined
+      cfg.direct_specular = false;
+      cfg.spec_mode = 0;
+      cfg.ao_steps = 0;
+      bool hit;
+      f3 pos;
+      c = MDH_SHADE<PART, 0, 0, MDH_RAD_QVIS != 0>(sc, pr, cfg, valid, world, ray_dir, ph, hit, pos);
+#if !MDH_RAD_REDERIVE
+      if (valid) atlas_store(pr.rad, pr.fmt, atlas_index(pr.pcx, pr.rres, pr.rshift, i, j), c);
+      if (valid && ro.steps) // the ray's sort key: the levels of its primary-march and soft-shadow step counts
+         ro.steps[(size_t)(probe_raw - pr.probe_begin) * (pr.rres * pr.rres) + y * pr.rres + x] = (unsigned char)((rad_level(ph.steps & 0xffff) << 4) | rad_level(ph.steps >> 16));
+#endif
+   }
+#if MDH_RAD_REDERIVE
+   // The texel again: nothing of the prologue stays live across the pixel program (its coordinates, the order's entry and
+   // the arguments the store needs were eleven dwords that the seven-wavefront build kept in scratch memory).  The lane
+   // index comes from the hardware, the arguments from the kernel argument segment through a pointer the compiler
+   // cannot trace: the same integer operations on the same inputs.
+   {
+      struct KArgs { KScene sc; KProbes pr; int first_round; RadOrder ro; };
+      typedef const KArgs __attribute__((address_space(4))) *KArgsPtr;
+      KArgsPtr ka = (KArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
+      asm volatile("" : "+s"(ka));
+      typedef const int __attribute__((address_space(4))) *IntPtr;
+      KProbes pr2;
+      RadOrder ro2;
+      {
+         IntPtr pp = (IntPtr)&ka->pr, po = (IntPtr)&ka->ro;
+         int *dp = (int *)&pr2, *dq = (int *)&ro2;
+#pragma unroll
+         for (int q = 0; q < (int)(sizeof(KProbes) / 4); ++q) dp[q] = pp[q];
+#pragma unroll
+         for (int q = 0; q < (int)(sizeof(RadOrder) / 4); ++q) dq[q] = po[q];
+      }
+      int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+      asm volatile("" : "+s"(wave));
+      const long lin = (long)blockIdx.x * MDH_BLOCK + wave * 64 + lane_index_fresh();
+      int x, y, probe_raw;
+      radiance_texel(pr2, ro2, lin, x, y, probe_raw);
+      if (probe_raw < pr2.probe_end) {
+         const int ty = probe_raw / pr2.pcx, tx = probe_raw - ty * pr2.pcx;
+         const int i = tx * pr2.rres + x, j = ty * pr2.rres + y;
+         atlas_store(pr2.rad, pr2.fmt, atlas_index(pr2.pcx, pr2.rres, pr2.rshift, i, j), c);
+         if (ro2.steps) // the ray's sort key: the levels of its primary-march and soft-shadow step counts
+            ro2.steps[(size_t)(probe_raw - pr2.probe_begin) * (pr2.rres * pr2.rres) + y * pr2.rres + x] = (unsigned char)((rad_level(ph.steps & 0xffff) << 4) | rad_level(ph.steps >> 16));
+      }
+   }
+#endif
    PH_KERNEL_END();
 }
 

@@ -253,6 +253,12 @@ template <int SLOT> MDH_DEV float park_load1(const float *pk, int wb)
 #ifndef MDH_QVIS_FAR_FIRST
 #define MDH_QVIS_FAR_FIRST 1
 #endif
+#ifndef MDH_MATERIAL_PER_LIGHT
+#define MDH_MATERIAL_PER_LIGHT 1
+#endif
+#ifndef MDH_QVIS_REDERIVE
+#define MDH_QVIS_REDERIVE 1
+#endif
 #ifndef MDH_QVIS_REFILL
 #define MDH_QVIS_REFILL 16 // idle lanes that trigger a refill
 #endif
@@ -473,7 +479,7 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
             if (h) park_store3<MDH_PARK_SPEC>(pk, wb, radiance_with_specular<PART>(sc, pr, pk, wb, ro + rd * t, u8_tab));
          } else
          if (h) {
-            const f3 P = ro + rd * t;
+            f3 P = ro + rd * t;
             int index = -1;
             (void)sdf_info<PART>(sc, P, index);
             f3 N;
@@ -495,10 +501,19 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
                // ---- compute_direct_lighting (lighting.glsl:1-40) at P, seen along rd
                f3 Lo = F3(0.0f, 0.0f, 0.0f);
                {
-                  Material m = get_material(sc, pm);
-                  if (ctx && !full2) m.albedo = F3(0.0f, 0.0f, 0.0f); // render_probes.glsl:202-205
 #pragma unroll 1
                   for (int li = 0; li < sc.total_lights; ++li) {
+                     // (the material is read again for every light, through an id the compiler cannot look through: read
+                     //  once in front of the loop, what the BRDF derives from it -- F0, 1 - F0, k -- is hoisted and then
+                     //  lives across the shadow march: eight dwords of scratch memory per ray in the seven-wavefront builds)
+#if MDH_MATERIAL_PER_LIGHT
+                     int pm_l = pm;
+                     asm volatile("" : "+v"(pm_l));
+                     Material m = get_material(sc, pm_l);
+#else
+                     Material m = get_material(sc, pm);
+#endif
+                     if (ctx && !full2) m.albedo = F3(0.0f, 0.0f, 0.0f); // render_probes.glsl:202-205
                      f3 L;
                      float L_dist;
                      f3 radiance = sample_light<(PART & MDH_PF_CUSTOM) != 0>(sc, li, P, N, L, L_dist);
@@ -545,7 +560,7 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
                } else {
                   // ---- the 8 cage probes of P (render_probes.glsl:13-63 and :156-184)
                   const KProbes pg = probes_fresh(pr);
-                  const i3 gp = world_to_grid(pg, P);
+                  i3 gp = world_to_grid(pg, P);
                   // sample_irradiance at this point (the first point; the second one in mode 3), or the best cage probe of the second
                   const bool irrp = ctx == 0 || full2;
                   // irrp: acc = sum sqrt(irradiance) * w, accw = sum w; else: acc = best probe_to_spec, accw = best weight
@@ -556,11 +571,25 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
                   // probe grid along an axis: all six walls of the example rooms are) name the SAME probe,
                   // hence the same visibility ray: its result is reused instead of marched again.
                   // bit a of `folded`: corners differing only in axis a coincide.
-                  const int folded = ((gp.x < 0 || gp.x >= pg.gx - 1) ? 1 : 0) | ((gp.y < 0 || gp.y >= pg.gy - 1) ? 2 : 0) |
-                                     ((gp.z < 0 || gp.z >= pg.gz - 1) ? 4 : 0);
+                  int folded = ((gp.x < 0 || gp.x >= pg.gx - 1) ? 1 : 0) | ((gp.y < 0 || gp.y >= pg.gy - 1) ? 2 : 0) |
+                               ((gp.z < 0 || gp.z >= pg.gz - 1) ? 4 : 0);
                   int vis_bits = 0; // bit i: visibility of corner i
                   PH_ADD(pt, 2);
-                  if (QVIS && ctx == 0) vis_bits = queued_visibility<PART>(sc, pr, pk, P, N, gp, folded, sd0);
+                  if (QVIS && ctx == 0) {
+                     vis_bits = queued_visibility<PART>(sc, pr, pk, P, N, gp, folded, sd0);
+#if MDH_QVIS_REDERIVE
+                     // Nothing of the point stays in registers across the queue (it is the pass's longest loop, and the
+                     // kernel is built for seven wavefronts per SIMD: what stayed live -- P, N, the cage cell, twenty dwords
+                     // -- went to scratch and back, 45 MB per launch at BASELINE config 3).  P and N wait in their park rows,
+                     // where the queue itself reads them; the cage cell and its folds are derived again: the same operations
+                     // on the same values.
+                     P = park_load3<0>(pk, wb);
+                     N = park_load3<3>(pk, wb);
+                     const KProbes pg2 = probes_fresh(pr);
+                     gp = world_to_grid(pg2, P);
+                     folded = ((gp.x < 0 || gp.x >= pg2.gx - 1) ? 1 : 0) | ((gp.y < 0 || gp.y >= pg2.gy - 1) ? 2 : 0) | ((gp.z < 0 || gp.z >= pg2.gz - 1) ? 4 : 0);
+#endif
+                  }
                   PH_ADD(pt, 5);
                   // (Reusing the whole irradiance term of a folded corner's twin through a small register ring was
                   // measured: the 16 extra VGPRs cost what the taps saved -- DESIGN.md, dropped experiments.)
