@@ -242,7 +242,12 @@ enum {
     * took, and later passes start the tiles in that order, slowest first (a pass ends with its slowest wavefront: in
     * image order the passes of the reference's scenes spend 15 - 45 % of their time waiting for a few late, long
     * tiles); re-sorted after camera moves and geometry edits; 0 = tiles in image order. */
-   MDH_OPT_SCREEN_ORDER = 15
+   MDH_OPT_SCREEN_ORDER = 15,
+   /* READ-ONLY: 0 = this library computes the oracle's bits (DESIGN.md "numerics contract": the only kind that ships);
+    * 1 = the labelled experiment build (`make -C madarch_amd/csrc fast`: hardware sqrt / rcp / log / exp, fused
+    * multiply-adds, the irradiance fold in four partial sums), which holds BASELINE.json's 1e-4 tolerance at best.
+    * Setting it to anything but the build's own value is refused. */
+   MDH_OPT_NUMERICS = 16
 };
 
 /* passes of Renderers.Render (madarch-renderers.adb:302-321) */

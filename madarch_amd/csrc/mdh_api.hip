@@ -38,7 +38,11 @@ static int seterr(int code, const char *msg)
    } while (0)
 
 extern "C" const char *mdh_last_error(void) { return g_err; }
-extern "C" const char *mdh_version(void) { return "madarch-hip 0.1 (gfx950)"; }
+#if MDH_FAST_NUMERICS
+extern "C" const char *mdh_version(void) { return "madarch-hip 0.3 (gfx950) FAST-NUMERICS EXPERIMENT BUILD: tolerance only, not the oracle's bits"; }
+#else
+extern "C" const char *mdh_version(void) { return "madarch-hip 0.3 (gfx950)"; }
+#endif
 
 // ------------------------------------------------------------------ std140 layout
 // = GPU_Types (support/gpu_types-base.ads:21-37, gpu_types-structs.adb:11-38,
@@ -948,6 +952,7 @@ extern "C" int32_t mdh_set_option(mdh_renderer *r, int32_t option, int32_t value
    case MDH_OPT_HYSTERESIS_PERMILLE: if (value < 0 || value > 999) return seterr(MDH_E_INVALID, "hysteresis is 0 .. 999 per mille"); r->opt_hyst = value; break;
    case MDH_OPT_RADIANCE_ORDER: r->opt_rad_order = value ? 1 : 0; r->rad_order_rays = 0; break;
    case MDH_OPT_SCREEN_ORDER: r->opt_scr_order = value ? 1 : 0; r->scr_order_cur = -1; break;
+   case MDH_OPT_NUMERICS: if (value != MDH_FAST_NUMERICS) return seterr(MDH_E_STATE, "the numerics are a property of the library build (make fast builds the experiment)"); break;
    default: return seterr(MDH_E_INVALID, "unknown option");
    }
    return MDH_OK;
@@ -972,6 +977,7 @@ extern "C" int32_t mdh_get_option(mdh_renderer *r, int32_t option, int32_t *valu
    case MDH_OPT_HYSTERESIS_PERMILLE: *value = r->opt_hyst; break;
    case MDH_OPT_RADIANCE_ORDER: *value = r->opt_rad_order; break;
    case MDH_OPT_SCREEN_ORDER: *value = r->opt_scr_order; break;
+   case MDH_OPT_NUMERICS: *value = MDH_FAST_NUMERICS; break;
    default: return seterr(MDH_E_INVALID, "unknown option");
    }
    return MDH_OK;
@@ -1558,6 +1564,10 @@ static int run_pass(mdh_renderer *r, int pass, hipStream_t st, int src, int dst,
       if (r->opt_world > 1 && r->opt_irr_all) { pr.probe_begin = 0; pr.probe_end = probe_total(r); } // every rank, every probe
       int n = pr.probe_end - pr.probe_begin; // one workgroup per probe, its taps staged in LDS
       size_t lds = (size_t)2 * pr.rres * pr.rres * sizeof(float4);
+#if MDH_FAST_NUMERICS
+      if (pr.ires * pr.ires <= 64) lds += (size_t)4 * 64 * sizeof(float4); // (the experiment's fold: all taps staged, four partial sums per texel)
+      else
+#endif
       if (MDH_IRR_CHUNK && pr.ires * pr.ires <= 64 && lds > (size_t)4 * MDH_IRR_CHUNK * sizeof(float4)) lds = (size_t)4 * MDH_IRR_CHUNK * sizeof(float4); // two chunk buffers
       if (lds > 64 * 1024) { // radiance tiles beyond 45 x 45 texels: up to the whole 160 KiB of a CU (70 x 70)
          if (lds > 160 * 1024) return seterr(MDH_E_INVALID, "radiance resolution too large for the irradiance pass (160 KiB of LDS: at most 70)");

@@ -211,8 +211,19 @@ MDH_DEV float min0_raw(float a) { return min_(a, 0.0f); }
 // compiler's own nine instructions, hence its result, for every input that it does not rescale: 0, anything from
 // 2^-96 up, infinities and NaN (for 0 both residual tests fail and the 0 of v_sqrt_f32 stands).  For callers that
 // KNOW their operand is no positive number below 2^-96.
+// MDH_FAST_NUMERICS: the LABELLED EXPERIMENT build (`make -C madarch_amd/csrc fast`, never the shipped library): what the
+// path would cost under BASELINE.json's tolerance (1e-4 relative per channel) instead of this build's own contract (the
+// oracle's bits) -- the hardware's v_sqrt_f32 / v_rcp_f32 / v_log_f32 / v_exp_f32 as GLSL on any GPU uses them, fused
+// multiply-adds, the irradiance fold in four partial sums.  scripts/numerics_experiment.py measures the rate and counts
+// the pixels that leave the tolerance.
+#ifndef MDH_FAST_NUMERICS
+#define MDH_FAST_NUMERICS 0
+#endif
 MDH_DEV float sqrt_unscaled_(float x)
 {
+#if MDH_FAST_NUMERICS
+   return __builtin_amdgcn_sqrtf(x);
+#endif
    float s = __builtin_amdgcn_sqrtf(x);
    const int si = __float_as_int(s);
    const float sd = __int_as_float(si - 1), su = __int_as_float(si + 1);
@@ -223,6 +234,9 @@ MDH_DEV float sqrt_unscaled_(float x)
 }
 MDH_DEV float sqrt_(float x)
 {
+#if MDH_FAST_NUMERICS
+   return __builtin_amdgcn_sqrtf(x);
+#endif
 #if MDH_FAST_EXACT_SQRT
    if (__builtin_expect(x < 0x1p-96f && x > 0.0f, 0)) return __builtin_sqrtf(x);
    return sqrt_unscaled_(x);
@@ -361,9 +375,16 @@ MDH_DEV float log2_(float x)
    p = p * s2 + 1.0f;
    return (float)e + ((2.0f * s) * p) * 1.44269502162933349609375f;
 }
+#if MDH_FAST_NUMERICS
+MDH_DEV float exp_(float x) { return __builtin_amdgcn_exp2f(x * 1.44269502162933349609375f); }
+#else
 MDH_DEV float exp_(float x) { return exp2_(x * 1.44269502162933349609375f); }
+#endif
 MDH_DEV float pow_(float x, float y)
 {
+#if MDH_FAST_NUMERICS
+   return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x)); // (v_log_f32 is log2; 0 -> -inf -> 0, negative -> NaN)
+#endif
    if (x != x || x < 0.0f) return __builtin_nanf("");
    if (x == 0.0f) return 0.0f;
    if (x > 3.40282347e+38f) return x;

@@ -523,6 +523,38 @@ __global__ __launch_bounds__(MDH_IRR_BLOCK) void k_irradiance(KProbes pr, const 
       s_taps[2 * (slot_)] = make_float4(rad.x, rad.y, rad.z, 1.0f);                                                      \
       s_taps[2 * (slot_) + 1] = make_float4(rad_dir.x, rad_dir.y, rad_dir.z, 0.0f);                                      \
    } while (0)
+#if MDH_FAST_NUMERICS
+   if (pr.ires * pr.ires <= 64 && MDH_IRR_BLOCK == 256) {
+      // The experiment's fold: every wavefront folds a QUARTER of the taps for all texels, the four partial sums are added
+      // in a fixed order, (0 + 1) + (2 + 3) -- not the reference's order of additions (a tolerance-only result), but a
+      // quarter of the pass's critical path.
+      for (int t = threadIdx.x; t < ntaps; t += MDH_IRR_BLOCK) MDH_IRR_STAGE(t, t);
+      __syncthreads();
+      const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+      const int x = lane % pr.ires, y = lane / pr.ires;
+      const int i = tx * pr.ires + x, j = ty * pr.ires + y;
+      const f2 nc = F2((centre(i, pr.pcx * pr.ires) + 1.0f) * 0.5f, (centre(j, pr.pcy * pr.ires) + 1.0f) * 0.5f);
+      const f3 irr_dir = ray_id_to_ray_dir(F2(fract_(nc.x * pcx), fract_(nc.y * pcy)));
+      float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      const int t0 = wv * (ntaps / 4), t1 = wv == 3 ? ntaps : t0 + ntaps / 4;
+      for (int t = t0; t < t1; ++t) {
+         const float4 r = s_taps[2 * t], d = s_taps[2 * t + 1];
+         const float w = max_(dot(irr_dir, xyz(d)), 0.0f);
+         acc.x += r.x * w; acc.y += r.y * w; acc.z += r.z * w; acc.w += w;
+      }
+      float4 *part = s_taps + 2 * ntaps;
+      part[wv * 64 + lane] = acc;
+      __syncthreads();
+      if (wv == 0 && lane < pr.ires * pr.ires) {
+         const float4 a = part[lane], b = part[64 + lane], c = part[128 + lane], d = part[192 + lane];
+         const f3 sum = F3((a.x + b.x) + (c.x + d.x), (a.y + b.y) + (c.y + d.y), (a.z + b.z) + (c.z + d.z));
+         const f3 irradiance = sum / ((a.w + b.w) + (c.w + d.w));
+         const unsigned idx = atlas_index(pr.pcx, pr.ires, pr.ishift, i, j);
+         atlas_store(pr.irr, pr.fmt, idx, irradiance_blend(pr, prev, hyst, idx, irradiance));
+      }
+      return;
+   }
+#endif
 #if MDH_IRR_CHUNK
    if (pr.ires * pr.ires <= 64) {
       // One wavefront folds (a lane per texel): the taps go through LDS in chunks of MDH_IRR_CHUNK, two buffers --
