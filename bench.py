@@ -137,8 +137,16 @@ def cpu_baseline(workload):
         if dt > 10.0 or frames >= 64:
             break
     mpix = R.Width * R.Height * frames / dt / 1e6
+    # the work of one frame as the reference's shaders do it: SDF evaluations over all passes
+    import ctypes as C
+    lib = oracle_binding().lib
+    evals = 0
+    for p in range(5):
+        out = (C.c_uint64 * 3)()
+        lib.orc_work_counters(R._h, p, out)
+        evals += int(out[2])
     R.Destroy()
-    return {"value": round(mpix, 4), "unit": "Mpixels/s", "cores": cores, "kind": "port",
+    return {"value": round(mpix, 4), "unit": "Mpixels/s", "cores": cores, "kind": "port", "sdf_evals_per_frame": evals,
             "sample": "%d full %dx%d frames of the same workload (%.1f s) after 1 warm-up frame, all passes, OpenMP over rows" % (frames, R.Width, R.Height, dt)}
 
 
@@ -394,6 +402,9 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.workload)
             out["cpu_baseline_exprs"] = cpu_baseline_exprs()
+            # the reference's work per second: what the oracle evaluates for a frame / the GPU's frame time (the kernels do
+            # less: DESIGN.md section 4 "Exact work elimination"; tests/test_gpu_work_counters.py holds the counts)
+            out["useful_sdf_evals_per_s"] = round(out["cpu_baseline"]["sdf_evals_per_frame"] / (dt / args.steps), 1)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -311,6 +311,9 @@ struct mdh_renderer {
    double pass_ms[MDH_PASS_COUNT] = {0};
    long long pass_n[MDH_PASS_COUNT] = {0};
    hipStream_t own_stream = nullptr;
+#ifdef MDH_DIAG
+   unsigned long long work[MDH_PASS_COUNT][4] = {{0}}; // g_work of the last run of each pass (mdh_diag_work)
+#endif
    // the communicator of a sharded run (mdh_comm_init): one rank per process and GPU.  With it mdh_render runs the
    // exchange of the atlas slices itself, on the probe stream, between the probe passes.
    ncclComm_t comm = nullptr;
@@ -1731,6 +1734,14 @@ static int run_pass(mdh_renderer *r, int pass, hipStream_t st, int src, int dst,
       HIP_TRY(hipEventRecord(e1, st));
       r->pending.push_back({pass, e0, e1}); // (folded at frame boundaries: bound_timing)
    }
+#ifdef MDH_DIAG
+   { // the diagnostic build waits for every pass and takes its work counters
+      HIP_TRY(hipStreamSynchronize(st));
+      HIP_TRY(hipMemcpyFromSymbol(r->work[pass], HIP_SYMBOL(g_work), sizeof r->work[pass]));
+      unsigned long long z[4] = {0, 0, 0, 0};
+      HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_work), z, sizeof z));
+   }
+#endif
    return MDH_OK;
 }
 
@@ -2497,6 +2508,14 @@ extern "C" int32_t mdh_partition_warnings(mdh_renderer *r)
 }
 
 #ifdef MDH_DIAG
+// rays started, SDF evaluations inside march loops, SDF evaluations in all, arg-min evaluations at hit points (lanes) of the
+// last run of `pass`: what the oracle reports as orc_work_counters
+extern "C" int32_t mdh_diag_work(mdh_renderer *r, int32_t pass, unsigned long long *out4)
+{
+   if (!r || !out4 || pass < 0 || pass >= MDH_PASS_COUNT) return MDH_E_INVALID;
+   memcpy(out4, r->work[pass], sizeof r->work[pass]);
+   return MDH_OK;
+}
 // debug: read and reset the lane-utilisation counters of mdh_march.h
 extern "C" int32_t mdh_diag_read(unsigned long long *out16)
 {

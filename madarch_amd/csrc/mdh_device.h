@@ -154,8 +154,19 @@ __device__ unsigned long long g_diag[16];
          atomicAdd(&g_diag[2 * (type) + 1], (unsigned long long)__popcll(m_));              \
       }                                                                                     \
    } while (0)
+// the work of a launch as the oracle counts it (orc_work_counters) -- slot 0 rays started,
+// 1 SDF evaluations inside march loops (a step that reuses the shared first evaluation counts: it is a step of the ray),
+// 2 SDF evaluations in all, 3 of them the arg-min evaluations at hit points (the kernels march without the arg-min and
+// evaluate it once at the hit; the reference's raycast carries it through every step) -- lanes, not wavefronts.
+__device__ unsigned long long g_work[4];
+#define MDH_WORK(slot)                                                                      \
+   do {                                                                                     \
+      unsigned long long m_ = __ballot(1);                                                  \
+      if ((threadIdx.x & 63) == __ffsll((long long)m_) - 1) atomicAdd(&g_work[slot], (unsigned long long)__popcll(m_)); \
+   } while (0)
 #else
 #define MDH_DIAG_STEP(type) do { } while (0)
+#define MDH_WORK(slot) do { } while (0)
 #endif
 // ------------------------------------------------------------------------------ vec math
 struct f3 { float x, y, z; };
@@ -1003,6 +1014,7 @@ template <bool CUSTOM, bool FALLBACK> MDH_DEV float partitioning_closest_bits(co
 #define MDH_PF_HAS_FALLBACK(PART) ((((PART) & MDH_PF_FALLBACK) != 0) || (((PART) & MDH_PF_CUSTOM) != 0))
 template <int PART> MDH_DEV float sdf(const KScene &sc, f3 x)
 {
+   MDH_WORK(2);
    int dummy;
    (void)dummy;
    if (PART & MDH_PF_PART) return MDH_PART_BITS ? partitioning_closest_bits<(PART & MDH_PF_CUSTOM) != 0, MDH_PF_HAS_FALLBACK(PART)>(sc, x) : partitioning_lookup<false, (PART & MDH_PF_CUSTOM) != 0, MDH_PF_HAS_FALLBACK(PART)>(sc, x, dummy);
@@ -1011,6 +1023,7 @@ template <int PART> MDH_DEV float sdf(const KScene &sc, f3 x)
 // the same with the first sphere and box already in registers (sdf_regs)
 template <int PART> MDH_DEV float sdf(const KScene &sc, f3 x, const SdfRegs &regs)
 {
+   MDH_WORK(2);
    int dummy;
    (void)dummy;
    if (PART & MDH_PF_PART) return MDH_PART_BITS ? partitioning_closest_bits<(PART & MDH_PF_CUSTOM) != 0, MDH_PF_HAS_FALLBACK(PART)>(sc, x) : partitioning_lookup<false, (PART & MDH_PF_CUSTOM) != 0, MDH_PF_HAS_FALLBACK(PART)>(sc, x, dummy);
@@ -1018,6 +1031,7 @@ template <int PART> MDH_DEV float sdf(const KScene &sc, f3 x, const SdfRegs &reg
 }
 template <int PART> MDH_DEV float sdf_info(const KScene &sc, f3 x, int &index)
 {
+   MDH_WORK(2);
    if (PART & MDH_PF_PART) return partitioning_lookup<true, (PART & MDH_PF_CUSTOM) != 0, MDH_PF_HAS_FALLBACK(PART)>(sc, x, index);
    return closest_primitive_info<(PART & MDH_PF_CUSTOM) != 0>(sc, x, index);
 }
@@ -1027,7 +1041,9 @@ template <int PART> MDH_DEV float sdf_info(const KScene &sc, f3 x, int &index)
 template <int PART> MDH_DEV bool raycast(const KScene &sc, f3 from, f3 dir, int &index, f3 &coll, float &t_out, int &steps)
 {
    int n = 0;
+   MDH_WORK(0);
    for (float total = 0.0f; total < sc.max_dist;) {
+      MDH_WORK(1);
       float dist = sdf_info<PART>(sc, from + dir * total, index);
       ++n;
       if (dist < MDH_EPS) {
@@ -1044,7 +1060,9 @@ template <int PART> MDH_DEV bool raycast(const KScene &sc, f3 from, f3 dir, int 
 // glsl/raymarching.glsl:39-56: raycast_visibility = 1 - float(hit)
 template <int PART> MDH_DEV float raycast_visibility(const KScene &sc, f3 from, f3 dir, float max_dist)
 {
+   MDH_WORK(0);
    for (float total = 0.0f; total < max_dist;) {
+      MDH_WORK(1);
       float dist = sdf<PART>(sc, from + dir * total);
       if (dist < MDH_EPS) return 0.0f;
       total += dist;

@@ -106,8 +106,10 @@ template <int PART> MDH_DEV bool march_plain(const KScene &sc, f3 o, f3 d, float
    // the first sphere and box stay in registers for the whole march (measured: +0.7 %; the same in the shadow,
    // visibility-queue and occlusion marches ±0, in the per-corner visibility march -1 %: register pressure)
    const SdfRegs regs = sdf_regs(sc);
+   MDH_WORK(0);
    while (total < tmax) {
       MDH_DIAG_STEP(0);
+      MDH_WORK(1);
       float dist = sdf<PART>(sc, o + d * total, regs);
       ++n;
       if (dist < MDH_EPS) { h = true; break; }
@@ -339,6 +341,7 @@ MDH_DEV int queued_visibility(const KScene &sc, const KProbes &pr, float *pk, f3
 #else
          MDH_DIAG_STEP(3);
 #endif
+         MDH_WORK(1);
          const float sd = sdf<PART>(sc, o + d * total);
          if (sd < MDH_EPS) job = -1; // blocked: the bit stays 0
          else {
@@ -383,7 +386,9 @@ MDH_DEV f3 radiance_with_specular(const KScene &sc, const KProbes &pr, const flo
       float res = 1.0f, prev = 1e20f;
       bool blocked = false;
       const float tmax = distance - MDH_MIN_STEP * 5.0f;
+      MDH_WORK(0);
       for (float total = MDH_MIN_STEP * 5.0f; total < tmax;) { // softshadows (spec_pos, -probe_to_spec, .., 0.5)
+         MDH_WORK(1);
          const float dist = sdf<PART>(sc, spec_pos + (-pts) * total);
          if (dist < MDH_EPS) { blocked = true; break; }
          const float y = dist * dist / (2.0f * prev);
@@ -481,6 +486,7 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
          if (h) {
             f3 P = ro + rd * t;
             int index = -1;
+            MDH_WORK(3);
             (void)sdf_info<PART>(sc, P, index);
             f3 N;
             int pm;
@@ -535,8 +541,10 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
                         float res = 1.0f, prev = 1e20f, total = 0.0f;
                         bool blocked = false;
                         bool first = MDH_SHARE_FIRST_STEP != 0;
+                        MDH_WORK(0);
                         while (total < L_dist) {
                            MDH_DIAG_STEP(1 + ctx);
+                           MDH_WORK(1);
                            if (SPEC == 0) ph.steps += 1 << 16; // (the radiance pass's sort key: shadow steps above the primary ones)
                            float dist = first ? sd0 : sdf<PART>(sc, from_off + L * total);
                            first = false;
@@ -618,7 +626,7 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
 #pragma unroll 1
                   for (int i = 0; i < 8; ++i) {
                      // best probe: a folded corner has the weight of its twin, which is not strictly larger
-                     if (!irrp && (i & folded)) continue;
+                     if (MDH_REUSE_FOLDED && !irrp && (i & folded)) continue;
                      KProbes pq = probes_fresh(pr); // (live up to the visibility march, read again behind it)
                      f3 s_term = F3(0.0f, 0.0f, 0.0f); // sqrt(irradiance tap) of this corner's probe
                      float wpre = 0.0f;                // its weight before the trilinear factor
@@ -669,8 +677,11 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
                      if (false)
 #endif
                      if (!(QVIS && !REFLECT)) // (with the queue and no second point this loop is dead code)
+                     MDH_WORK(0);
+                     if (!(QVIS && !REFLECT))
                      while (total < vmax) {
                         MDH_DIAG_STEP(3 + ctx);
+                        MDH_WORK(1);
                         float sd = first ? sd0 : sdf<PART>(sc, from_off + vd * total);
                         first = false;
                         if (sd < MDH_EPS) { vis = 0.0f; break; }

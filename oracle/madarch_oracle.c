@@ -130,10 +130,14 @@ struct orc_renderer {
    int opt_atlas, opt_mode, opt_ao, opt_gbuffer, opt_rank, opt_world, opt_timing, opt_ada_div, opt_irr_all, opt_window, opt_spec, opt_hyst;
    int opt_sdf_mode, opt_threads;
    uint64_t sdf_evals; /* closest_primitive[_info] calls of the last pass set */
+   /* the work of the last run of each pass -- rays started (raycast, raycast_hit_position /
+      raycast_visibility, softshadows), SDF evaluations inside their march loops, SDF evaluations in all (+ the
+      occlusion taps, lighting.glsl:51-69); a -DMDH_DIAG build of the kernels reports the same three (orc_work_counters) */
+   uint64_t work[MDH_PASS_COUNT][3];
 };
 typedef struct orc_renderer orc_renderer;
 
-static __thread uint64_t t_sdf_evals;
+static __thread uint64_t t_sdf_evals, t_rays, t_steps;
 
 /* Single'Image prints 6 significant digits; literals that travel through the
  * generated GLSL text lose the rest (scenes.adb:21-24,1200-1201; renderers.adb:119-134) */
@@ -564,8 +568,10 @@ static float softshadows(const orc_renderer *r, v3 from, v3 dir, float min_dist,
 {
    float res = 1.0f;
    float prev_dist = 1e20f;
+   ++t_rays;
    for (float total = min_dist; total < max_dist;) {
       float dist = partitioning_closest(r, add(from, scale(dir, total)));
+      ++t_steps;
       if (dist < ORC_EPSILON) return 0.0f;
       float y = dist * dist / (2.0f * prev_dist);
       float d = sqrtf(dist * dist - y * y);
@@ -579,9 +585,11 @@ static float softshadows(const orc_renderer *r, v3 from, v3 dir, float min_dist,
 static int raycast(const orc_renderer *r, v3 from, v3 dir, int *index, v3 *coll, float *t_out, int *steps)
 {
    int n = 0;
+   ++t_rays;
    for (float total = 0.0f; total < r->max_dist;) {
       float dist = partitioning_closest_info(r, add(from, scale(dir, total)), index);
       ++n;
+      ++t_steps;
       if (dist < ORC_EPSILON) {
          *coll = add(from, scale(dir, total));
          if (t_out) *t_out = total;
@@ -596,8 +604,10 @@ static int raycast(const orc_renderer *r, v3 from, v3 dir, int *index, v3 *coll,
 /* glsl/raymarching.glsl:39-51 */
 static int raycast_hit_position(const orc_renderer *r, v3 from, v3 dir, float max_dist, v3 *coll)
 {
+   ++t_rays;
    for (float total = 0.0f; total < max_dist;) {
       float dist = partitioning_closest(r, add(from, scale(dir, total)));
+      ++t_steps;
       if (dist < ORC_EPSILON) {
          *coll = add(from, scale(dir, total));
          return 1;
@@ -1100,10 +1110,10 @@ static void pass_radiance(orc_renderer *r)
    pass_cfg cfg = {0, 0, 0, 0, 0}; /* renderers.adb:115-117; AO/volumetrics macros undefined (Q12) */
    int pb, pe;
    own_probes(r, &pb, &pe);
-   uint64_t evals = 0;
-#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads(r)) reduction(+ : evals)
+   uint64_t evals = 0, rays = 0, steps = 0;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads(r)) reduction(+ : evals, rays, steps)
    for (int j = 0; j < t->h; ++j) {
-      t_sdf_evals = 0;
+      t_sdf_evals = 0; t_rays = 0; t_steps = 0;
       for (int i = 0; i < t->w; ++i) {
          v2 nc = V2((centre(i, t->w) + 1.0f) * 0.5f, (centre(j, t->h) + 1.0f) * 0.5f);
          int probe_id = coord_to_probe_id(r, nc);
@@ -1114,9 +1124,10 @@ static void pass_radiance(orc_renderer *r)
          float o[3] = {c.x, c.y, c.z};
          tex_store(t, i, j, o);
       }
-      evals += t_sdf_evals;
+      evals += t_sdf_evals; rays += t_rays; steps += t_steps;
    }
    r->sdf_evals += evals;
+   r->work[MDH_PASS_RADIANCE][0] = rays; r->work[MDH_PASS_RADIANCE][1] = steps; r->work[MDH_PASS_RADIANCE][2] = evals;
 }
 
 /* update_probe_irradiance.glsl:8-43 */
@@ -1168,10 +1179,10 @@ static void pass_visibility(orc_renderer *r)
    tex_t *t = &r->tex[MDH_TEX_VISIBILITY];
    float dz = (float)r->vol.visibility_resolution[2];
    float vstep = image_roundtrip(r->vol.visibility_step_size);
-   uint64_t evals = 0;
-#pragma omp parallel for schedule(dynamic, 4) num_threads(nthreads(r)) reduction(+ : evals)
+   uint64_t evals = 0, rays = 0, steps = 0;
+#pragma omp parallel for schedule(dynamic, 4) num_threads(nthreads(r)) reduction(+ : evals, rays, steps)
    for (int j = 0; j < t->h; ++j) {
-      t_sdf_evals = 0;
+      t_sdf_evals = 0; t_rays = 0; t_steps = 0;
       for (int i = 0; i < t->w; ++i) {
          float px = centre(i, t->w), py = centre(j, t->h);
          float norm_height = (py + 1.0f) * 0.5f;
@@ -1195,9 +1206,10 @@ static void pass_visibility(orc_renderer *r)
          float o[3] = {result.x, result.y, result.z};
          tex_store(t, i, j, o);
       }
-      evals += t_sdf_evals;
+      evals += t_sdf_evals; rays += t_rays; steps += t_steps;
    }
    r->sdf_evals += evals;
+   r->work[MDH_PASS_VISIBILITY][0] = rays; r->work[MDH_PASS_VISIBILITY][1] = steps; r->work[MDH_PASS_VISIBILITY][2] = evals;
 }
 
 /* accumulate_scattering.glsl:9-48 */
@@ -1209,10 +1221,10 @@ static void pass_scattering(orc_renderer *r)
    float vstep = image_roundtrip(r->vol.visibility_step_size);
    float sstep = image_roundtrip(r->vol.scattering_step_size);
    float max_depth = vstep * dz; /* volumetrics.glsl:3-4 */
-   uint64_t evals = 0;
-#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads(r)) reduction(+ : evals)
+   uint64_t evals = 0, rays = 0, steps = 0;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads(r)) reduction(+ : evals, rays, steps)
    for (int j = 0; j < t->h; ++j) {
-      t_sdf_evals = 0;
+      t_sdf_evals = 0; t_rays = 0; t_steps = 0;
       for (int i = 0; i < t->w; ++i) {
          float px = centre(i, t->w), py = centre(j, t->h);
          v3 from, dir;
@@ -1233,9 +1245,10 @@ static void pass_scattering(orc_renderer *r)
          float o[4] = {L.x, L.y, L.z, len};
          tex_store(t, i, j, o);
       }
-      evals += t_sdf_evals;
+      evals += t_sdf_evals; rays += t_rays; steps += t_steps;
    }
    r->sdf_evals += evals;
+   r->work[MDH_PASS_SCATTERING][0] = rays; r->work[MDH_PASS_SCATTERING][1] = steps; r->work[MDH_PASS_SCATTERING][2] = evals;
 }
 
 /* 8x8 screen tiles dealt round-robin over the ranks of a sharded run */
@@ -1250,10 +1263,10 @@ static void pass_screen(orc_renderer *r)
 {
    pass_cfg cfg = {1, r->opt_spec, r->opt_ao, r->vol.enabled ? 1 : 0, r->opt_mode}; /* renderers.adb:136-143; MDH_OPT_INDIRECT_SPECULAR */
    if (cfg.mode != 0) cfg.volumetrics = 0;
-   uint64_t evals = 0;
-#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads(r)) reduction(+ : evals)
+   uint64_t evals = 0, rays = 0, steps = 0;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads(r)) reduction(+ : evals, rays, steps)
    for (int j = 0; j < r->H; ++j) {
-      t_sdf_evals = 0;
+      t_sdf_evals = 0; t_rays = 0; t_steps = 0;
       for (int i = 0; i < r->W; ++i) {
          float *o = r->fb + ((size_t)j * r->W + i) * 3;
          if (r->opt_world > 1 && tile_owner(r, i, j) != r->opt_rank) { o[0] = o[1] = o[2] = 0.0f; continue; }
@@ -1267,9 +1280,10 @@ static void pass_screen(orc_renderer *r)
             c = V3(pow_(c.x / (c.x + 1.0f), 0.4545f), pow_(c.y / (c.y + 1.0f), 0.4545f), pow_(c.z / (c.z + 1.0f), 0.4545f));
          o[0] = c.x; o[1] = c.y; o[2] = c.z;
       }
-      evals += t_sdf_evals;
+      evals += t_sdf_evals; rays += t_rays; steps += t_steps;
    }
    r->sdf_evals += evals;
+   r->work[MDH_PASS_SCREEN][0] = rays; r->work[MDH_PASS_SCREEN][1] = steps; r->work[MDH_PASS_SCREEN][2] = evals;
 }
 
 /* ---------------------------------------------------------------------- C ABI */
@@ -1772,6 +1786,13 @@ int32_t orc_read_partitioning(orc_renderer *r, int32_t *out, int32_t n_ints)
 
 /* oracle-only probes for the unit tests ------------------------------------ */
 uint64_t orc_sdf_evals(orc_renderer *r) { return r ? r->sdf_evals : 0; }
+/* rays, march steps and SDF evaluations of the last run of `pass` */
+int32_t orc_work_counters(orc_renderer *r, int32_t pass, uint64_t out[3])
+{
+   if (!r || !out || pass < 0 || pass >= MDH_PASS_COUNT) return seterr(MDH_E_INVALID, "bad argument");
+   memcpy(out, r->work[pass], sizeof r->work[pass]);
+   return MDH_OK;
+}
 int32_t orc_partition_warnings(orc_renderer *r) { return r ? r->part_warnings : 0; }
 
 /* closest_primitive_info / partitioning_closest_info at n points */
