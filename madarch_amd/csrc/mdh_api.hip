@@ -1497,7 +1497,7 @@ static int run_pass(mdh_renderer *r, int pass, hipStream_t st, int src, int dst,
       if (n > 0) {
          // the rays in the order of the previous pass's primary-march lengths (RadOrder, mdh_kernels.h)
          const long rays = (long)(pr.probe_end - pr.probe_begin) * pr.rres * pr.rres;
-         RadOrder ro = {nullptr, nullptr, (int)rays};
+         RadOrder ro = {nullptr, nullptr, (int)rays, 64};
          // (chunks of whole workgroup strides, at most MDH_RO_MAX_CHUNKS of them)
          const long ro_chunk = std::max(2048l, ((rays + MDH_RO_MAX_CHUNKS - 1) / MDH_RO_MAX_CHUNKS + 1023) / 1024 * 1024);
          const int ro_chunks = (int)((rays + ro_chunk - 1) / ro_chunk);
@@ -1525,6 +1525,16 @@ static int run_pass(mdh_renderer *r, int pass, hipStream_t st, int src, int dst,
             // passes besides -- the sort kernels (20 us) are out of almost every frame.
             ++r->rad_order_age;
             if (!have || r->rad_order_age >= MDH_RAD_RESORT || (r->rad_order_scene != r->geometry_edits && r->rad_order_age >= MDH_RAD_RESORT_MOVING)) ro.steps = r->d_rad_steps;
+         }
+         // RadOrder::fill: quarter or half filled wavefronts for launches that leave most slots of the chip empty.  Measured
+         // (rank 0's radiance slice of an 8-way sharded frame, 1 024 full wavefronts on 1 024 SIMDs): 0.094 ms full, 0.096 ms
+         // half filled, 0.125 ms quarter filled (profiles/r03_x_radiance_partial_fill.log) -- the rays are sorted by their
+         // march lengths already, so a wavefront's lanes end together whatever their number, and four wavefronts of 16 issue
+         // four times the instructions.  Dropped: full wavefronts unless MADARCH_HIP_RAD_FILL says otherwise.
+         {
+            static const int fill_env = [] { const char *e = getenv("MADARCH_HIP_RAD_FILL"); return e ? atoi(e) : 0; }();
+            ro.fill = fill_env == 16 || fill_env == 32 ? fill_env : 64;
+            n = (n + ro.fill - 1) / ro.fill * 64;
          }
          int blocks = (int)((n + MDH_BLOCK - 1) / MDH_BLOCK);
          const size_t lds = lds_bytes_march(r);

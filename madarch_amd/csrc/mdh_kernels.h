@@ -230,6 +230,11 @@ struct RadOrder {
    const unsigned *order; // [n_rays] ray at every place, or nullptr: rays in probe order
    unsigned char *steps;  // [n_rays] every ray's sort key (rad_level of its primary-march and shadow steps), written by the pass; or nullptr
    int n_rays;
+   // Lanes of every wavefront that carry a ray: 64, or 32 / 16 for launches that would leave most wavefront slots of
+   // the chip empty (a rank's slice of a sharded frame: 1 024 full wavefronts on 1 024 SIMDs, each alone on its SIMD and
+   // paying every latency of its dependency chain in full).  Spread over four times as many wavefronts the same rays
+   // hide each other's latencies, and a wavefront's marches end with the longest of 16 rays instead of 64.
+   int fill;
 };
 // `first_round`: the workgroups the chip holds at once (0: not told).  The pass is ONE round of wavefronts and a
 // remainder -- 8 192 wavefronts on 7 168 slots at the headline size -- and ends with its slowest wavefront.  A SIMD
@@ -242,6 +247,11 @@ struct RadOrder {
 MDH_DEV void radiance_texel(const KProbes &pr, const RadOrder &ro, long lin, int &x, int &y, int &probe_raw)
 {
    const int per_probe = pr.rres * pr.rres;
+   if (ro.fill < 64) { // the launch's lanes that carry rays, renumbered: wavefront w holds rays w * fill .. w * fill + fill - 1
+      const int l = (int)(lin & 63);
+      if (l >= ro.fill) { x = y = 0; probe_raw = pr.probe_end; return; }
+      lin = (lin >> 6) * ro.fill + l;
+   }
    // a wavefront = a TxT texel tile (T*T = 64 / G) of the octahedral maps of G consecutive probes:
    // G = 1 is one 8x8 tile of one probe, G = 64 the same ray direction from 64 probes
    constexpr int G = MDH_RAD_PROBES_PER_WAVE, T = (G == 1) ? 8 : (G == 4) ? 4 : (G == 16) ? 2 : 1;
@@ -490,6 +500,13 @@ __global__ __launch_bounds__(256) void k_order_floor(unsigned char *keys, int n,
 #ifndef MDH_IRR_PREFETCH
 #define MDH_IRR_PREFETCH 1
 #endif
+#ifndef MDH_IRR_FOLD_WAVES
+// wavefronts that fold a probe's taps: 1 = one carries all four channels; 2 = (x, y) on one and (z, weight) on another -- the
+// same bits with 7 instead of 13 instructions per tap and wavefront, measured SLOWER (0.040 against 0.038 ms for 512 probes,
+// with two, four or six staging wavefronts beside them: profiles/r03_x_irradiance_two_folders.log): the fold does not wait
+// for its instructions but for its taps' LDS reads, and two wavefronts read every tap twice.  Kept as a switch; default 1.
+#define MDH_IRR_FOLD_WAVES 1
+#endif
 #ifndef MDH_IRR_CHUNK
 #define MDH_IRR_CHUNK 256 // taps per LDS buffer when one wavefront folds (0 = all taps staged at once)
 #endif
@@ -557,12 +574,16 @@ __global__ __launch_bounds__(MDH_IRR_BLOCK) void k_irradiance(KProbes pr, const 
 #endif
 #if MDH_IRR_CHUNK
    if (pr.ires * pr.ires <= 64) {
-      // One wavefront folds (a lane per texel): the taps go through LDS in chunks of MDH_IRR_CHUNK, two buffers --
-      // while the first wavefront folds chunk c, the other three stage chunk c + 1.  The same taps in the same
-      // order; a quarter of the LDS (room for the march kernels' workgroups beside it) and the staging hidden.
+      // One wavefront folds (a lane per texel) -- or two (MDH_IRR_FOLD_WAVES: the sums of a texel's four channels are four
+      // independent chains of additions, so one wavefront can carry (x, y) and another (z, weight), each with the
+      // reference's taps in the reference's order: the same bits).  The taps go through LDS in chunks of MDH_IRR_CHUNK,
+      // two buffers: while the folding wavefronts work on chunk c, the others stage chunk c + 1.  The same taps in the
+      // same order; a quarter of the LDS (room for the march kernels' workgroups beside it) and the staging hidden.
       constexpr int CH = MDH_IRR_CHUNK;
+      constexpr int FOLDERS = MDH_IRR_FOLD_WAVES; // 1 or 2
       const int nchunks = (ntaps + CH - 1) / CH;
-      const int x = threadIdx.x % pr.ires, y = threadIdx.x / pr.ires; // (used by the folding lanes only)
+      const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+      const int x = lane % pr.ires, y = lane / pr.ires; // (used by the folding lanes only)
       const int i = tx * pr.ires + x, j = ty * pr.ires + y;
       const f2 nc = F2((centre(i, pr.pcx * pr.ires) + 1.0f) * 0.5f, (centre(j, pr.pcy * pr.ires) + 1.0f) * 0.5f);
       const f3 irr_dir = ray_id_to_ray_dir(F2(fract_(nc.x * pcx), fract_(nc.y * pcy)));
@@ -573,56 +594,59 @@ __global__ __launch_bounds__(MDH_IRR_BLOCK) void k_irradiance(KProbes pr, const 
       for (int c = 0; c < nchunks; ++c) {
          const int base = c * CH, n_here = min(CH, ntaps - base);
          const float4 *buf = s_taps + (size_t)(c & 1) * 2 * CH;
-         if (threadIdx.x < 64) {
-            if ((int)threadIdx.x < pr.ires * pr.ires) {
-#define MDH_IRR_FOLD(r_, d_)                                                                  \
+         if (wv < FOLDERS) {
+            if (lane < pr.ires * pr.ires) {
+               // WHICH: 0 = all four channels (one folding wavefront), 1 = (x, y), 2 = (z, weight)
+#define MDH_IRR_FOLD(WHICH, r_, d_)                                                           \
                do {                                                                           \
                   const float4 r = (r_), d = (d_);                                            \
                   const pk2 d_xy = {d.x, d.y}, r_xy = {r.x, r.y}, r_z1 = {r.z, r.w};          \
                   const pk2 p = dir_xy * d_xy;                                                \
                   const float w = max_((p.x + p.y) + irr_dir.z * d.z, 0.0f);                  \
                   const pk2 ww = {w, w};                                                      \
-                  acc_xy = acc_xy + r_xy * ww;                                                \
-                  acc_zw = acc_zw + r_z1 * ww;                                                \
+                  if (WHICH != 2) acc_xy = acc_xy + r_xy * ww;                                \
+                  if (WHICH != 1) acc_zw = acc_zw + r_z1 * ww;                                \
                } while (0)
-#if MDH_IRR_PREFETCH
-               // six taps per turn in two groups of three, each group on its way from LDS while the other is folded (this
-               // one wavefront is the pass's critical path: 1 024 taps in the reference's order, each waiting for its two LDS
-               // reads otherwise).  Three: two groups in flight are 12 LDS reads, and the counter a wavefront waits on
-               // holds 15.
-               constexpr int GR = 3;
-               const int nt = n_here - n_here % (2 * GR);
-               int t = 0;
-               float4 ra[GR], da[GR], rb[GR], db[GR];
-               if (nt > 0) {
-#pragma unroll
-                  for (int k = 0; k < GR; ++k) { ra[k] = buf[2 * k]; da[k] = buf[2 * k + 1]; }
-               }
-#pragma unroll 1
-               for (; t < nt; t += 2 * GR) {
-#pragma unroll
-                  for (int k = 0; k < GR; ++k) { rb[k] = buf[2 * (t + GR + k)]; db[k] = buf[2 * (t + GR + k) + 1]; }
-#pragma unroll
-                  for (int k = 0; k < GR; ++k) MDH_IRR_FOLD(ra[k], da[k]);
-                  const int tn = t + 2 * GR < nt ? t + 2 * GR : t; // (the last turn reads its own taps again)
-#pragma unroll
-                  for (int k = 0; k < GR; ++k) { ra[k] = buf[2 * (tn + k)]; da[k] = buf[2 * (tn + k) + 1]; }
-#pragma unroll
-                  for (int k = 0; k < GR; ++k) MDH_IRR_FOLD(rb[k], db[k]);
-               }
-               for (; t < n_here; ++t) MDH_IRR_FOLD(buf[2 * t], buf[2 * t + 1]);
-#else
-               for (int t = 0; t < n_here; ++t) MDH_IRR_FOLD(buf[2 * t], buf[2 * t + 1]);
-#endif
+               // six taps per turn in two groups of three, each group on its way from LDS while the other is folded (the
+               // folding wavefronts are the pass's critical path: 1 024 taps in the reference's order, each waiting for its two
+               // LDS reads otherwise).  Three: two groups in flight are 12 LDS reads, and the counter a wavefront waits on holds 15.
+#define MDH_IRR_FOLD_CHUNK(WHICH)                                                             \
+               do {                                                                           \
+                  constexpr int GR = 3;                                                       \
+                  const int nt = n_here - n_here % (2 * GR);                                  \
+                  int t = 0;                                                                  \
+                  float4 ra[GR], da[GR], rb[GR], db[GR];                                      \
+                  if (nt > 0) {                                                               \
+                     _Pragma("unroll") for (int k = 0; k < GR; ++k) { ra[k] = buf[2 * k]; da[k] = buf[2 * k + 1]; } \
+                  }                                                                           \
+                  _Pragma("unroll 1") for (; t < nt; t += 2 * GR) {                           \
+                     _Pragma("unroll") for (int k = 0; k < GR; ++k) { rb[k] = buf[2 * (t + GR + k)]; db[k] = buf[2 * (t + GR + k) + 1]; } \
+                     _Pragma("unroll") for (int k = 0; k < GR; ++k) MDH_IRR_FOLD(WHICH, ra[k], da[k]); \
+                     const int tn = t + 2 * GR < nt ? t + 2 * GR : t; /* (the last turn reads its own taps again) */ \
+                     _Pragma("unroll") for (int k = 0; k < GR; ++k) { ra[k] = buf[2 * (tn + k)]; da[k] = buf[2 * (tn + k) + 1]; } \
+                     _Pragma("unroll") for (int k = 0; k < GR; ++k) MDH_IRR_FOLD(WHICH, rb[k], db[k]); \
+                  }                                                                           \
+                  for (; t < n_here; ++t) MDH_IRR_FOLD(WHICH, buf[2 * t], buf[2 * t + 1]);    \
+               } while (0)
+               if (FOLDERS == 1) MDH_IRR_FOLD_CHUNK(0);
+               else if (wv == 0) MDH_IRR_FOLD_CHUNK(1);
+               else MDH_IRR_FOLD_CHUNK(2);
+#undef MDH_IRR_FOLD_CHUNK
 #undef MDH_IRR_FOLD
             }
          } else if (c + 1 < nchunks) {
             const int nbase = base + CH, n_next = min(CH, ntaps - nbase), off = ((c + 1) & 1) * CH;
-            for (int t = (int)threadIdx.x - 64; t < n_next; t += MDH_IRR_BLOCK - 64) MDH_IRR_STAGE(nbase + t, off + t);
+            for (int t = (int)threadIdx.x - 64 * FOLDERS; t < n_next; t += MDH_IRR_BLOCK - 64 * FOLDERS) MDH_IRR_STAGE(nbase + t, off + t);
          }
          __syncthreads();
       }
-      if ((int)threadIdx.x < pr.ires * pr.ires) {
+      if (FOLDERS == 2) { // (z, weight) of every texel to the first wavefront, through the tap buffers (no longer read)
+         pk2 *hand = (pk2 *)s_taps;
+         if (wv == 1) hand[lane] = acc_zw;
+         __syncthreads();
+         if (wv == 0) acc_zw = hand[lane];
+      }
+      if (wv == 0 && lane < pr.ires * pr.ires) {
          const f3 irradiance = F3(acc_xy.x, acc_xy.y, acc_zw.x) / acc_zw.y;
          const unsigned idx = atlas_index(pr.pcx, pr.ires, pr.ishift, i, j);
          atlas_store(pr.irr, pr.fmt, idx, irradiance_blend(pr, prev, hyst, idx, irradiance));
