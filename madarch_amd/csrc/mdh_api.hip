@@ -409,7 +409,7 @@ static int part_mask_words(const mdh_renderer *r)
 {
    int declared = 0;
    for (int k = 0; k < r->npk; ++k) declared += r->pk[k].max_count;
-   return declared > 0 ? (declared + 31) / 32 : 1;
+   return declared > 32 ? (declared + 31) / 32 : 2; // (at least two: scenes of up to 64 primitives read a cell's bits as one 8-byte pair)
 }
 static size_t part_bits_ints(const mdh_renderer *r) { return ((size_t)r->part_cells * part_mask_words(r) + 3) / 4 * 4; }
 static size_t part_buffer_ints(const mdh_renderer *r) { return part_table_ints(r) + part_bits_ints(r); }
@@ -670,6 +670,18 @@ static int commit_scene(mdh_renderer *r, hipStream_t up)
    s.part_mask_off = (int)part_table_ints(r);
    s.part_mask_words = part_mask_words(r);
    s.part_bits_f4 = part_bits_f4(r);
+   { // KScene::part_small: one 8-byte load per lookup, a shift and a mask per built-in type
+      int declared = 0;
+      bool small = r->part.enable != 0;
+      for (int ty = 0; ty < 4; ++ty) { s.part_tbit[ty] = 0u; s.part_tmask[ty] = 0u; }
+      for (int k = 0; k < r->npk; ++k) {
+         const Kind &kd = r->pk[k];
+         if (kd.type == PK_CUSTOM || kd.max_count > 32) small = false;
+         else if (kd.max_count > 0) { s.part_tbit[kd.type] = (unsigned)r->prim_base[k]; s.part_tmask[kd.type] = kd.max_count == 32 ? 0xffffffffu : ((1u << kd.max_count) - 1u); }
+         declared += kd.max_count;
+      }
+      s.part_small = small && declared <= 64 && part_mask_words(r) == 2 ? 1 : 0;
+   }
    r->table_dirty = false;
    return MDH_OK;
 }

@@ -64,6 +64,12 @@ struct KScene {
    const int *part_table; // [cell][nk + index_count], then the same lists as bits: [cell][part_mask_words] at int part_mask_off
    int part_mask_off, part_mask_words; // (partitioning_closest_bits below)
    int part_bits_f4; // float4 count of the bits when every workgroup stages them into LDS behind the scene table (0: read from memory)
+   // Small scenes (no user-defined kinds, at most 64 declared primitives, at most 32 of a kind -- every scene of the
+   // reference's examples): a cell's bits are ONE 8-byte load and every built-in TYPE's candidates one shift and mask of
+   // it -- part_tbit = the first bit of the type's kind, part_tmask = its declared count as a mask (0: no such kind) --
+   // so the lookup is straight-line code without the table's kind headers (partitioning_closest_bits).
+   int part_small;
+   unsigned part_tbit[4], part_tmask[4];
 };
 // int block at table[0..]: per-kind data in SCENE order (the order the flat primitive index
 // and the arg-min tie-break follow, scenes.adb:656-666) and the light kinds
@@ -637,6 +643,9 @@ MDH_DEV float prim_dist(int type, int slot, f3 x)
 #ifndef MDH_FAST_INFO
 #define MDH_FAST_INFO 1
 #endif
+#ifndef MDH_PART_SMALL
+#define MDH_PART_SMALL 1 // small scenes walk a cell's bits in straight-line code (KScene::part_small)
+#endif
 #ifndef MDH_PART_BITS
 #define MDH_PART_BITS 1 // the distance-only partition lookup walks a cell's candidates as bits (partitioning_closest_bits)
 #endif
@@ -921,6 +930,35 @@ template <bool INFO, bool CUSTOM, bool FALLBACK = true> MDH_DEV float partitioni
 // per cell for simple_scene, 16 KB for the whole grid instead of 184 KB.  A lane loads its cell's dwords (one or two
 // loads per step) and walks its set bits; the loop over kinds stays wave-uniform, so the type dispatch is scalar and
 // lanes in the same cell gather the same primitive (an LDS broadcast).
+// A lane's set bits of one built-in type, two at a time: both gathers are in flight before either distance is computed (a
+// lane's last odd candidate is evaluated twice -- the minimum does not change, and the wave waits for its longest list
+// anyway).  Lanes whose rays are in the same cell -- most of an 8 x 8 tile's -- gather the same primitive at the same time
+// (an LDS broadcast).  `t` = the first float4 of the instance bit 0 stands for.
+template <int TYPE> MDH_DEV float walk_bits(unsigned w, const float4 *t, f3 x, float closest)
+{
+   if (TYPE == PK_TRIANGLE) {
+      while (w) { const int pi = __builtin_ctz(w); w &= w - 1u; closest = min_raw(closest, sd_triangle<false>(xyz(t[3 * pi]), xyz(t[3 * pi + 1]), xyz(t[3 * pi + 2]), x)); }
+      return closest;
+   }
+   while (w) {
+      MDH_DIAG_STEP(6);
+      const int p0 = __builtin_ctz(w);
+      w &= w - 1u;
+      const int p1 = w ? __builtin_ctz(w) : p0;
+      w &= w - 1u; // (0 & 0xffffffff = 0)
+      if (TYPE == PK_SPHERE) {
+         const float4 a0 = t[p0], a1 = t[p1];
+         closest = min_raw(min_raw(closest, sd_sphere(a0, x)), sd_sphere(a1, x));
+      } else if (TYPE == PK_PLANE) {
+         const float4 a0 = t[p0], a1 = t[p1];
+         closest = min_raw(min_raw(closest, sd_plane(a0, x)), sd_plane(a1, x));
+      } else {
+         const float4 a0 = t[2 * p0], b0 = t[2 * p0 + 1], a1 = t[2 * p1], b1 = t[2 * p1 + 1];
+         closest = min_raw(min_raw(closest, sd_box(a0, b0, x)), sd_box(a1, b1, x));
+      }
+   }
+   return closest;
+}
 // FALLBACK: the kernel variant of scenes whose Border_Behavior is Fallback (a point outside the grid scans every
 // primitive, scenes.adb:943-957).  Scenes that clamp -- the reference's own -- run variants without that scan: inlined, its
 // loops sat in every march loop of the partition kernels (a quarter of their code).
@@ -932,6 +970,19 @@ template <bool CUSTOM, bool FALLBACK> MDH_DEV float partitioning_closest_bits(co
    float closest = sc.max_dist;
    if (cell < 0 || cell >= sc.part_cells) return closest;
    MDH_DIAG_STEP(5); // lookups that reach a cell
+   if (!CUSTOM && MDH_PART_SMALL && sc.part_small) { // (wave-uniform) straight-line code: one load, a shift and a mask per type
+      typedef const unsigned long long __attribute__((address_space(1))) *GlobalPairs;
+      const unsigned long long mm = ((GlobalPairs)(sc.part_table + sc.part_mask_off))[cell];
+      uint2 m;
+      m.x = (unsigned)mm; m.y = (unsigned)(mm >> 32);
+#define MDH_TYPE_BITS(T) ((sc.part_tbit[T] < 32u ? __builtin_amdgcn_alignbit(m.y, m.x, sc.part_tbit[T]) : m.y >> (sc.part_tbit[T] - 32u)) & sc.part_tmask[T])
+      if (sc.part_tmask[PK_PLANE]) closest = walk_bits<PK_PLANE>(MDH_TYPE_BITS(PK_PLANE), s_tab + sc.tslot[PK_PLANE], x, closest);
+      if (sc.part_tmask[PK_SPHERE]) closest = walk_bits<PK_SPHERE>(MDH_TYPE_BITS(PK_SPHERE), s_tab + sc.tslot[PK_SPHERE], x, closest);
+      if (sc.part_tmask[PK_BOX]) closest = walk_bits<PK_BOX>(MDH_TYPE_BITS(PK_BOX), s_tab + sc.tslot[PK_BOX], x, closest);
+      if (sc.part_tmask[PK_TRIANGLE]) closest = walk_bits<PK_TRIANGLE>(MDH_TYPE_BITS(PK_TRIANGLE), s_tab + sc.tslot[PK_TRIANGLE], x, closest);
+#undef MDH_TYPE_BITS
+      return closest;
+   }
    typedef const unsigned __attribute__((address_space(1))) *GlobalWords;
    const int nk = hdr(H_NK), nw = sc.part_mask_words;
    const bool in_lds = sc.part_bits_f4 > 0; // (wave-uniform: the whole grid's bits are staged behind the scene table)
@@ -963,44 +1014,13 @@ template <bool CUSTOM, bool FALLBACK> MDH_DEV float partitioning_closest_bits(co
             if ((threadIdx.x & 63) == __ffsll((long long)m_) - 1) { atomicAdd(&g_diag[14], 1ull); atomicAdd(&g_diag[15], (unsigned long long)pc_); }
          }
 #endif
-         // the type is wave-uniform: one loop per type, each lane walking its own set bits, two at a time: both gathers
-         // are in flight before either distance is computed (a lane's last odd candidate is evaluated twice -- the minimum
-         // does not change, and the wave waits for its longest list anyway).  Lanes whose rays are in the same cell --
-         // most of an 8 x 8 tile's -- gather the same primitive at the same time (an LDS broadcast).
-#define MDH_BITS_PAIR(p0_, p1_)                                                              \
-         MDH_DIAG_STEP(6);                                                                   \
-         const int p0_ = __builtin_ctz(w);                                                   \
-         w &= w - 1u;                                                                        \
-         const int p1_ = w ? __builtin_ctz(w) : p0_;                                         \
-         w &= w - 1u /* (0 & 0xffffffff = 0) */
+         // the type is wave-uniform: one walk per type (walk_bits)
          if (CUSTOM && type == PK_CUSTOM) {
             while (w) { const int pi = c + __builtin_ctz(w); w &= w - 1u; closest = min_raw(closest, xdist<false>(k, pi, x)); }
-         } else if (type == PK_SPHERE) {
-            const float4 *t = s_tab + s0 + c;
-            while (w) {
-               MDH_BITS_PAIR(p0, p1);
-               const float4 a0 = t[p0], a1 = t[p1];
-               closest = min_raw(min_raw(closest, sd_sphere(a0, x)), sd_sphere(a1, x));
-            }
-         } else if (type == PK_PLANE) {
-            const float4 *t = s_tab + s0 + c;
-            while (w) {
-               MDH_BITS_PAIR(p0, p1);
-               const float4 a0 = t[p0], a1 = t[p1];
-               closest = min_raw(min_raw(closest, sd_plane(a0, x)), sd_plane(a1, x));
-            }
-         } else if (type == PK_BOX) {
-            const float4 *t = s_tab + s0 + 2 * c;
-            while (w) {
-               MDH_BITS_PAIR(p0, p1);
-               const float4 a0 = t[2 * p0], b0 = t[2 * p0 + 1], a1 = t[2 * p1], b1 = t[2 * p1 + 1];
-               closest = min_raw(min_raw(closest, sd_box(a0, b0, x)), sd_box(a1, b1, x));
-            }
-         } else {
-            const float4 *t = s_tab + s0 + 3 * c;
-            while (w) { const int pi = __builtin_ctz(w); w &= w - 1u; closest = min_raw(closest, sd_triangle<false>(xyz(t[3 * pi]), xyz(t[3 * pi + 1]), xyz(t[3 * pi + 2]), x)); }
-         }
-#undef MDH_BITS_PAIR
+         } else if (type == PK_SPHERE) closest = walk_bits<PK_SPHERE>(w, s_tab + s0 + c, x, closest);
+         else if (type == PK_PLANE) closest = walk_bits<PK_PLANE>(w, s_tab + s0 + c, x, closest);
+         else if (type == PK_BOX) closest = walk_bits<PK_BOX>(w, s_tab + s0 + 2 * c, x, closest);
+         else closest = walk_bits<PK_TRIANGLE>(w, s_tab + s0 + 3 * c, x, closest);
       }
    }
    return closest;
