@@ -973,9 +973,7 @@ template <bool CUSTOM, bool FALLBACK> MDH_DEV float partitioning_closest_bits(co
    if (!CUSTOM && MDH_PART_SMALL && sc.part_small) { // (wave-uniform) straight-line code: one load, a shift and a mask per type
       typedef const unsigned long long __attribute__((address_space(1))) *GlobalPairs;
       const unsigned long long mm = ((GlobalPairs)(sc.part_table + sc.part_mask_off))[cell];
-      uint2 m;
-      m.x = (unsigned)mm; m.y = (unsigned)(mm >> 32);
-#define MDH_TYPE_BITS(T) ((sc.part_tbit[T] < 32u ? __builtin_amdgcn_alignbit(m.y, m.x, sc.part_tbit[T]) : m.y >> (sc.part_tbit[T] - 32u)) & sc.part_tmask[T])
+#define MDH_TYPE_BITS(T) ((unsigned)(mm >> sc.part_tbit[T]) & sc.part_tmask[T]) /* (one 64-bit shift by a scalar) */
       if (sc.part_tmask[PK_PLANE]) closest = walk_bits<PK_PLANE>(MDH_TYPE_BITS(PK_PLANE), s_tab + sc.tslot[PK_PLANE], x, closest);
       if (sc.part_tmask[PK_SPHERE]) closest = walk_bits<PK_SPHERE>(MDH_TYPE_BITS(PK_SPHERE), s_tab + sc.tslot[PK_SPHERE], x, closest);
       if (sc.part_tmask[PK_BOX]) closest = walk_bits<PK_BOX>(MDH_TYPE_BITS(PK_BOX), s_tab + sc.tslot[PK_BOX], x, closest);
