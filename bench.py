@@ -406,8 +406,14 @@ def main():
             # less: DESIGN.md section 4 "Exact work elimination"; tests/test_gpu_work_counters.py holds the counts)
             out["useful_sdf_evals_per_s"] = round(out["cpu_baseline"]["sdf_evals_per_frame"] / (dt / args.steps), 1)
         print(json.dumps(out), flush=True)
+    # leave in order: the communicator while every rank is still here, then the renderer, then the control plane
+    if how == "rccl":
+        R.Comm_Barrier()
+        R.Comm_Destroy()
     if dist is not None:
         dist.barrier()
+    R.Destroy()
+    if dist is not None:
         dist.destroy_process_group()
 
 

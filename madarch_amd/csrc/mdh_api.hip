@@ -161,6 +161,9 @@ static float image_roundtrip(float x)
 
 // -------------------------------------------------------------------- the renderer
 #define MAX_MATERIALS 20 // glsl/materials.glsl:9
+#ifndef MDH_ATLAS_SETS
+#define MDH_ATLAS_SETS 3 // sets of probe atlases (and volumetric textures) that pipelined frames rotate through
+#endif
 // how often the probe rays (MDH_OPT_RADIANCE_ORDER) and the screen tiles (MDH_OPT_SCREEN_ORDER) are sorted again: every
 // MDH_RAD_RESORT passes, and after MDH_RAD_RESORT_MOVING passes when the geometry (or, for the tiles, the camera) changed
 #ifndef MDH_RAD_RESORT
@@ -231,7 +234,11 @@ struct mdh_renderer {
    // Two sets of probe atlases.  `last` is the set the most recent frame wrote: every read, write and
    // single pass works on it in place.  A pipelined mdh_render (frame overlap, see mdh_render) writes the
    // other set while the previous frame's screen pass still reads this one, then flips.
-   void *d_rad2[2] = {nullptr, nullptr}, *d_irr2[2] = {nullptr, nullptr};
+   // (MDH_ATLAS_SETS of them, three since round 3: with two, the probe passes of frame N + 1 write the set the screen pass of
+   //  frame N - 1 still reads and wait for it -- the chain screen (N - 1) -> probes (N + 1) -> screen (N + 1) bound the frame
+   //  rate of pipelined frames; with three they wait for the screen pass of frame N - 2, long gone)
+   static const int NSETS = MDH_ATLAS_SETS;
+   void *d_rad2[NSETS] = {nullptr}, *d_irr2[NSETS] = {nullptr};
    int n_cus = 0;                          // compute units of the device
    // RadOrder (mdh_kernels.h): every ray's primary-march steps, the rays sorted by them, the sort's histograms
    unsigned char *d_rad_steps = nullptr;
@@ -262,9 +269,9 @@ struct mdh_renderer {
    std::string jit_kinds; // mdh_jit_kinds.h of this scene (generated once)
    hipStream_t probe_stream = nullptr;   // radiance + irradiance passes of pipelined frames
    hipStream_t alt_stream = nullptr;     // screen pass of every other pipelined frame
-   hipEvent_t ev_screen[2] = {nullptr, nullptr}, ev_probe[2] = {nullptr, nullptr}, ev_join = nullptr, ev_join_alt = nullptr;
-   hipEvent_t ev_vol[2] = {nullptr, nullptr}; // the camera-only volumetric passes of a pipelined frame (on vol_stream, beside its probe passes)
-   bool ev_screen_valid[2] = {false, false};
+   hipEvent_t ev_screen[NSETS] = {nullptr}, ev_probe[NSETS] = {nullptr}, ev_join = nullptr, ev_join_alt = nullptr;
+   hipEvent_t ev_vol[NSETS] = {nullptr}; // the camera-only volumetric passes of a pipelined frame (on vol_stream, beside its probe passes)
+   bool ev_screen_valid[NSETS] = {false};
    bool alt_pending = false; // work on alt_stream that `stream` has not been ordered after yet
    // an open frame (mdh_frame_begin .. mdh_frame_end)
    bool in_frame = false, frame_pipelined = false;
@@ -274,8 +281,8 @@ struct mdh_renderer {
    bool main_dirty = true; // work went to `stream` outside a pipelined frame since the probe stream last joined it
    // froxel and scattering textures, one per atlas set: the volumetric passes of a pipelined frame run on the
    // probe stream into the set that frame produces
-   float *d_vis2[2] = {nullptr, nullptr};
-   float4 *d_scat2[2] = {nullptr, nullptr};
+   float *d_vis2[NSETS] = {nullptr};
+   float4 *d_scat2[NSETS] = {nullptr};
    float4 *d_fb2[2] = {nullptr, nullptr}; // two framebuffers: consecutive pipelined frames draw on two streams
    int fb_last = 0;                       // the one the most recent frame drew
    // mdh_swap_buffers: a ring of RGBA8 copies of a framebuffer, each a device buffer (written on the stream that
@@ -737,7 +744,7 @@ static KVolumetrics make_vol(const mdh_renderer *r, bool enabled, int set)
 
 static int alloc_atlases(mdh_renderer *r)
 {
-   for (int s = 0; s < 2; ++s) {
+   for (int s = 0; s < mdh_renderer::NSETS; ++s) {
       if (r->d_rad2[s]) HIP_TRY(hipFree(r->d_rad2[s]));
       if (r->d_irr2[s]) HIP_TRY(hipFree(r->d_irr2[s]));
       r->d_rad2[s] = r->d_irr2[s] = nullptr;
@@ -763,13 +770,19 @@ extern "C" int32_t mdh_destroy(mdh_renderer *r)
    if (r->vol_stream) (void)hipStreamSynchronize(r->vol_stream);
    if (r->comm) { ncclComm_t c = r->comm; r->comm = nullptr; (void)rccl_api_destroy(c); }
    if (r->d_comm_scratch) (void)hipFree(r->d_comm_scratch);
-   void *ptrs[] = {r->d_table_ring[0], r->d_table_ring[1], r->d_table_ring[2], r->d_table_ring[3], r->d_part_ring[0], r->d_part_ring[1], r->d_part_ring[2], r->d_part_ring[3], r->d_warn, r->d_query, r->d_rad_steps, r->d_rad_order, r->d_rad_hist, r->d_scr_cost, r->d_scr_order[0], r->d_scr_order[1], r->d_scr_hist, r->d_rad2[0], r->d_irr2[0], r->d_rad2[1], r->d_irr2[1], r->d_vis2[0], r->d_scat2[0], r->d_vis2[1], r->d_scat2[1], r->d_fb2[0], r->d_fb2[1], r->d_gb2[0][0], r->d_gb2[0][1], r->d_gb2[0][2], r->d_gb2[1][0], r->d_gb2[1][1], r->d_gb2[1][2]};
+   void *ptrs[] = {r->d_table_ring[0], r->d_table_ring[1], r->d_table_ring[2], r->d_table_ring[3], r->d_part_ring[0], r->d_part_ring[1], r->d_part_ring[2], r->d_part_ring[3], r->d_warn, r->d_query, r->d_rad_steps, r->d_rad_order, r->d_rad_hist, r->d_scr_cost, r->d_scr_order[0], r->d_scr_order[1], r->d_scr_hist, r->d_fb2[0], r->d_fb2[1], r->d_gb2[0][0], r->d_gb2[0][1], r->d_gb2[0][2], r->d_gb2[1][0], r->d_gb2[1][1], r->d_gb2[1][2]};
    for (void *p : ptrs)
       if (p) (void)hipFree(p);
+   for (int q = 0; q < mdh_renderer::NSETS; ++q)
+      for (void *p : {(void *)r->d_rad2[q], (void *)r->d_irr2[q], (void *)r->d_vis2[q], (void *)r->d_scat2[q]})
+         if (p) (void)hipFree(p);
    for (auto &p : r->pending) { (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1); }
    for (auto e : r->free_events) (void)hipEventDestroy(e);
-   for (hipEvent_t e : {r->ev_screen[0], r->ev_screen[1], r->ev_probe[0], r->ev_probe[1], r->ev_vol[0], r->ev_vol[1], r->ev_join, r->ev_join_alt, r->ev_table})
+   for (hipEvent_t e : {r->ev_join, r->ev_join_alt, r->ev_table})
       if (e) (void)hipEventDestroy(e);
+   for (int q = 0; q < mdh_renderer::NSETS; ++q)
+      for (hipEvent_t e : {r->ev_screen[q], r->ev_probe[q], r->ev_vol[q]})
+         if (e) (void)hipEventDestroy(e);
    for (int q = 0; q < mdh_renderer::TAB_RING; ++q) {
       if (r->h_table_ring[q]) (void)hipHostFree(r->h_table_ring[q]);
       for (int si = 0; si < mdh_renderer::NSTREAMS; ++si)
@@ -880,7 +893,9 @@ extern "C" int32_t mdh_create(int32_t width, int32_t height, const mdh_scene_des
       prio = prio < 0 ? hi : (prio > 0 ? lo : 0);
       TRY_OR_FAIL(hipStreamCreateWithPriority(&r->probe_stream, hipStreamNonBlocking, prio));
       TRY_OR_FAIL(hipStreamCreateWithFlags(&r->alt_stream, hipStreamNonBlocking));
-      for (hipEvent_t *e : {&r->ev_screen[0], &r->ev_screen[1], &r->ev_probe[0], &r->ev_probe[1], &r->ev_vol[0], &r->ev_vol[1], &r->ev_join, &r->ev_join_alt, &r->ev_table}) TRY_OR_FAIL(hipEventCreateWithFlags(e, hipEventDisableTiming));
+      for (hipEvent_t *e : {&r->ev_join, &r->ev_join_alt, &r->ev_table}) TRY_OR_FAIL(hipEventCreateWithFlags(e, hipEventDisableTiming));
+      for (int q = 0; q < mdh_renderer::NSETS; ++q)
+         for (hipEvent_t *e : {&r->ev_screen[q], &r->ev_probe[q], &r->ev_vol[q]}) TRY_OR_FAIL(hipEventCreateWithFlags(e, hipEventDisableTiming));
       // (HIP maps a process's streams onto a few hardware queues, four by default: a fifth stream shares one with another
       //  and their work serialises -- measured: light_shafts lost a fifth of its frame rate.  So the volumetric stream exists
       //  only with volumetrics, and the query stream from the first Eval_Distance_To on.)
@@ -905,7 +920,7 @@ extern "C" int32_t mdh_create(int32_t width, int32_t height, const mdh_scene_des
    size_t vis_n = (size_t)vol->visibility_resolution[0] * vol->visibility_resolution[1] * vol->visibility_resolution[2] * 3;
    size_t scat_n = (size_t)vol->scattering_resolution[0] * vol->scattering_resolution[1];
    if (vis_n / 3 >= (1ull << 32) || scat_n >= (1ull << 32)) { seterr(MDH_E_INVALID, "a volumetrics texture of 2^32 texels or more"); return fail(MDH_E_INVALID); } // (tex_sample: 32-bit texel index)
-   for (int s = 0; s < 2; ++s) {
+   for (int s = 0; s < mdh_renderer::NSETS; ++s) {
       TRY_OR_FAIL(hipMalloc(&r->d_vis2[s], (vis_n ? vis_n : 1) * 4));
       TRY_OR_FAIL(hipMemsetAsync(r->d_vis2[s], 0, (vis_n ? vis_n : 1) * 4, r->stream));
       TRY_OR_FAIL(hipMalloc(&r->d_scat2[s], (scat_n ? scat_n : 1) * sizeof(float4)));
@@ -1816,7 +1831,7 @@ extern "C" int32_t mdh_frame_begin(mdh_renderer *r)
       r->frame_cur = r->last;
    } else {
       // modes 1 and 2 run no probe passes: the atlas sets stay as they are (their screen passes still alternate)
-      const int cur = r->opt_mode == 0 ? r->last ^ 1 : r->last;
+      const int cur = r->opt_mode == 0 ? (r->last + 1) % mdh_renderer::NSETS : r->last;
       if (r->main_dirty) { // the other streams have to see everything that went to the main stream meanwhile
          if ((rc = join_main(r)) != MDH_OK) return rc;
          HIP_TRY(hipEventRecord(r->ev_join, r->stream));
