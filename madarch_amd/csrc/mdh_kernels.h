@@ -287,6 +287,9 @@ MDH_DEV void radiance_texel(const KProbes &pr, const RadOrder &ro, long lin, int
 template <int PART, bool SMALL = false> __global__ __launch_bounds__(MDH_BLOCK, MDH_OCC_RAD(PART, SMALL)) void k_radiance(KScene sc, KProbes pr, int first_round, RadOrder ro)
 {
    if (first_round > 0 && (int)blockIdx.x >= first_round) __builtin_amdgcn_s_setprio(3);
+#if MDH_QVIS_SHARED && MDH_RAD_QVIS
+   qvis_shared_init(sc); // (made visible to the workgroup by the barrier of stage_table)
+#endif
    stage_table(sc);
    f3 c;
    PrimaryHit ph;

@@ -139,8 +139,11 @@ template <int PART> MDH_DEV bool march_plain(const KScene &sc, f3 o, f3 d, float
 #else
 #define MDH_DIRECT_PARK_ROWS 13
 #endif
-#ifdef MDH_PHASES
-#define MDH_PARK_DWORDS 20
+#ifndef MDH_QVIS_SHARED
+#define MDH_QVIS_SHARED 0 // the radiance pass's visibility queue shared by the four wavefronts of a workgroup (queued_visibility_shared)
+#endif
+#if defined(MDH_PHASES) || MDH_QVIS_SHARED || defined(MDH_PARK_PAD) // (MDH_PARK_PAD: what one more row costs, measured by itself)
+#define MDH_PARK_DWORDS 20 // (row 19: the diagnostic's accumulators / the shared queue's second list and counters)
 #else
 #define MDH_PARK_DWORDS 19
 #endif
@@ -359,6 +362,254 @@ MDH_DEV int queued_visibility(const KScene &sc, const KProbes &pr, float *pk, f3
    return bits | words[threadIdx.x];
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// queued_visibility_shared (MDH_QVIS_SHARED) -- the same queue with its END shared by the workgroup.
+//
+// What the per-wavefront queue loses is its end: once its list is handed out a wavefront marches on until its longest
+// ray ends, with 12.6 of 64 lanes alive on average (98 k of the radiance pass's 274 k wave-evaluations).  Here every
+// wavefront still lists its own jobs in its own rows and draws from them, but the lists' heads are LDS counters, so a
+// wavefront whose list is empty draws from its neighbours' (a STOLEN job), and a wavefront down to a few rays while
+// another one still marches DONATES them -- resumable jobs (entry + the distance marched so far) in a second, small
+// list -- and waits for its results instead of marching at a fraction of its width.  The last marching wavefront
+// never donates (a counter of marching wavefronts decides, atomically), so every job is finished by somebody.  Nothing
+// here waits at a barrier (a wavefront that hits nothing never comes here), and every wait is bounded: if a bound were
+// ever reached the results would be wrong and the parity tests would say so, but no wavefront spins for ever.
+//
+// The LDS unit serves the DS instructions of a workgroup's wavefronts one after the other, each wavefront's in program
+// order: a wavefront that sees a counter move sees everything its writer stored before.  The fences below are therefore
+// wavefront-scoped (they order the compiler, not the hardware), and the counters a march step looks at are read one
+// step AHEAD (their latency hides behind the distance evaluation; acting on a stale value is harmless: a draw that comes
+// too late gets nothing).
+//
+// LDS of the workgroup (behind the scene table): rows 12-15 = the four wavefronts' lists (u16 entries lane | corner << 6),
+// row 16 = first-step distances, row 17 = result words, row 19 = the counters and list 2:
+#define QS_ROW 19
+#define QS_LIST 0      // [4] head | njobs << 16 of each wavefront's list (a draw adds to the head, whatever is left)
+#define QS_Q2 4        // head | tail << 16 of list 2 (draws by compare-and-swap: its tail grows)
+#define QS_MARCHING 5  // wavefronts in the march loop
+#define QS_PENDING 8   // [4] per wavefront: its jobs in other wavefronts' hands
+#define QS_E2 64       // [64] entries of list 2 (-1 = not written yet)
+#define QS_T2 128      // [64] distances marched so far
+#ifndef QS_DONATE_MAX
+#define QS_DONATE_MAX 16
+#endif
+#ifndef QS_BISECT
+#define QS_BISECT 0 // (1: the per-wavefront queue inside the shared build; 2: no stealing)
+#endif
+static_assert(QS_DONATE_MAX * 4 <= 64, "list 2 holds one donation of every wavefront");
+#define QS_SPIN_MAX (1 << 16) // (a few milliseconds: a legitimate wait is some tens of march steps)
+#define QS_FOREIGN 0x800      // job bit: counted in QS_PENDING of its owner (stolen or donated)
+MDH_DEV void qvis_shared_init(const KScene &sc) // all threads, before the kernel's first barrier
+{
+   int *ctl = (int *)(park_base(sc) + QS_ROW * MDH_BLOCK);
+   ctl[threadIdx.x] = threadIdx.x >= QS_E2 && threadIdx.x < QS_T2 ? -1 : 0;
+}
+template <int PART>
+MDH_DEV int queued_visibility_shared(const KScene &sc, const KProbes &pr, float *pk, f3 P, f3 N, i3 gp, int folded, float sd0)
+{
+   const int lane = threadIdx.x & 63, wbase = threadIdx.x & ~63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+   const bool leader = lane == (int)__ffsll((long long)__ballot(true)) - 1; // (only the lanes whose point was hit are here)
+   int *words = (int *)(pk + 17 * MDH_BLOCK);
+   int *ctl = (int *)(pk + QS_ROW * MDH_BLOCK);
+   // (reads of what other wavefronts write: relaxed atomic loads through an LDS-typed pointer -- a volatile access
+   // through the generic pointer is a system-scope FLAT load with a full wait behind it, 40 % of the pass when the
+   // counters were read that way)
+   typedef __attribute__((address_space(3))) int *LdsInt;
+   const LdsInt lctl = (LdsInt)ctl;
+#define QS_LD(k) __hip_atomic_load(lctl + (k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define QS_ST(k, v) __hip_atomic_store(lctl + (k), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+   pk[16 * MDH_BLOCK + threadIdx.x] = sd0;
+   words[threadIdx.x] = 0;
+   int bits = 0, njobs = 0;
+   int far = 0;
+#if MDH_QVIS_FAR_FIRST
+   {
+      const f3 lo = grid_to_world(pr, gp);
+      far = ((P.x - lo.x) < (lo.x + pr.sx - P.x) ? 1 : 0) | ((P.y - lo.y) < (lo.y + pr.sy - P.y) ? 2 : 0) | ((P.z - lo.z) < (lo.z + pr.sz - P.z) ? 4 : 0);
+   }
+#endif
+#pragma unroll 1
+   for (int j = 0; j < 8; ++j) { // (as in queued_visibility)
+      const int i = j ^ far;
+      bool need = false;
+      if (!(i & folded)) {
+         const f3 hvec = grid_to_world(pr, cage_probe(pr, gp, i)) - P;
+         const float vmax = length(hvec) - MDH_MIN_STEP * 5.0f;
+         if (!(0.0f < vmax)) bits |= 1 << i;
+         else if (sd0 < MDH_EPS) { }
+         else if (!(sd0 < vmax)) bits |= 1 << i;
+         else need = true;
+      }
+      const unsigned long long m = __ballot(need);
+      if (need) *qvis_entry(pk, wbase, njobs + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))) = (unsigned short)(lane | (i << 6));
+      njobs += __popcll(m);
+   }
+   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+   if (leader) { // the list is open: its length, and one more marching wavefront
+      atomicAdd(&ctl[QS_MARCHING], 1);
+      atomicAdd(&ctl[QS_LIST + wv], njobs << 16);
+   }
+   int job = -1;
+   float total = 0.0f, vmax = 0.0f;
+   f3 o = F3(0.0f, 0.0f, 0.0f), d = F3(0.0f, 0.0f, 0.0f);
+   bool donated = false;
+   const int n_here = (int)__popcll(__ballot(true));
+   const int refill = min((int)MDH_QVIS_REFILL, n_here);
+   int own_left = njobs; // (an upper bound: thieves take from it too)
+   // the counters as they were one step ago
+   int c_list[4] = {0, 0, 0, 0}, c_q2 = 0, c_marching = 0;
+#define QS_OPEN(w) ((c_list[w] & 0xffff) < ((unsigned)c_list[w] >> 16))
+#define QS_READ_COUNTERS() do { c_list[0] = QS_LD(QS_LIST + 0); c_list[1] = QS_LD(QS_LIST + 1); c_list[2] = QS_LD(QS_LIST + 2); c_list[3] = QS_LD(QS_LIST + 3); \
+                                c_q2 = QS_LD(QS_Q2); c_marching = QS_LD(QS_MARCHING); } while (0)
+   for (;;) {
+      const unsigned long long idle = __ballot(job < 0);
+      const int n_idle = __popcll(idle);
+      const int n_active = n_here - n_idle;
+      if (n_idle >= refill) {
+         // where to draw from: the own list, a neighbour's, the donated rays
+         int from = -1;
+         if (own_left > 0) from = wv;
+         else {
+            int any = __builtin_amdgcn_readfirstlane((QS_OPEN(0) ? 1 : 0) | (QS_OPEN(1) ? 2 : 0) | (QS_OPEN(2) ? 4 : 0) | (QS_OPEN(3) ? 8 : 0) |
+                                                           ((c_q2 & 0xffff) < ((unsigned)c_q2 >> 16) ? 16 : 0));
+#if QS_BISECT == 2
+            any = 0; // (no stealing)
+#endif
+            if (any) from = __ffs(any) - 1;
+         }
+         if (from >= 0 && from < 4) {
+            const bool foreign = from != wv;
+            int old = 0;
+            if (leader) {
+               if (foreign) atomicAdd(&ctl[QS_PENDING + from], n_idle); // (before the draw: its owner may be about to look)
+               old = atomicAdd(&ctl[QS_LIST + from], n_idle);
+            }
+            old = __builtin_amdgcn_readfirstlane(old);
+            const int h = old & 0xffff, got = max(0, min(n_idle, (int)((unsigned)old >> 16) - h));
+            if (foreign && leader && got < n_idle) atomicSub(&ctl[QS_PENDING + from], n_idle - got);
+            if (!foreign) own_left = (int)((unsigned)old >> 16) - h - got;
+            if (job < 0) {
+               const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(idle >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)idle, 0u));
+               if (rank < got) {
+                  const int e = *qvis_entry(pk, from * 64, h + rank);
+                  const int owner = from * 64 + (e & 63), corner = e >> 6;
+                  const f3 oP = F3(pk[0 * MDH_BLOCK + owner], pk[1 * MDH_BLOCK + owner], pk[2 * MDH_BLOCK + owner]);
+                  const f3 oN = F3(pk[3 * MDH_BLOCK + owner], pk[4 * MDH_BLOCK + owner], pk[5 * MDH_BLOCK + owner]);
+                  const f3 hvec = grid_to_world(pr, cage_probe(pr, world_to_grid(pr, oP), corner)) - oP;
+                  const float dist = length(hvec);
+                  d = hvec / dist;
+                  vmax = dist - MDH_MIN_STEP * 5.0f;
+                  o = oP + (oN * MDH_MIN_STEP) * 5.0f;
+                  total = pk[16 * MDH_BLOCK + owner];
+                  job = e | (from << 9) | (foreign ? QS_FOREIGN : 0);
+               }
+            }
+            if (foreign || got == 0) { QS_READ_COUNTERS(); }
+            continue; // (the lanes have changed: count them again)
+         } else if (from == 4) { // the donated rays: their list grows, so the draw is a compare-and-swap
+            int h = 0, got = 0;
+            if (leader)
+               for (int tries = 0; tries < 64; ++tries) {
+                  const int q = QS_LD(QS_Q2);
+                  const int want = min(n_idle, (int)((unsigned)q >> 16) - (q & 0xffff));
+                  if (want <= 0) break;
+                  if (atomicCAS(&ctl[QS_Q2], q, q + want) == q) { h = q & 0xffff; got = want; break; }
+               }
+            h = __builtin_amdgcn_readfirstlane(h); got = __builtin_amdgcn_readfirstlane(got);
+            if (job < 0) {
+               const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(idle >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)idle, 0u));
+               if (rank < got) {
+                  int e = -1;
+                  for (int spin = 0; spin < QS_SPIN_MAX; ++spin) { e = QS_LD(QS_E2 + ((h + rank) & 63)); if (e >= 0) break; __builtin_amdgcn_s_sleep(1); }
+                  if (e >= 0) {
+                     const int owner = ((e >> 9) & 3) * 64 + (e & 63), corner = (e >> 6) & 7;
+                     const f3 oP = F3(pk[0 * MDH_BLOCK + owner], pk[1 * MDH_BLOCK + owner], pk[2 * MDH_BLOCK + owner]);
+                     const f3 oN = F3(pk[3 * MDH_BLOCK + owner], pk[4 * MDH_BLOCK + owner], pk[5 * MDH_BLOCK + owner]);
+                     const f3 hvec = grid_to_world(pr, cage_probe(pr, world_to_grid(pr, oP), corner)) - oP;
+                     const float dist = length(hvec);
+                     d = hvec / dist;
+                     vmax = dist - MDH_MIN_STEP * 5.0f;
+                     o = oP + (oN * MDH_MIN_STEP) * 5.0f;
+                     total = __int_as_float(QS_LD(QS_T2 + ((h + rank) & 63)));
+                     job = e;
+                  }
+               }
+            }
+            QS_READ_COUNTERS();
+            continue;
+         } else if (n_active == 0) {
+            // nothing runs and, one step ago, nothing was left to draw: look now
+            QS_READ_COUNTERS();
+            int any = __builtin_amdgcn_readfirstlane((QS_OPEN(0) || QS_OPEN(1) || QS_OPEN(2) || QS_OPEN(3) || (c_q2 & 0xffff) < ((unsigned)c_q2 >> 16)) ? 1 : 0);
+#if QS_BISECT == 2
+            any = 0;
+#endif
+            if (any) continue;
+            // leave the march -- unless this is its last wavefront and a donor has appended meanwhile (donors append before they leave)
+            int was = 0;
+            if (leader) was = atomicSub(&ctl[QS_MARCHING], 1);
+            was = __builtin_amdgcn_readfirstlane(was);
+            if (was > 1) break;
+            const int q = __builtin_amdgcn_readfirstlane(QS_LD(QS_Q2));
+            if (!((q & 0xffff) < (int)((unsigned)q >> 16))) break;
+            if (leader) atomicAdd(&ctl[QS_MARCHING], 1);
+            QS_READ_COUNTERS();
+            continue;
+         }
+      }
+      if (!donated && own_left <= 0 && n_active <= QS_DONATE_MAX && __builtin_amdgcn_readfirstlane(c_marching) > 1) {
+         // hand the last rays to the wavefronts that still march
+         const unsigned long long act = __ballot(job >= 0);
+         int b2 = 0;
+         if (leader) b2 = atomicAdd(&ctl[QS_Q2], n_active << 16);
+         b2 = (int)((unsigned)__builtin_amdgcn_readfirstlane(b2) >> 16);
+         if (job >= 0) {
+            const int r2 = (b2 + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(act >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)act, 0u))) & 63;
+            if (!(job & QS_FOREIGN)) atomicAdd(&ctl[QS_PENDING + ((job >> 9) & 3)], 1);
+            QS_ST(QS_T2 + r2, __float_as_int(total));
+            QS_ST(QS_E2 + r2, job | QS_FOREIGN);
+            job = -1;
+         }
+         donated = true;
+         int was = 0;
+         if (leader) was = atomicSub(&ctl[QS_MARCHING], 1);
+         was = __builtin_amdgcn_readfirstlane(was);
+         if (was > 1) break;                           // somebody marches on: wait for the results below
+         if (leader) atomicAdd(&ctl[QS_MARCHING], 1);  // the others left meanwhile: take the rays back from list 2
+         QS_READ_COUNTERS();
+         continue;
+      }
+      QS_READ_COUNTERS(); // (for the next step: the reads complete behind the distance evaluation)
+      if (job >= 0) {
+         MDH_DIAG_STEP(3);
+         MDH_WORK(1);
+         const float sd = sdf<PART>(sc, o + d * total);
+         bool done = false;
+         if (sd < MDH_EPS) done = true; // blocked: the bit stays 0
+         else {
+            total += sd;
+            if (!(total < vmax)) { atomicOr(&words[((job >> 9) & 3) * 64 + (job & 63)], 1 << ((job >> 6) & 7)); done = true; }
+         }
+         if (done) {
+            if (job & QS_FOREIGN) atomicSub(&ctl[QS_PENDING + ((job >> 9) & 3)], 1); // (behind the result, in this wavefront's DS order)
+            job = -1;
+         }
+      }
+   }
+   // this wavefront's own jobs may still be in other hands
+   for (int spin = 0; spin < QS_SPIN_MAX; ++spin) {
+      if (__builtin_amdgcn_readfirstlane(QS_LD(QS_PENDING + wv)) <= 0) break;
+      __builtin_amdgcn_s_sleep(2);
+   }
+   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+   return bits | __hip_atomic_load((LdsInt)words + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#undef QS_OPEN
+#undef QS_READ_COUNTERS
+#undef QS_LD
+#undef QS_ST
+}
+
 // sample_radiance_with_specular (render_probes.glsl:71-136, M_COMPUTE_INDIRECT_SPECULAR == 1) from the reflection's hit
 // position on: the eight cage probes of the FIRST point (parked: slots 0-2, its material id in MDH_PARK_MAT) light
 // that position, each weighted by a soft shadow ray from it towards the probe (k = 0.5, raymarching.glsl:4-23 with
@@ -462,6 +713,9 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
    // (the reflection's colour and the primary hit's material id wait in LDS for the combine, like P, N and the light;
    //  the colour's rows are cleared behind the first point's corner loop, which uses them meanwhile)
    bool shaded = false; // the primary ray hit and the full shading ran
+#if MDH_QVIS_SHARED
+   f3 irr_keep = F3(0.0f, 0.0f, 0.0f);
+#endif
    // the ray that finds the next point to shade
    f3 ro = from, rd = dir_in;
    bool active = lane_valid;
@@ -584,7 +838,13 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
                   int vis_bits = 0; // bit i: visibility of corner i
                   PH_ADD(pt, 2);
                   if (QVIS && ctx == 0) {
+#if MDH_QVIS_SHARED && QS_BISECT == 1
                      vis_bits = queued_visibility<PART>(sc, pr, pk, P, N, gp, folded, sd0);
+#elif MDH_QVIS_SHARED
+                     vis_bits = queued_visibility_shared<PART>(sc, pr, pk, P, N, gp, folded, sd0);
+#else
+                     vis_bits = queued_visibility<PART>(sc, pr, pk, P, N, gp, folded, sd0);
+#endif
 #if MDH_QVIS_REDERIVE
                      // Nothing of the point stays in registers across the queue (it is the pass's longest loop, and the
                      // kernel is built for seven wavefronts per SIMD: what stayed live -- P, N, the cage cell, twenty dwords
@@ -744,6 +1004,10 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
                      // render_probes.glsl:65-66 (0/0 fixed as 0)
                      f3 irr = F3(0.0f, 0.0f, 0.0f);
                      if (accw != 0.0f) { irr = acc / accw; irr = irr * irr; }
+#if MDH_QVIS_SHARED
+                     if (QVIS && !REFLECT) irr_keep = irr; // (rows 12-15 are the workgroup's job list until the kernel ends)
+                     else
+#endif
                      park_store3<12>(pk, wb, irr);
                      if (REFLECT) park_store3<MDH_PARK_SPEC>(pk, wb, F3(0.0f, 0.0f, 0.0f));
                      shaded = true;
@@ -790,7 +1054,11 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
          (void)shaded;
          f3 direct = park_load3<9>(pk, wb);
          if (MODE == 0) {
+#if MDH_QVIS_SHARED
+            const f3 irr = (QVIS && !REFLECT) ? irr_keep : park_load3<12>(pk, wb);
+#else
             const f3 irr = park_load3<12>(pk, wb);
+#endif
             const f3 specular_col = REFLECT ? park_load3<MDH_PARK_SPEC>(pk, wb) : F3(0.0f, 0.0f, 0.0f);
             Material m = get_material(sc, __float_as_int(park_load1<PARK_MAT>(pk, wb)));
             const f3 specular_dir = reflect(dir, normal);
