@@ -1113,15 +1113,87 @@ static size_t lds_bytes_screen(const mdh_renderer *r) { return lds_bytes(r) + (s
 // the kernels of this library are compiled again around it with hiprtc -- the analogue of the
 // reference's runtime glCompileShader of its generated GLSL.  Modules are cached per process by their
 // generated source.
-static void jit_emit_program(std::string &out, const char *name, const std::vector<int32_t> &code)
+// A Distance program whose result is  sqrt (A) - R,  sqrt (A) + S  or  sqrt (A)  itself (a sphere, a torus, a capsule, a rounded
+// anything: most distance functions end that way) can take part in the wave-level culling of the built-in spheres
+// (mdh_device.h: closest_primitive): inside  closest = min (closest, d)  the root is not taken when, in every lane of the
+// wavefront, A already proves d >= closest -- the same rule, the same margins, the same proof (rounding is monotone), and the
+// same operations on the same values whenever the root IS taken.  jit_min_form finds the two instructions: the root S whose
+// only reader is the final operation F, and F whose value (through moves) is the program's r0.
+struct JitMinForm { int pc_sqrt = -1, pc_final = -1, kind = 0; }; // kind: 1 = sqrt - r[b], 2 = sqrt + r[b], 3 = r[a] + sqrt, 4 = sqrt
+static int jit_op_reads(int op) // registers an instruction reads (SEL: three, see below)
 {
-   char buf[256];
+   switch (op) {
+   case MDH_X_LIT: case MDH_X_COMP: case MDH_X_POINT: return 0;
+   case MDH_X_MOV: case MDH_X_NEG: case MDH_X_ABS: case MDH_X_FLOOR: case MDH_X_SIGN: case MDH_X_SQRT: case MDH_X_ITOF:
+   case MDH_X_ACOS: case MDH_X_SIN: case MDH_X_COS: case MDH_X_TAN: case MDH_X_ASIN: case MDH_X_ATAN: return 1;
+   case MDH_X_SEL: return 3;
+   default: return 2;
+   }
+}
+static JitMinForm jit_min_form(const std::vector<int32_t> &code)
+{
+   JitMinForm none, f;
+   struct Val { int pc, op, a, b; int readers; };
+   std::vector<Val> vals; // value 0: "never written" (registers start as 0.0f)
+   vals.push_back({-1, -1, 0, 0, 0});
+   int id[MDH_X_REGS];
+   for (int i = 0; i < MDH_X_REGS; ++i) id[i] = 0;
+   for (size_t pc = 0; pc < code.size(); ++pc) {
+      const uint32_t w = (uint32_t)code[pc];
+      const int op = w & 255, d = (w >> 8) & 63, a = (w >> 16) & 255, b = (w >> 24) & 63, ra = a & 63;
+      const int reads = jit_op_reads(op);
+      int c = 0;
+      if (op == MDH_X_LIT) ++pc;
+      if (op == MDH_X_SEL) c = code[++pc] & 63;
+      if (op == MDH_X_MOV) { id[d] = id[ra]; continue; } // (a move hands the value on)
+      if (reads >= 1) ++vals[id[ra]].readers;
+      if (reads >= 2) ++vals[id[b]].readers;
+      if (reads >= 3) ++vals[id[c]].readers;
+      vals.push_back({(int)pc - (op == MDH_X_LIT || op == MDH_X_SEL ? 1 : 0), op, reads >= 1 ? id[ra] : 0, reads >= 2 ? id[b] : 0, 0});
+      id[d] = (int)vals.size() - 1;
+   }
+   const Val &F = vals[id[0]];
+   if (F.pc < 0) return none;
+   auto is_root = [&](int v) { return v > 0 && vals[v].op == MDH_X_SQRT && vals[v].readers == 1; };
+   if (F.op == MDH_X_SQRT && F.readers == 0) { f.pc_sqrt = f.pc_final = F.pc; f.kind = 4; return f; }
+   if (F.op == MDH_X_SUB && is_root(F.a) && F.b != F.a) { f.pc_sqrt = vals[F.a].pc; f.pc_final = F.pc; f.kind = 1; return f; }
+   if (F.op == MDH_X_ADD && is_root(F.a) && F.b != F.a) { f.pc_sqrt = vals[F.a].pc; f.pc_final = F.pc; f.kind = 2; return f; }
+   if (F.op == MDH_X_ADD && is_root(F.b) && F.b != F.a) { f.pc_sqrt = vals[F.b].pc; f.pc_final = F.pc; f.kind = 3; return f; }
+   return none;
+}
+// min_form: emit  float NAME (int ent, f3 x, float closest)  =  min (closest, the program's distance)  with the root culled
+static void jit_emit_program(std::string &out, const char *name, const std::vector<int32_t> &code, const JitMinForm *min_form = nullptr)
+{
+   char buf[512];
    bool used[MDH_X_REGS] = {false};
    std::string body;
    static const char *ARG[10] = {"x.x", "x.y", "x.z", "nrm.x", "nrm.y", "nrm.z", "dir.x", "dir.y", "dir.z", "dist"};
    for (size_t pc = 0; pc < code.size(); ++pc) {
       const uint32_t w = (uint32_t)code[pc];
       const int op = w & 255, d = (w >> 8) & 63, a = (w >> 16) & 255, b = (w >> 24) & 63, ra = a & 63;
+      if (min_form && (int)pc == min_form->pc_final) { // the final operation: cull, or take the root and finish as the program does
+         used[ra] = used[b] = true;
+         char rr[32], fin[64];
+         switch (min_form->kind) {
+         case 1: snprintf(rr, sizeof rr, "r%d", b); snprintf(fin, sizeof fin, "sqrt_(d2_) - r%d", b); break;
+         case 2: snprintf(rr, sizeof rr, "-r%d", b); snprintf(fin, sizeof fin, "sqrt_(d2_) + r%d", b); break;
+         case 3: snprintf(rr, sizeof rr, "-r%d", ra); snprintf(fin, sizeof fin, "r%d + sqrt_(d2_)", ra); break;
+         default: snprintf(rr, sizeof rr, "0.0f"); snprintf(fin, sizeof fin, "sqrt_(d2_)"); break;
+         }
+         if (min_form->kind == 4) { snprintf(buf, sizeof buf, "   const float d2_ = r%d;\n", ra); body += buf; }
+         snprintf(buf, sizeof buf,
+                  "   const float tsum_ = closest + (%s);\n"
+                  "   const bool need_ = !(tsum_ < 0.0f) && !(d2_ > (tsum_ * tsum_) * 1.000001f);\n"
+                  "   if (__ballot(need_) != 0ull) closest = min_raw(closest, %s);\n"
+                  "   return closest;\n", rr, fin);
+         body += buf;
+         break;
+      }
+      if (min_form && (int)pc == min_form->pc_sqrt) { // the root waits (its register is read by the final operation only)
+         used[ra] = true;
+         snprintf(buf, sizeof buf, "   const float d2_ = r%d;\n", ra); body += buf;
+         continue;
+      }
       used[d] = true;
       const char *fmt = nullptr;
       switch (op) {
@@ -1166,22 +1238,39 @@ static void jit_emit_program(std::string &out, const char *name, const std::vect
       body += buf;
    }
    used[0] = used[1] = used[2] = true;
-   out += "template <bool ADA_DIV> MDH_DEV f3 ";
-   out += name;
-   out += "(int ent, f3 x, f3 nrm, f3 dir, float dist)\n{\n   float";
+   if (min_form) {
+      out += "MDH_DEV float ";
+      out += name;
+      out += "(int ent, f3 x, float closest)\n{\n   constexpr bool ADA_DIV = false;\n   float";
+   } else {
+      out += "template <bool ADA_DIV> MDH_DEV f3 ";
+      out += name;
+      out += "(int ent, f3 x, f3 nrm, f3 dir, float dist)\n{\n   float";
+   }
    bool first = true;
    for (int i = 0; i < MDH_X_REGS; ++i)
       if (used[i]) { snprintf(buf, sizeof buf, "%s r%d = 0.0f", first ? "" : ",", i); out += buf; first = false; }
-   out += ";\n" + body + "   return F3(r0, r1, r2);\n}\n";
+   out += ";\n" + body + (min_form ? "}\n" : "   return F3(r0, r1, r2);\n}\n");
 }
 // mdh_jit_kinds.h of a scene: the programs as functions and the two dispatchers mdh_device.h calls
 static std::string jit_kinds_header(const mdh_renderer *r)
 {
-   std::string s = "// generated by libmadarch_hip (mdh_api.hip: jit_kinds_header)\n", prim_cases, light_cases;
-   char name[64], buf[256];
+   std::string s = "// generated by libmadarch_hip (mdh_api.hip: jit_kinds_header)\n", prim_cases, light_cases, closest_all;
+   char name[64], buf[512];
    for (int k = 0; k < r->npk; ++k) {
       if (r->pk[k].type != PK_CUSTOM) continue;
       const std::vector<int32_t> *progs[3] = {&r->pk[k].x_dist, &r->pk[k].x_nrm, &r->pk[k].x_mat};
+      { // closest_primitive's loop over this kind's instances, the kind a constant; Distance in its min form where it has one
+         const JitMinForm mf = jit_min_form(r->pk[k].x_dist);
+         snprintf(name, sizeof name, "jit_p%d_min", k);
+         if (mf.kind) jit_emit_program(s, name, r->pk[k].x_dist, &mf);
+         snprintf(buf, sizeof buf,
+                  "   {\n      const int n = hdr(H_KCOUNT + %d), stride = hdr(H_KSTRIDE + %d) * 4;\n      int ent = hdr(H_KSLOT + %d) * 4;\n"
+                  "#pragma unroll 1\n      for (int i = 0; i < n; ++i, ent += stride) closest = %s;\n   }\n", k, k, k,
+                  mf.kind ? (std::string(name) + "(ent, x, closest)").c_str()
+                          : ("min_raw(closest, jit_p" + std::to_string(k) + "_0<false>(ent, x, F3(0.0f, 0.0f, 0.0f), F3(0.0f, 0.0f, 0.0f), 0.0f).x)").c_str());
+         closest_all += buf;
+      }
       for (int q = 0; q < 3; ++q) {
          snprintf(name, sizeof name, "jit_p%d_%d", k, q);
          jit_emit_program(s, name, *progs[q]);
@@ -1199,6 +1288,8 @@ static std::string jit_kinds_header(const mdh_renderer *r)
          light_cases += buf;
       }
    }
+   s += "// closest_primitive over every instance of every user-defined kind (scenes.adb:602-629)\n"
+        "#define MDH_JIT_CLOSEST_ALL 1\nMDH_DEV float jit_closest_all(f3 x, float closest)\n{\n" + closest_all + "   return closest;\n}\n";
    s += "// which: 0 Distance, 1 Normal, 2 Material; k: the kind (wave-uniform)\n"
         "template <bool ADA_DIV> MDH_DEV f3 jit_prim(int which, int k, int ent, f3 x)\n{\n   switch (which * 8 + k) {\n" + prim_cases +
         "   default: break;\n   }\n   return F3(0.0f, 0.0f, 0.0f);\n}\n"
@@ -1256,7 +1347,11 @@ static JitModule *jit_module(mdh_renderer *r, const std::vector<std::string> &ex
 {
    const HiprtcApi &rtc = hiprtc_api();
    if (!rtc.ok) { seterr(MDH_E_DEVICE, "libhiprtc.so cannot be loaded: user-defined kinds are interpreted"); return nullptr; }
-   if (r->jit_kinds.empty()) r->jit_kinds = jit_kinds_header(r);
+   if (r->jit_kinds.empty()) {
+      r->jit_kinds = jit_kinds_header(r);
+      if (const char *dump = getenv("MADARCH_HIP_JIT_DUMP")) // (diagnostic: the generated mdh_jit_kinds.h of the scene)
+         if (FILE *f = fopen(dump, "w")) { fputs(r->jit_kinds.c_str(), f); fclose(f); }
+   }
    std::string key = "device " + std::to_string(r->device) + "\n" + r->jit_kinds; // (a module and its functions belong to the device they were loaded on)
    for (auto &e : exprs) key += "|" + e;
    std::lock_guard<std::mutex> lock(g_jit_mutex);

@@ -746,6 +746,10 @@ template <bool CUSTOM> MDH_DEV float closest_primitive(const KScene &sc, f3 x, c
       for (int i = 0; i < n; ++i)
          closest = min_raw(closest, sd_triangle<false>(xyz(s_tab[s0 + 3 * i]), xyz(s_tab[s0 + 3 * i + 1]), xyz(s_tab[s0 + 3 * i + 2]), x));
    }
+#ifdef MDH_JIT_CLOSEST_ALL
+   if (CUSTOM) closest = jit_closest_all(x, closest); // (compiled: one loop per kind, roots culled like the built-in spheres')
+   else
+#endif
    if (CUSTOM) { // user-defined kinds: their Distance programs, interpreted
       const int nk = hdr(H_NK);
 #pragma unroll 1

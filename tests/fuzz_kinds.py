@@ -80,9 +80,22 @@ class Gen:
         return (v() + LV((0.1, 0.2, 0.3))).Normalize()
 
 
+ROOTED_SEEDS = 100000
+
+
 def make_kind(seed):
     def distance(S, P):
         g = Gen(np.random.default_rng(seed), S, P)
+        if seed >= ROOTED_SEEDS:
+            # distances that END in a square root (seeds of their own, so that the earlier ones keep their scenes): the forms the
+            # hiprtc build compiles with the root culled at wave level (mdh_api.hip: jit_min_form) -- root - R, root + S, S + root, root
+            v = (P - S.Get(C_V1)) + g.v(3).Max(LV((-0.3, -0.3, -0.3))).Min(LV((0.3, 0.3, 0.3))) * LF(0.5)
+            t = g.f(3).Clamp(LF(-0.4), LF(0.4)) * LF(0.5)
+            form = seed % 4
+            if form == 0: return v.Length() - (LF(0.8) + t)
+            if form == 1: return v.Length() + (t - LF(0.9))
+            if form == 2: return (t - LF(0.9)) + v.Length()
+            return (v.Dot(v) * LF(0.25) + t * t).Sqrt()
         # a sphere shell keeps the field a sane distance bound far away; the random term deforms it nearby
         return ((P - S.Get(C_V1)).Length() - LF(1.0)) + g.f(4).Clamp(LF(-0.4), LF(0.4)) * LF(0.5)
 

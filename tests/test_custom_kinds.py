@@ -195,6 +195,28 @@ def test_hip_jit_equals_the_interpreter(hip):
 
 
 @pytest.mark.gpu
+def test_compiled_distance_programs_join_the_wave_level_culling(hip, tmp_path, monkeypatch):
+    """A Distance program that ends in  sqrt (A) - R,  sqrt (A) + S  or  sqrt (A)  is compiled in a min form whose root is
+    culled like the built-in spheres' (mdh_api.hip: jit_min_form): the generated header shows which kinds have one, and the
+    frames are the interpreter's bit for bit (no culling there)."""
+    dump = tmp_path / "mdh_jit_kinds.h"
+    monkeypatch.setenv("MADARCH_HIP_JIT_DUMP", str(dump))
+    outs = []
+    for jit in (1, 0):
+        R = room(hip, True, W=96, H=64, extra=EXTRA)
+        R.Set_Option(B.OPT_JIT, jit)
+        outs.append(snapshot(R, 2))
+        assert R.Get_Option(B.OPT_JIT) == jit
+    assert_same(*outs)
+    text = dump.read_text()
+    has_min = {k for k in range(8) if "float jit_p%d_min(" % k in text}
+    # kinds in table order: My_Sphere, My_Plane, My_Box, My_Triangle, Torus, Ripple, Capsule
+    assert {0, 4, 6} <= has_min, has_min  # sqrt (dot (v, v)) - radius
+    assert 1 not in has_min and 5 not in has_min  # a plane has no root; the ripple's distance does not end in one
+    assert "jit_closest_all" in text
+
+
+@pytest.mark.gpu
 def test_hip_rejects_invalid_programs(hip):
     k = type(ck.My_Sphere)("Broken", ck.My_Sphere.comps, ck.My_Sphere.distance, ck.My_Sphere.normal, ck.My_Sphere.material)
     d, n, m = ck.My_Sphere.programs()
