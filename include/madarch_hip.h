@@ -247,7 +247,16 @@ enum {
     * 1 = the labelled experiment build (`make -C madarch_amd/csrc fast`: hardware sqrt / rcp / log / exp, fused
     * multiply-adds, the irradiance fold in four partial sums), which holds BASELINE.json's 1e-4 tolerance at best.
     * Setting it to anything but the build's own value is refused. */
-   MDH_OPT_NUMERICS = 16
+   MDH_OPT_NUMERICS = 16,
+   /* 1 = a mip chain for the radiance atlas (default 0 = the reference's behaviour).  The reference asks
+      textureLod for level 1 (mode 2, render_probes.glsl:197) and for mix (0, radiance_lods, 2 roughness)
+      (mode 1, render_probes.glsl:84-86,131; probe_utils.glsl:17) of an atlas it allocates with ONE level
+      (render_passes.adb:113): every tap reads level 0.  With the switch on, each screen pass first builds
+      levels 1 .. radiance_lods of the radiance atlas it reads (2x2 box filter of the level below,
+      ((a + b) + (c + d)) / 4 per channel in fp32, stored in the atlas's format) and the two taps read
+      them as GL_LINEAR_MIPMAP_LINEAR would.  Needs a power-of-two radiance resolution
+      (MDH_E_INVALID otherwise).  Levels can be read back: mdh_read_texture (MDH_TEX_RADIANCE_MIP0 + l). */
+   MDH_OPT_RADIANCE_MIPS = 17
 };
 
 /* passes of Renderers.Render (madarch-renderers.adb:302-321) */
@@ -264,6 +273,7 @@ enum {
 
 /* atlases / textures of the renderer (texture units 0-3, renderers.adb:239-279) */
 enum { MDH_TEX_RADIANCE = 0, MDH_TEX_IRRADIANCE = 1, MDH_TEX_VISIBILITY = 2, MDH_TEX_SCATTERING = 3 };
+#define MDH_TEX_RADIANCE_MIP0 16 /* mdh_read_texture only: + l = level l >= 1 of the radiance atlas (MDH_OPT_RADIANCE_MIPS) */
 
 /* Renderers.Create (madarch-renderers.adb:91-300) together with Scenes.Compile
  * (madarch-scenes.adb:1378-1421).  `width`/`height` replace the window size

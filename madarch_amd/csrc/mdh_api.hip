@@ -239,6 +239,8 @@ struct mdh_renderer {
    //  rate of pipelined frames; with three they wait for the screen pass of frame N - 2, long gone)
    static const int NSETS = MDH_ATLAS_SETS;
    void *d_rad2[NSETS] = {nullptr}, *d_irr2[NSETS] = {nullptr};
+   void *d_rad_mips[NSETS] = {nullptr}; // MDH_OPT_RADIANCE_MIPS: levels 1 .. radiance_lods of each set's radiance atlas, one behind the other
+   int opt_mips = 0;
    int n_cus = 0;                          // compute units of the device
    // RadOrder (mdh_kernels.h): every ray's primary-march steps, the rays sorted by them, the sort's histograms
    unsigned char *d_rad_steps = nullptr;
@@ -722,6 +724,7 @@ static KProbes make_probes(const mdh_renderer *r)
    p.m_rres = small && p.rres > 1 ? magic(p.rres) : 0u;
    p.m_ires = small && p.ires > 1 ? magic(p.ires) : 0u;
    p.m_pcx = small && p.pcx > 1 ? magic(p.pcx) : 0u;
+   p.rad_mips = nullptr; // (the screen pass sets it: run_pass)
    return p;
 }
 static KCamera make_camera(const mdh_renderer *r)
@@ -758,6 +761,36 @@ static int alloc_atlases(mdh_renderer *r)
    return MDH_OK;
 }
 
+// MDH_OPT_RADIANCE_MIPS: texels of levels 1 .. radiance_lods together (a third of level 0 at most)
+static size_t rad_mips_texels(const mdh_renderer *r)
+{
+   size_t n = 0;
+   for (int res = r->probes.radiance_resolution >> 1; res >= 1; res >>= 1) n += (size_t)probe_total(r) * res * res;
+   return n;
+}
+static int alloc_rad_mips(mdh_renderer *r)
+{
+   for (int s = 0; s < mdh_renderer::NSETS; ++s) {
+      if (r->d_rad_mips[s]) { void *q = r->d_rad_mips[s]; r->d_rad_mips[s] = nullptr; HIP_TRY(hipFree(q)); }
+      if (r->opt_mips && rad_mips_texels(r) > 0) HIP_TRY(hipMalloc(&r->d_rad_mips[s], rad_mips_texels(r) * texel_bytes(r)));
+   }
+   return MDH_OK;
+}
+// the levels of set `set`'s radiance atlas on stream st (before the screen pass that reads them)
+static int build_rad_mips(mdh_renderer *r, int set, hipStream_t st)
+{
+   const char *src = (const char *)r->d_rad2[set];
+   char *dst = (char *)r->d_rad_mips[set];
+   for (int res = r->probes.radiance_resolution >> 1; res >= 1; res >>= 1) {
+      const long n = (long)probe_total(r) * res * res;
+      hipLaunchKernelGGL(k_radiance_mips, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const void *)src, (void *)dst, r->opt_atlas, res, (int)n);
+      src = dst;
+      dst += (size_t)n * texel_bytes(r);
+   }
+   HIP_TRY(hipGetLastError());
+   return MDH_OK;
+}
+
 static int rccl_api_destroy(ncclComm_t c); // (mdh_comm_* below)
 extern "C" int32_t mdh_destroy(mdh_renderer *r)
 {
@@ -774,7 +807,7 @@ extern "C" int32_t mdh_destroy(mdh_renderer *r)
    for (void *p : ptrs)
       if (p) (void)hipFree(p);
    for (int q = 0; q < mdh_renderer::NSETS; ++q)
-      for (void *p : {(void *)r->d_rad2[q], (void *)r->d_irr2[q], (void *)r->d_vis2[q], (void *)r->d_scat2[q]})
+      for (void *p : {(void *)r->d_rad2[q], (void *)r->d_irr2[q], (void *)r->d_vis2[q], (void *)r->d_scat2[q], (void *)r->d_rad_mips[q]})
          if (p) (void)hipFree(p);
    for (auto &p : r->pending) { (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1); }
    for (auto e : r->free_events) (void)hipEventDestroy(e);
@@ -958,6 +991,7 @@ extern "C" int32_t mdh_set_option(mdh_renderer *r, int32_t option, int32_t value
          r->opt_atlas = value;
          int rc = alloc_atlases(r);
          if (rc != MDH_OK) return rc;
+         if ((rc = alloc_rad_mips(r)) != MDH_OK) return rc;
       }
       break;
    case MDH_OPT_SCREEN_MODE: if (value < 0 || value > 2) return seterr(MDH_E_INVALID, "screen mode is 0, 1 or 2"); r->opt_mode = value; break;
@@ -983,6 +1017,18 @@ extern "C" int32_t mdh_set_option(mdh_renderer *r, int32_t option, int32_t value
    case MDH_OPT_RADIANCE_ORDER: r->opt_rad_order = value ? 1 : 0; r->rad_order_rays = 0; break;
    case MDH_OPT_SCREEN_ORDER: r->opt_scr_order = value ? 1 : 0; r->scr_order_cur = -1; break;
    case MDH_OPT_NUMERICS: if (value != MDH_FAST_NUMERICS) return seterr(MDH_E_STATE, "the numerics are a property of the library build (make fast builds the experiment)"); break;
+   case MDH_OPT_RADIANCE_MIPS: {
+      const int res = r->probes.radiance_resolution;
+      if (value && (res & (res - 1)) != 0) return seterr(MDH_E_INVALID, "radiance mips need a power-of-two radiance resolution");
+      if ((value != 0) != (r->opt_mips != 0)) {
+         HIP_TRY(hipSetDevice(r->device));
+         { int dr = drain_streams(r); if (dr != MDH_OK) return dr; }
+         r->opt_mips = value ? 1 : 0;
+         int rc = alloc_rad_mips(r);
+         if (rc != MDH_OK) return rc;
+      }
+      break;
+   }
    default: return seterr(MDH_E_INVALID, "unknown option");
    }
    return MDH_OK;
@@ -1008,6 +1054,7 @@ extern "C" int32_t mdh_get_option(mdh_renderer *r, int32_t option, int32_t *valu
    case MDH_OPT_RADIANCE_ORDER: *value = r->opt_rad_order; break;
    case MDH_OPT_SCREEN_ORDER: *value = r->opt_scr_order; break;
    case MDH_OPT_NUMERICS: *value = MDH_FAST_NUMERICS; break;
+   case MDH_OPT_RADIANCE_MIPS: *value = r->opt_mips; break;
    default: return seterr(MDH_E_INVALID, "unknown option");
    }
    return MDH_OK;
@@ -1507,7 +1554,7 @@ template <int PART, int MODE> static void launch_screen_g(mdh_renderer *r, hipSt
 template <int PART> static void launch_screen_m(mdh_renderer *r, hipStream_t st, const KProbes &pr, const KVolumetrics &vol, const KCamera &cam, const ScreenArgs &a, int blocks, bool pow2)
 {
    if (r->opt_mode == 0) {
-      if (a.spec_mode == 1 || a.spec_mode == 3) { // the other two bodies of render_probes.glsl:264-272: a variant of their own
+      if (a.spec_mode == 1 || a.spec_mode == 3 || (a.spec_mode == 2 && pr.rad_mips)) { // the other two bodies of render_probes.glsl:264-272 (and mode 2 over a mip chain): a variant of their own
          if (r->opt_gbuffer) hipLaunchKernelGGL((k_screen<PART, 0, true, true>), dim3(blocks), dim3(MDH_BLOCK), lds_bytes_screen(r), st, r->ks, pr, vol, cam, a);
          else hipLaunchKernelGGL((k_screen<PART, 0, false, true>), dim3(blocks), dim3(MDH_BLOCK), lds_bytes_screen(r), st, r->ks, pr, vol, cam, a);
       }
@@ -1594,7 +1641,7 @@ static int run_pass(mdh_renderer *r, int pass, hipStream_t st, int src, int dst,
       case MDH_PASS_VISIBILITY: snprintf(kname, sizeof kname, "k_visibility<%d>", pf); break;
       case MDH_PASS_SCATTERING: snprintf(kname, sizeof kname, "k_scattering<%d>", pf); break;
       case MDH_PASS_SCREEN: {
-         const bool alt = r->opt_mode == 0 && (r->opt_spec == 1 || r->opt_spec == 3);
+         const bool alt = r->opt_mode == 0 && (r->opt_spec == 1 || r->opt_spec == 3 || (r->opt_spec == 2 && r->opt_mips));
          snprintf(kname, sizeof kname, "k_screen<%d, %d, %s, %s>", pf | (pow2 && r->opt_mode == 0 && !alt ? MDH_PF_POW2 : 0), r->opt_mode, r->opt_gbuffer ? "true" : "false", alt ? "true" : "false");
          break;
       }
@@ -1752,6 +1799,11 @@ static int run_pass(mdh_renderer *r, int pass, hipStream_t st, int src, int dst,
       a.rank = r->opt_rank; a.world = r->opt_world;
       a.ao_steps = r->opt_ao;
       a.spec_mode = r->opt_spec;
+      if (r->opt_mips && r->opt_mode == 0 && r->opt_spec != 0 && r->d_rad_mips[dst]) { // MDH_OPT_RADIANCE_MIPS: the levels of the atlas this pass reads
+         int mrc = build_rad_mips(r, dst, st);
+         if (mrc != MDH_OK) return mrc;
+         pr.rad_mips = r->d_rad_mips[dst];
+      }
       a.fb = r->d_fb2[fbix]; a.gb_index = (int *)r->d_gb2[fbix][0]; a.gb_t = (float *)r->d_gb2[fbix][1]; a.gb_steps = (int *)r->d_gb2[fbix][2];
       a.window = nullptr;
       if (r->opt_window == 1 || (r->opt_window == 2 && r->swaps > 0)) { // the window's pixels straight into pinned host memory (mdh_swap_buffers)
@@ -2410,6 +2462,43 @@ static int atlas_from_host(mdh_renderer *r, int tex, size_t first, size_t n, con
 
 extern "C" int32_t mdh_read_texture(mdh_renderer *r, int32_t tex, float *out, int32_t *w, int32_t *h, int32_t *c)
 {
+   if (r && tex > MDH_TEX_RADIANCE_MIP0 && tex <= MDH_TEX_RADIANCE_MIP0 + 15) { // level l of the radiance atlas, built now from the current atlas
+      const int l = tex - MDH_TEX_RADIANCE_MIP0, res = r->probes.radiance_resolution >> l, pcx = r->probes.probe_count[0];
+      if (!r->opt_mips || res < 1) return seterr(MDH_E_INVALID, "no such level (MDH_OPT_RADIANCE_MIPS)");
+      HIP_TRY(hipSetDevice(r->device));
+      { int jr = join_main(r); if (jr != MDH_OK) return jr; }
+      const int set = atlas_set(r), W = res * pcx, H = res * r->probes.probe_count[1];
+      if (out) {
+         int rc = build_rad_mips(r, set, r->stream);
+         if (rc != MDH_OK) return rc;
+         size_t off = 0;
+         for (int k = 1; k < l; ++k) off += (size_t)probe_total(r) * (r->probes.radiance_resolution >> k) * (r->probes.radiance_resolution >> k);
+         const size_t n = (size_t)probe_total(r) * res * res;
+         std::vector<float> rgb(n * 3);
+         const char *src = (const char *)r->d_rad_mips[set] + off * texel_bytes(r);
+         if (r->opt_atlas == 0) {
+            std::vector<uchar4> tmp(n);
+            HIP_TRY(hipMemcpyAsync(tmp.data(), src, n * 4, hipMemcpyDeviceToHost, r->stream));
+            HIP_TRY(hipStreamSynchronize(r->stream));
+            for (size_t i = 0; i < n; ++i) { rgb[3 * i] = (float)tmp[i].x / 255.0f; rgb[3 * i + 1] = (float)tmp[i].y / 255.0f; rgb[3 * i + 2] = (float)tmp[i].z / 255.0f; }
+         } else {
+            std::vector<float4> tmp(n);
+            HIP_TRY(hipMemcpyAsync(tmp.data(), src, n * 16, hipMemcpyDeviceToHost, r->stream));
+            HIP_TRY(hipStreamSynchronize(r->stream));
+            for (size_t i = 0; i < n; ++i) { rgb[3 * i] = tmp[i].x; rgb[3 * i + 1] = tmp[i].y; rgb[3 * i + 2] = tmp[i].z; }
+         }
+         for (int Y = 0; Y < H; ++Y)
+            for (int X = 0; X < W; ++X) {
+               const int tx = X / res, ty = Y / res;
+               const size_t idx = ((size_t)(ty * pcx + tx) * res + (Y - ty * res)) * res + (X - tx * res);
+               memcpy(out + ((size_t)Y * W + X) * 3, &rgb[idx * 3], 12);
+            }
+      }
+      if (w) *w = W;
+      if (h) *h = H;
+      if (c) *c = 3;
+      return MDH_OK;
+   }
    if (!r || tex < 0 || tex > 3) return seterr(MDH_E_INVALID, "bad argument");
    HIP_TRY(hipSetDevice(r->device));
    { int jr = join_main(r); if (jr != MDH_OK) return jr; }

@@ -121,6 +121,7 @@ struct KProbes {
    float fpcx, fpcy;     // (float)pcx, (float)pcy
    int rad_lods;         // radiance_lods = int(log2(radiance_resolution)) (probe_utils.glsl:17): the highest set bit
    unsigned m_rres, m_ires, m_pcx; // div_magic's numbers for rres, ires and pcx (0: the atlas is too large for them)
+   void *rad_mips;       // MDH_OPT_RADIANCE_MIPS: levels 1 .. rad_lods of `rad`, one behind the other (null: level 0 only)
 };
 
 struct KCamera {
@@ -1351,6 +1352,30 @@ MDH_DEV f3 atlas_sample(const void *base, int fmt, int pcx, int pcy, int res, in
    f3 a = atlas_texel<P2>(base, fmt, r0 + c0, u8_tab), b = atlas_texel<P2>(base, fmt, r0 + c1, u8_tab);
    f3 c = atlas_texel<P2>(base, fmt, r1 + c0, u8_tab), d = atlas_texel<P2>(base, fmt, r1 + c1, u8_tab);
    return ((a * w00 + b * w10) + c * w01) + d * w11;
+}
+
+// MDH_OPT_RADIANCE_MIPS: textureLod (radiance_data, coord, lod) as GL_LINEAR_MIPMAP_LINEAR reads a mip chain -- lod clamped to
+// the chain, the two nearest levels sampled bilinearly and mixed by the fraction (the upper one only when the fraction is
+// not 0).  Level l >= 1 has the atlas's probe-major layout with tiles of res >> l texels; the levels follow one another
+// in pq.rad_mips (k_radiance_mips).  Only the screen kernel's variant for the optional paths calls this.
+MDH_DEV f3 radiance_level_sample(const KProbes &pq, int l, float cx, float cy, int u8_tab)
+{
+   if (l == 0) return atlas_sample<false>(pq.rad, pq.fmt, pq.pcx, pq.pcy, pq.rres, pq.rshift, pq.rad_w, pq.rad_h, cx, cy, u8_tab, pq.m_rres);
+   unsigned off = 0; // texels of levels 1 .. l - 1
+   for (int k = 1; k < l; ++k) { const int rk = pq.rres >> k; off += (unsigned)(pq.pcx * pq.pcy) * (unsigned)(rk * rk); }
+   const int res = pq.rres >> l;
+   const char *base = (const char *)pq.rad_mips + (size_t)off * (pq.fmt == 0 ? 4u : 16u);
+   return atlas_sample<false>(base, pq.fmt, pq.pcx, pq.pcy, res, pq.rshift - l, (float)(pq.pcx * res), (float)(pq.pcy * res), cx, cy, u8_tab, 0u);
+}
+MDH_DEV f3 radiance_lod_sample(const KProbes &pq, float lod, float cx, float cy, int u8_tab)
+{
+   const float d = clamp_(lod, 0.0f, (float)pq.rad_lods);
+   const int l0 = (int)d;
+   const float f = d - (float)l0;
+   const f3 lo = radiance_level_sample(pq, l0, cx, cy, u8_tab);
+   if (!(f > 0.0f)) return lo;
+   const f3 hi = radiance_level_sample(pq, l0 + 1, cx, cy, u8_tab);
+   return lo * (1.0f - f) + hi * f; // mix ()
 }
 
 // The same tap in two halves, so that the four texel loads of an RGBA8 atlas can be issued long

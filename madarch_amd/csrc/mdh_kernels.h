@@ -359,6 +359,22 @@ template <int PART, bool SMALL = false> __global__ __launch_bounds__(MDH_BLOCK, 
    PH_KERNEL_END();
 }
 
+// MDH_OPT_RADIANCE_MIPS: one level of the radiance atlas's mip chain from the level below -- the 2x2 box filter over the
+// atlas image, ((a + b) + (c + d)) * 0.25 per channel in fp32 on the texels as stored, stored in the atlas's format.  Both
+// levels are probe-major ([probe][y][x]); the resolution is a power of two, so no box crosses a probe's tile.
+// thread = texel of the destination level (n = probes * res * res), res = its tile resolution
+__global__ __launch_bounds__(256) void k_radiance_mips(const void *src, void *dst, int fmt, int res, int n)
+{
+   const int idx = blockIdx.x * 256 + threadIdx.x;
+   if (idx >= n) return;
+   const int per = res * res, p = idx / per, rem = idx - p * per, y = rem / res, x = rem - y * res;
+   const int rs = 2 * res;
+   const unsigned s0 = ((unsigned)(p * rs + 2 * y) * (unsigned)rs) + (unsigned)(2 * x), s1 = s0 + (unsigned)rs;
+   const f3 a = atlas_texel<false>(src, fmt, s0, -1), b = atlas_texel<false>(src, fmt, s0 + 1, -1);
+   const f3 c = atlas_texel<false>(src, fmt, s1, -1), d = atlas_texel<false>(src, fmt, s1 + 1, -1);
+   atlas_store(dst, fmt, (unsigned)idx, ((a + b) + (c + d)) * 0.25f);
+}
+
 // ---- Rays in the order of their primary-march lengths.  In lock step a wavefront pays the LONGEST primary march
 // among its 64 rays: 20 of 64 lanes are alive in an average step of that march, which is 60 % of the pass's SDF
 // evaluations.  A probe ray's march hardly changes from frame to frame (the probes do not move): every pass leaves each

@@ -655,7 +655,8 @@ MDH_DEV f3 radiance_with_specular(const KScene &sc, const KProbes &pr, const flo
       const f2 base = probe_id_to_coord(pr, grid_to_probe_id(pr, q));
       f2 rid = ray_dir_to_ray_id(pts);
       rid = F2(clamp_(rid.x, rmin, rmax), clamp_(rid.y, rmin, rmax));
-      const f3 tx = atlas_sample(pr.rad, pr.fmt, pr.pcx, pr.pcy, pr.rres, pr.rshift, pr.rad_w, pr.rad_h, base.x + div_pcx(pr, rid.x), base.y + div_pcy(pr, rid.y), u8_tab, pr.m_rres);
+      const f3 tx = pr.rad_mips ? radiance_lod_sample(pr, lod, base.x + div_pcx(pr, rid.x), base.y + div_pcy(pr, rid.y), u8_tab) // (MDH_OPT_RADIANCE_MIPS)
+                                : atlas_sample(pr.rad, pr.fmt, pr.pcx, pr.pcy, pr.rres, pr.rshift, pr.rad_w, pr.rad_h, base.x + div_pcx(pr, rid.x), base.y + div_pcy(pr, rid.y), u8_tab, pr.m_rres);
       radiance = radiance + tx * weight;
       total_weight += weight;
    }
@@ -1026,7 +1027,9 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
                      f2 base = probe_id_to_coord<P2>(pq, grid_to_probe_id<P2>(pq, bq));
                      f2 brid = ray_dir_to_ray_id(acc);
                      brid = F2(clamp_(brid.x, pq.rad_lo, pq.rad_hi), clamp_(brid.y, pq.rad_lo, pq.rad_hi));
-                     f3 radiance = atlas_sample<P2>(pq.rad, pq.fmt, pq.pcx, pq.pcy, pq.rres, pq.rshift, pq.rad_w, pq.rad_h, base.x + div_pcx<P2>(pq, brid.x), base.y + div_pcy<P2>(pq, brid.y), u8_tab, pq.m_rres);
+                     f3 radiance = (SPEC == 2 && pq.rad_mips) // (MDH_OPT_RADIANCE_MIPS, in the kernel variant of the optional paths only: textureLod (.., 1.0))
+                        ? radiance_lod_sample(pq, 1.0f, base.x + div_pcx<P2>(pq, brid.x), base.y + div_pcy<P2>(pq, brid.y), u8_tab)
+                        : atlas_sample<P2>(pq.rad, pq.fmt, pq.pcx, pq.pcy, pq.rres, pq.rshift, pq.rad_w, pq.rad_h, base.x + div_pcx<P2>(pq, brid.x), base.y + div_pcy<P2>(pq, brid.y), u8_tab, pq.m_rres);
                      specular_col = radiance + specular_col;
                      park_store3<MDH_PARK_SPEC>(pk, wb, specular_col);
                   }

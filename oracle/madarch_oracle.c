@@ -127,7 +127,8 @@ struct orc_renderer {
    int64_t swaps;
    int32_t *gb_index, *gb_steps;
    float *gb_t;
-   int opt_atlas, opt_mode, opt_ao, opt_gbuffer, opt_rank, opt_world, opt_timing, opt_ada_div, opt_irr_all, opt_window, opt_spec, opt_hyst;
+   int opt_atlas, opt_mode, opt_ao, opt_gbuffer, opt_rank, opt_world, opt_timing, opt_ada_div, opt_irr_all, opt_window, opt_spec, opt_hyst, opt_mips;
+   tex_t rad_mips[16]; /* MDH_OPT_RADIANCE_MIPS: levels 1 .. radiance_lods of the radiance atlas ([0] unused) */
    int opt_sdf_mode, opt_threads;
    uint64_t sdf_evals; /* closest_primitive[_info] calls of the last pass set */
    /* the work of the last run of each pass -- rays started (raycast, raycast_hit_position /
@@ -886,6 +887,54 @@ static v3 sample_irradiance(const orc_renderer *r, v3 pos, v3 normal)
    return mul(irradiance, irradiance);
 }
 
+/* MDH_OPT_RADIANCE_MIPS (not the reference's behaviour: its atlases have ONE level, render_passes.adb:113, so textureLod
+   reads level 0 whatever lod says; the switch builds what probe_utils.glsl:17 and render_probes.glsl:84-86,131,197 were
+   written for).  Level l of the radiance atlas = the 2x2 box filter of level l - 1 over the whole atlas image --
+   ((a + b) + (c + d)) * 0.25 per channel in fp32, texels taken as stored and the result stored in the atlas's own format --
+   down to one texel per probe (radiance_lods = int (log2 (radiance_resolution)) levels; the resolution must be a power
+   of two, so that no box crosses a probe's tile). */
+static void tex_alloc(tex_t *t, int w, int h, int c, int unorm);
+static int radiance_lods(const orc_renderer *r)
+{
+   int lods = 0;
+   while ((2 << lods) <= r->probes.radiance_resolution) ++lods;
+   return lods;
+}
+static void build_radiance_mips(orc_renderer *r)
+{
+   const int lods = radiance_lods(r);
+   const tex_t *src = &r->tex[MDH_TEX_RADIANCE];
+   for (int l = 1; l <= lods; ++l) {
+      tex_t *dst = &r->rad_mips[l];
+      if (dst->w != src->w / 2 || dst->h != src->h / 2 || !dst->data) tex_alloc(dst, src->w / 2, src->h / 2, 3, 0);
+      dst->unorm8 = r->tex[MDH_TEX_RADIANCE].unorm8; dst->flush_nan = r->tex[MDH_TEX_RADIANCE].flush_nan;
+      for (int y = 0; y < dst->h; ++y)
+         for (int x = 0; x < dst->w; ++x) {
+            const float *a = src->data + ((size_t)(2 * y) * src->w + 2 * x) * 3, *b = a + 3;
+            const float *c = src->data + ((size_t)(2 * y + 1) * src->w + 2 * x) * 3, *d = c + 3;
+            float v[3];
+            for (int k = 0; k < 3; ++k) v[k] = ((a[k] + b[k]) + (c[k] + d[k])) * 0.25f;
+            tex_store(dst, x, y, v);
+         }
+      src = dst;
+   }
+}
+/* textureLod (radiance_data, coord, lod) with GL_LINEAR_MIPMAP_LINEAR: lod clamped to the chain, the two nearest levels
+   sampled bilinearly and mixed by the fraction (the upper one only when the fraction is not 0); level 0 without the switch */
+static void sample_radiance_lod(const orc_renderer *r, float cx, float cy, float lod, float *out)
+{
+   if (!r->opt_mips) { tex_sample(&r->tex[MDH_TEX_RADIANCE], cx, cy, out); return; }
+   const float top = (float)radiance_lods(r);
+   const float d = clamp_(lod, 0.0f, top);
+   const int l0 = (int)d;
+   const float f = d - (float)l0;
+   float lo[4], hi[4];
+   tex_sample(l0 == 0 ? &r->tex[MDH_TEX_RADIANCE] : &r->rad_mips[l0], cx, cy, lo);
+   if (!(f > 0.0f)) { out[0] = lo[0]; out[1] = lo[1]; out[2] = lo[2]; return; }
+   tex_sample(&r->rad_mips[l0 + 1], cx, cy, hi);
+   for (int k = 0; k < 3; ++k) out[k] = lo[k] * (1.0f - f) + hi[k] * f; /* mix () */
+}
+
 /* glsl/render_probes.glsl:138-209 (M_COMPUTE_INDIRECT_SPECULAR == 2, M_ADD_INDIRECT_SPECULAR == 1) */
 static v3 sample_radiance_no_specular(const orc_renderer *r, v3 pos, v3 normal, v3 dir)
 {
@@ -920,7 +969,7 @@ static v3 sample_radiance_no_specular(const orc_renderer *r, v3 pos, v3 normal, 
    rid = V2(clamp_(rid.x, rmin, rmax), clamp_(rid.y, rmin, rmax));
    v2 coord = V2(base.x + rid.x / (float)r->probes.probe_count[0], base.y + rid.y / (float)r->probes.probe_count[1]);
    float tx[4];
-   tex_sample(&r->tex[MDH_TEX_RADIANCE], coord.x, coord.y, tx); /* textureLod(.., 1.0) on a single level = lod 0 */
+   sample_radiance_lod(r, coord.x, coord.y, 1.0f, tx); /* textureLod(.., 1.0): on a single level = lod 0 (MDH_OPT_RADIANCE_MIPS: level 1) */
    v3 radiance = V3(tx[0], tx[1], tx[2]);
    material_t m = get_material(r, spec_mat);
    radiance = add(radiance, compute_direct_lighting(r, spec_pos, spec_normal, dir, V3(0, 0, 0), m.metallic, m.roughness, 1));
@@ -963,7 +1012,7 @@ static v3 sample_radiance_with_specular(const orc_renderer *r, v3 pos, v3 normal
       rid = V2(clamp_(rid.x, rmin, rmax), clamp_(rid.y, rmin, rmax));
       v2 coord = V2(base.x + rid.x / (float)r->probes.probe_count[0], base.y + rid.y / (float)r->probes.probe_count[1]);
       float tx[4];
-      tex_sample(&r->tex[MDH_TEX_RADIANCE], coord.x, coord.y, tx);
+      sample_radiance_lod(r, coord.x, coord.y, lod, tx);
       radiance = add(radiance, scale(V3(tx[0], tx[1], tx[2]), weight));
       total_weight += weight;
    }
@@ -1261,6 +1310,7 @@ static int tile_owner(const orc_renderer *r, int px, int py)
 /* draw_screen.glsl:20-30 */
 static void pass_screen(orc_renderer *r)
 {
+   if (r->opt_mips && r->opt_mode == 0) build_radiance_mips(r); /* (every screen pass: the levels of the atlas it is about to read) */
    pass_cfg cfg = {1, r->opt_spec, r->opt_ao, r->vol.enabled ? 1 : 0, r->opt_mode}; /* renderers.adb:136-143; MDH_OPT_INDIRECT_SPECULAR */
    if (cfg.mode != 0) cfg.volumetrics = 0;
    uint64_t evals = 0, rays = 0, steps = 0;
@@ -1413,6 +1463,7 @@ int32_t orc_destroy(orc_renderer *r)
 {
    if (!r) return MDH_OK;
    for (int i = 0; i < 4; ++i) free(r->tex[i].data);
+   for (int i = 0; i < 16; ++i) free(r->rad_mips[i].data);
    for (int k = 0; k < MAX_KINDS; ++k)
       for (int q = 0; q < 3; ++q) { free(r->pk[k].x_code[q]); free(r->lk[k].x_code[q]); }
    free(r->scene_ubo); free(r->part_table); free(r->fb); free(r->front); free(r->gb_index); free(r->gb_steps); free(r->gb_t);
@@ -1453,6 +1504,11 @@ int32_t orc_set_option(orc_renderer *r, int32_t option, int32_t value)
    case MDH_OPT_RADIANCE_ORDER: break; /* which lane computes a texel, not what it holds: nothing to restate */
    case MDH_OPT_SCREEN_ORDER: break;   /* the order the tiles are started in: nothing to restate */
    case MDH_OPT_NUMERICS: if (value != 0) return seterr(MDH_E_STATE, "the oracle's numerics are the contract"); break;
+   case MDH_OPT_RADIANCE_MIPS:
+      if (value && (r->probes.radiance_resolution & (r->probes.radiance_resolution - 1)) != 0)
+         return seterr(MDH_E_INVALID, "radiance mips need a power-of-two radiance resolution");
+      r->opt_mips = value ? 1 : 0;
+      break;
    case ORC_OPT_SDF_MODE: r->opt_sdf_mode = value; break;
    case ORC_OPT_THREADS: r->opt_threads = value; break;
    default: return seterr(MDH_E_INVALID, "unknown option");
@@ -1477,6 +1533,7 @@ int32_t orc_get_option(orc_renderer *r, int32_t option, int32_t *value)
    case MDH_OPT_WINDOW: *value = r->opt_window; break;
    case MDH_OPT_INDIRECT_SPECULAR: *value = r->opt_spec; break;
    case MDH_OPT_HYSTERESIS_PERMILLE: *value = r->opt_hyst; break;
+   case MDH_OPT_RADIANCE_MIPS: *value = r->opt_mips; break;
    case MDH_OPT_RADIANCE_ORDER: *value = 0; break;
    case MDH_OPT_SCREEN_ORDER: *value = 0; break;
    case MDH_OPT_NUMERICS: *value = 0; break;
@@ -1663,6 +1720,16 @@ int32_t orc_read_gbuffer(orc_renderer *r, int32_t *index_out, float *t_out, int3
 }
 int32_t orc_read_texture(orc_renderer *r, int32_t tex, float *out, int32_t *w, int32_t *h, int32_t *c)
 {
+   if (r && tex > MDH_TEX_RADIANCE_MIP0 && tex <= MDH_TEX_RADIANCE_MIP0 + 15) { /* level tex - MDH_TEX_RADIANCE_MIP0 of the radiance atlas */
+      if (!r->opt_mips || tex - MDH_TEX_RADIANCE_MIP0 > radiance_lods(r)) return seterr(MDH_E_INVALID, "no such level (MDH_OPT_RADIANCE_MIPS)");
+      build_radiance_mips(r);
+      const tex_t *m = &r->rad_mips[tex - MDH_TEX_RADIANCE_MIP0];
+      if (w) *w = m->w;
+      if (h) *h = m->h;
+      if (c) *c = m->c;
+      if (out) memcpy(out, m->data, (size_t)m->w * m->h * m->c * sizeof(float));
+      return MDH_OK;
+   }
    if (!r || tex < 0 || tex > 3) return seterr(MDH_E_INVALID, "bad argument");
    const tex_t *t = &r->tex[tex];
    if (w) *w = t->w;
@@ -1839,6 +1906,7 @@ int32_t orc_probe_sample_irradiance(orc_renderer *r, int32_t n, const float *pos
    REFLECTED direction and the shaded point's roughness (mode 1), from the current atlases */
 int32_t orc_probe_specular(orc_renderer *r, int32_t mode, int32_t n, const float *pos, const float *nrm, const float *dir, const float *roughness, float *out)
 {
+   if (r->opt_mips) build_radiance_mips(r);
    for (int q = 0; q < n; ++q) {
       v3 P = V3(pos[3 * q], pos[3 * q + 1], pos[3 * q + 2]), N = V3(nrm[3 * q], nrm[3 * q + 1], nrm[3 * q + 2]), D = V3(dir[3 * q], dir[3 * q + 1], dir[3 * q + 2]);
       v3 c = mode == 1 ? sample_radiance_with_specular(r, P, N, D, roughness[q]) : (mode == 2 ? sample_radiance_no_specular(r, P, N, D) : compute_indirect_specular(r, P, N, D, 1));

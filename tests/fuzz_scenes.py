@@ -78,6 +78,9 @@ def build(seed, binding):
     R.Set_Option(B.OPT_WINDOW, int(rng.integers(0, 2)))
     # (a generator of its own: the scenes of the seeds run before this option existed stay what they were)
     R.Set_Option(B.OPT_INDIRECT_SPECULAR, int(np.random.default_rng(int(seed) ^ 0x5BEC).choice([2, 2, 0, 1, 3])))
+    # (seeds from 6000 on: the optional mip chain of the radiance atlas, where the drawn resolution is a power of two)
+    if int(seed) >= 6000 and np.random.default_rng(int(seed) ^ 0x3195).integers(0, 3) == 0 and (R.Probes.Radiance_Resolution & (R.Probes.Radiance_Resolution - 1)) == 0:
+        R.Set_Option(B.OPT_RADIANCE_MIPS, 1)
     frames = int(rng.integers(1, 4))
     out = snapshot(R, frames)
     if part_on:

@@ -561,6 +561,51 @@ def test_indirect_specular_modes(hip, orc, spec, scene, W, H, probes, atlas):
         R.Set_Option(B.OPT_INDIRECT_SPECULAR, 4)
 
 
+@pytest.mark.parametrize("scene,W,H,spec,atlas,overlap", [("global_illumination", 80, 56, 2, 0, 2), ("global_illumination", 72, 48, 1, 1, 0),
+                                                         ("simple_scene", 64, 48, 2, 1, 2), ("light_shafts", 48, 40, 1, 0, 2)])
+def test_radiance_mips_switch(hip, orc, scene, W, H, spec, atlas, overlap):
+    """MDH_OPT_RADIANCE_MIPS (off by default; the reference's atlases have one level): a mip chain of the radiance atlas,
+    rebuilt before every screen pass, read by mode 2's tap at level 1 and by mode 1's at mix (0, radiance_lods, 2 roughness)
+    -- RGB8 and fp32 atlases, frames in flight or not, through the space partition and the volumetric composite.  The
+    levels themselves are read back and compared bit for bit."""
+    outs, levels = [], []
+    for b in (hip, orc):
+        R = make(scene, W, H, b, atlas=atlas, probes=SMALL_PROBES)
+        R.Set_Option(B.OPT_FRAME_OVERLAP, overlap)
+        R.Set_Option(B.OPT_INDIRECT_SPECULAR, spec)
+        assert R.Get_Option(B.OPT_RADIANCE_MIPS) == 0
+        R.Set_Option(B.OPT_RADIANCE_MIPS, 1)
+        assert R.Get_Option(B.OPT_RADIANCE_MIPS) == 1
+        outs.append(snapshot(R, 3))
+        levels.append([R.Read_Texture(B.TEX_RADIANCE_MIP0 + l) for l in range(1, 5)])
+    assert_parity(*outs)
+    assert (outs[0]["image"].view(np.uint32) == outs[1]["image"].view(np.uint32)).mean() > 0.999
+    for l, (g, w) in enumerate(zip(*levels), 1):
+        assert g.shape == (outs[0]["radiance"].shape[0] >> l, outs[0]["radiance"].shape[1] >> l, 3)
+        assert same_bits(g, w), "level %d" % l
+    # the switch really changes the image (where a pixel sends a reflection ray: every material of light_shafts has roughness 1) ...
+    R = make(scene, W, H, hip, atlas=atlas, probes=SMALL_PROBES)
+    R.Set_Option(B.OPT_FRAME_OVERLAP, overlap)
+    R.Set_Option(B.OPT_INDIRECT_SPECULAR, spec)
+    plain = snapshot(R, 3)
+    assert same_bits(plain["image"], outs[0]["image"]) == (scene == "light_shafts")
+    # ... and switching it off again gives the plain frames back
+    R2 = make(scene, W, H, hip, atlas=atlas, probes=SMALL_PROBES)
+    R2.Set_Option(B.OPT_FRAME_OVERLAP, overlap)
+    R2.Set_Option(B.OPT_INDIRECT_SPECULAR, spec)
+    R2.Set_Option(B.OPT_RADIANCE_MIPS, 1)
+    R2.Render()
+    R2.Set_Option(B.OPT_RADIANCE_MIPS, 0)
+    R3 = make(scene, W, H, hip, atlas=atlas, probes=SMALL_PROBES)
+    R3.Set_Option(B.OPT_FRAME_OVERLAP, overlap)
+    R3.Set_Option(B.OPT_INDIRECT_SPECULAR, spec)
+    R3.Render()
+    assert same_bits(snapshot(R2, 2)["image"], snapshot(R3, 2)["image"])
+    R4 = make(scene, W, H, hip, atlas=atlas, probes=ODD_PROBES)
+    with pytest.raises(B.MadarchError):
+        R4.Set_Option(B.OPT_RADIANCE_MIPS, 1)  # 12 texels per probe
+
+
 @pytest.mark.parametrize("atlas,overlap,probes", [(0, 2, SMALL_PROBES), (1, 0, ODD_PROBES), (1, 2, SMALL_PROBES)])
 def test_hysteresis_blends_with_the_previous_frames_irradiance(hip, orc, atlas, overlap, probes):
     """MDH_OPT_HYSTERESIS_PERMILLE (a deviation the survey lists, off by default): stored = mix (fresh, previous, h),

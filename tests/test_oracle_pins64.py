@@ -469,3 +469,109 @@ def test_cpu_best_acceptance_order_against_restatement(orc):
         assert table[cell, nk:nk + len(want_idx)].tolist() == want_idx, (cell, table[cell], want_idx)
         checked += 1
     assert checked > 200
+
+
+# --------------------------------------------------------------------------- MDH_OPT_RADIANCE_MIPS (an optional switch)
+def _mips64(rad):
+    """levels 0 .. log2 (res) of the atlas image: 2 x 2 box filter of the level below"""
+    levels = [rad]
+    while levels[-1].shape[0] % 2 == 0 and levels[-1].shape[1] % 2 == 0 and len(levels) <= int(np.log2(SMALL_PROBES.Radiance_Resolution)):
+        a = levels[-1]
+        levels.append((a[0::2, 0::2] + a[0::2, 1::2] + a[1::2, 0::2] + a[1::2, 1::2]) / 4.0)
+    return levels
+
+
+def _lod_tap64(levels, q, dims, pc, res, direction, lod, lo=None):
+    """textureLod as GL_LINEAR_MIPMAP_LINEAR: lod clamped to the chain, two bilinear taps mixed by its fraction"""
+    d = min(max(lod, 0.0), float(len(levels) - 1))
+    l0 = int(np.floor(d))
+    f = d - l0
+    a = _probe_tap64(levels[l0], q, dims, pc, res, direction, lo=lo)
+    return a if f == 0.0 else a * (1.0 - f) + _probe_tap64(levels[l0 + 1], q, dims, pc, res, direction, lo=lo) * f
+
+
+def test_radiance_mip_levels_against_float64(orc):
+    """The switch's chain: every level is the 2 x 2 box filter of the one below over the whole atlas image, down to one
+    texel per probe; refused for a resolution that is no power of two; off by default."""
+    R, rad, _ = _gi(orc)
+    assert R.Get_Option(B.OPT_RADIANCE_MIPS) == 0
+    with pytest.raises(B.MadarchError):
+        R.Read_Texture(B.TEX_RADIANCE_MIP0 + 1)
+    R.Set_Option(B.OPT_RADIANCE_MIPS, 1)
+    levels = _mips64(rad)
+    assert len(levels) == 5  # 16, 8, 4, 2, 1 texels per probe
+    for l in range(1, len(levels)):
+        got = R.Read_Texture(B.TEX_RADIANCE_MIP0 + l)
+        assert got.shape == levels[l].shape
+        assert np.allclose(got, levels[l], rtol=1e-6, atol=1e-7), l
+    with pytest.raises(B.MadarchError):
+        R.Read_Texture(B.TEX_RADIANCE_MIP0 + len(levels))
+    from helpers import ODD_PROBES
+    R2 = examples.global_illumination(8, 8, Probes=ODD_PROBES, Binding=orc)
+    with pytest.raises(B.MadarchError):
+        R2.Set_Option(B.OPT_RADIANCE_MIPS, 1)  # 12 texels per probe: no chain without boxes across tiles
+
+
+def test_specular_taps_over_the_mip_chain_against_float64(orc):
+    """With the switch on, mode 2's tap reads level 1 (textureLod (.., 1.0), render_probes.glsl:197) and mode 1's reads
+    lod = mix (0, radiance_lods, 2 roughness) between two levels (render_probes.glsl:84-86,131)."""
+    R, rad, _ = _gi(orc)
+    R.Set_Option(B.OPT_RADIANCE_MIPS, 1)
+    levels = _mips64(rad)
+    P = SMALL_PROBES
+    sp, dims, pc, rres = np.array(P.Grid_Spacing, np.float64), np.array(P.Grid_Dimensions), np.array(P.Probe_Count), P.Radiance_Resolution
+    # mode 2
+    pts = _surface_points(50, 47)
+    got = _call_specular(orc, R, 2, pts)
+    ok = differs = 0
+    for (pos, nrm, r, _), g in zip(pts, got):
+        spec = raycast64(pos + nrm * MSS * 5.0, r)
+        if spec is None:
+            want = want0 = np.zeros(3)
+        else:
+            sn, smat = gi_info64(spec)
+            gp = np.floor(spec / sp).astype(int)
+            best, bq, bpts = -2.0, None, None
+            for i in range(8):
+                q = np.clip(gp + np.array([i & 1, (i >> 1) & 1, (i >> 2) & 1]), 0, dims - 1)
+                pts_ = spec - q * sp
+                dist = np.linalg.norm(pts_)
+                pts_ = pts_ / dist
+                w = np.dot(pts_, -sn) * visibility64(spec + sn * MSS * 5.0, -pts_, dist - MSS * 5.0)
+                if w > best:
+                    best, bq, bpts = w, q, pts_
+            direct = direct64(spec, sn, r, (0.0, 0.0, 0.0), GI_MATS[smat][1], GI_MATS[smat][2])
+            want = _lod_tap64(levels, bq, dims, pc, rres, bpts, 1.0) + direct
+            want0 = _probe_tap64(rad, bq, dims, pc, rres, bpts) + direct
+        ok += np.allclose(g, want, rtol=2e-3, atol=2e-4)
+        differs += not np.allclose(want, want0, rtol=2e-3, atol=2e-4)
+    assert ok >= 0.9 * len(pts), ok
+    assert differs >= 0.5 * len(pts)  # (level 1 of a random atlas is not level 0: the test tells them apart)
+    # mode 1
+    pts = _surface_points(40, 53)
+    rough = np.random.RandomState(6).uniform(0.0, 0.7, len(pts)).astype(np.float32)
+    got = _call_specular(orc, R, 1, pts, rough)
+    ok = 0
+    for (pos, nrm, r, _), g, ro in zip(pts, got, rough.astype(np.float64)):
+        spec = raycast64(pos + nrm * MSS * 5.0, r)
+        if spec is None:
+            want = np.zeros(3)
+        else:
+            gp = np.floor(pos / sp).astype(int)
+            alpha = pos / sp - gp
+            lod = float(int(np.log2(rres))) * (ro * 2.0)
+            new_res = rres // int(lod + 1.0)
+            acc, wsum = np.zeros(3), 0.0
+            for i in range(8):
+                off = np.array([i & 1, (i >> 1) & 1, (i >> 2) & 1])
+                q = np.clip(gp + off, 0, dims - 1)
+                pts_ = (pos - q * sp) + (spec - pos)
+                dist = np.linalg.norm(pts_)
+                pts_ = pts_ / dist
+                w = max(softshadows64(spec, -pts_, MSS * 5.0, dist - MSS * 5.0, 0.5), 0.001)
+                w *= np.where(off == 1, alpha, 1.0 - alpha).prod()
+                acc += _lod_tap64(levels, q, dims, pc, rres, pts_, lod, lo=0.5 / new_res) * w
+                wsum += w
+            want = acc / wsum if wsum else np.zeros(3)
+        ok += np.allclose(g, want, rtol=3e-3, atol=3e-4)
+    assert ok >= 0.85 * len(pts), ok
