@@ -293,13 +293,13 @@ template <int PART, bool SMALL = false> __global__ __launch_bounds__(MDH_BLOCK, 
    stage_table(sc);
    f3 c;
    PrimaryHit ph;
+   PH_KERNEL_BEGIN();
    {
       const long lin = (long)blockIdx.x * MDH_BLOCK + threadIdx.x;
       int x, y, probe_raw;
       radiance_texel(pr, ro, lin, x, y, probe_raw);
       const bool valid = probe_raw < pr.probe_end;
       MDH_DIAG_WAVE(lin >> 6);
-      PH_KERNEL_BEGIN();
       const int probe = valid ? probe_raw : pr.probe_begin;
       const int ty = probe / pr.pcx, tx = probe - ty * pr.pcx;
       const int i = tx * pr.rres + x, j = ty * pr.rres + y; // texel of the reference's 2-D atlas image

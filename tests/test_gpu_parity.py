@@ -216,8 +216,8 @@ def test_sharded_frame_equals_whole_frame(hip, probes, N, irr_all):
         assert same_bits(R.Read_Texture(B.TEX_RADIANCE), whole["radiance"])
 
 
-@pytest.mark.parametrize("irr_all", [1, 0])
-def test_sharded_frames_in_flight_equal_whole_frames(hip, irr_all):
+@pytest.mark.parametrize("irr_all,mips", [(1, 0), (0, 0), (1, 1)])
+def test_sharded_frames_in_flight_equal_whole_frames(hip, irr_all, mips):
     """The same two ranks through the three-step frame (Frame_Begin / Frame_Probe_Pass / Frame_End) that
     madarch_amd.sharding drives: frames stay in flight (two atlas sets, three streams per renderer) while
     the slices are exchanged inside the open frame."""
@@ -225,6 +225,7 @@ def test_sharded_frames_in_flight_equal_whole_frames(hip, irr_all):
     W = make("global_illumination", 120, 72, hip, probes=SMALL_PROBES)
     W.Set_Option(B.OPT_GBUFFER, 0)
     W.Set_Option(B.OPT_FRAME_OVERLAP, 0)
+    W.Set_Option(B.OPT_RADIANCE_MIPS, mips)  # (the optional mip chain: every rank builds it from the whole, exchanged atlas)
     for _ in range(frames):
         W.Render()
     want = {"image": W.Read_Framebuffer(), "irradiance": W.Read_Texture(B.TEX_IRRADIANCE), "radiance": W.Read_Texture(B.TEX_RADIANCE)}
@@ -234,6 +235,7 @@ def test_sharded_frames_in_flight_equal_whole_frames(hip, irr_all):
         R.Set_Option(B.OPT_RANK, r)
         R.Set_Option(B.OPT_WORLD, 2)
         R.Set_Option(B.OPT_IRRADIANCE_ALL, irr_all)
+        R.Set_Option(B.OPT_RADIANCE_MIPS, mips)
     P = Rs[0].Probe_Total()
     for _ in range(frames):
         for R in Rs:
