@@ -5,9 +5,10 @@ sys.path.insert(0, ROOT)
 from madarch_amd import examples, _binding as B
 R = examples.global_illumination(1920, 1080, Probes=examples.GI_8X8X8_PROBES)
 R.Set_Option(B.OPT_FRAME_OVERLAP, 0)
+if os.environ.get("RAD_ORDER") is not None: R.Set_Option(B.OPT_RADIANCE_ORDER, int(os.environ["RAD_ORDER"]))
 for _ in range(5): R.Render()
 out = {}
-for world in (8, 4):
+for world in (8, 4, 2, 1):
     R.Set_Option(B.OPT_WORLD, world); R.Set_Option(B.OPT_RANK, 0)
     for _ in range(20): R.Render_Pass(B.PASS_RADIANCE)
     R.Finish(); R.Set_Option(B.OPT_TIMING, 1); R.Reset_Pass_Times()
@@ -16,4 +17,4 @@ for world in (8, 4):
     ms, n = R.Pass_Time(B.PASS_RADIANCE)
     out[world] = round(ms / n * 1e3, 1)
     R.Set_Option(B.OPT_TIMING, 0)
-print("team %s owners %s: radiance pass of rank 0's slice, us: %s" % (os.environ.get("MADARCH_HIP_RAD_TEAM", "1"), os.environ.get("MADARCH_HIP_RAD_OWNERS", "auto"), out), flush=True)
+print("rays sorted %s: radiance pass of rank 0's slice, us: %s" % (R.Get_Option(B.OPT_RADIANCE_ORDER), out), flush=True)

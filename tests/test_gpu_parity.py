@@ -632,7 +632,12 @@ MANY_PROBES = renderers.Probe_Settings(Radiance_Resolution=8, Irradiance_Resolut
                                        Grid_Spacing=(0.45, 0.35, 0.5))
 
 
-@pytest.mark.parametrize("probes,world", [(examples.GI_8X8X8_PROBES, 1), (ODD_PROBES, 1), (MANY_PROBES, 1), (examples.GI_8X8X8_PROBES, 2)])
+# tiles of 12 x 12 texels (no power of two) in a launch of more than one wavefront per SIMD of an MI355X
+BIG_ODD_PROBES = renderers.Probe_Settings(Radiance_Resolution=12, Irradiance_Resolution=6, Probe_Count=(25, 20), Grid_Dimensions=(10, 10, 5),
+                                          Grid_Spacing=(0.7, 0.7, 1.4))
+
+
+@pytest.mark.parametrize("probes,world", [(examples.GI_8X8X8_PROBES, 1), (BIG_ODD_PROBES, 1), (ODD_PROBES, 1), (MANY_PROBES, 1), (examples.GI_8X8X8_PROBES, 2)])
 def test_radiance_ray_order_changes_no_texel(hip, probes, world):
     """MDH_OPT_RADIANCE_ORDER: from the second frame on the radiance pass takes its rays sorted by the previous frame's
     primary-march lengths (power-of-two and other tile sizes, a rank's slice, a light that moves between frames so that
