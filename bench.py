@@ -384,6 +384,11 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": int(alg_bytes), "bytes_per_pixel": per_px,
                          "kernel_ms_avg": screen_ms_piped, "kernel_ms_source": "timed region, HIP events on the kernel's stream",
+                         # consecutive frames draw on two streams: launches of this kernel overlap one another, each stretched
+                         # by its neighbour -- the rate the chip sustains for the kernel is all launches' bytes over the region
+                         "launches_overlapping": round(screen_ms_piped * 1e-3 * args.steps / dt, 3),
+                         "achieved_all_launches": round(alg_bytes * args.steps / dt / 1e9, 3),
+                         "frac_all_launches": round(alg_bytes * args.steps / dt / 1e9 / HBM_PEAK_GBS, 6),
                          "note": "the path is fp32-VALU bound (sphere tracing), not HBM bound; see DESIGN.md 'Roofline' and valu_issue below; achieved = algorithmic bytes of one k_screen launch / its average duration in the timed region, where kernels of neighbouring frames share the chip (roofline_serial: the same kernel with the chip to itself)"},
             "passes": passes,
         }
