@@ -217,6 +217,24 @@ def test_compiled_distance_programs_join_the_wave_level_culling(hip, tmp_path, m
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("jit", [1, 0])
+def test_hip_new_kinds_over_the_radiance_mip_chain(hip, orc, jit):
+    """MDH_OPT_RADIANCE_MIPS with user-defined kinds: the screen kernel's variant for the optional paths, compiled around the
+    scene's programs by hiprtc (or interpreting them), against the oracle."""
+    outs = []
+    for b in (hip, orc):
+        R = room(b, False, W=72, H=48, extra=EXTRA)
+        R.Set_Option(B.OPT_JIT, jit)
+        R.Set_Option(B.OPT_RADIANCE_MIPS, 1)
+        outs.append(snapshot(R, 2))
+        if b is hip:
+            assert R.Get_Option(B.OPT_JIT) == jit
+    assert_same(*outs)
+    plain = snapshot(room(hip, False, W=72, H=48, extra=EXTRA), 2)
+    assert not same_bits(plain["image"], outs[0]["image"])  # (the chain is read: reflecting spheres and capsules are in view)
+
+
+@pytest.mark.gpu
 def test_hip_rejects_invalid_programs(hip):
     k = type(ck.My_Sphere)("Broken", ck.My_Sphere.comps, ck.My_Sphere.distance, ck.My_Sphere.normal, ck.My_Sphere.material)
     d, n, m = ck.My_Sphere.programs()
