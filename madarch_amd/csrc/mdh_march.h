@@ -255,6 +255,9 @@ template <int SLOT> MDH_DEV float park_load1(const float *pk, int wb)
 // LDS: entries are u16 in park slots 12..15 of the wave (free until the irradiance is parked),
 // slot 16 = first-step distance, slot 17 = visibility word.
 // ---------------------------------------------------------------------------------------------
+#ifndef MDH_CORNER_UNROLL
+#define MDH_CORNER_UNROLL 8 // the cage-corner loop of the pixel program, unrolled: constant corner bits, no loop branch (measured 1, 2, 4, 8)
+#endif
 #ifndef MDH_QVIS_FAR_FIRST
 #define MDH_QVIS_FAR_FIRST 1
 #endif
@@ -701,6 +704,10 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
 {
    constexpr bool P2 = (PART & MDH_PF_POW2) != 0;
    constexpr bool REFLECT = SPEC != 0 && MODE == 0; // (modes 1 and 2 never shade a second point: no loop, and nothing kept for one)
+   // The cage-corner loop unrolled where the registers allow it (the brute-force screen kernel of the reference's fixed mode:
+   // 96 VGPRs with and without; the partition variants and the one for the optional specular modes would spill 80 - 200 bytes
+   // per lane, the radiance kernel gains nothing): constant corner bits, no loop branch, the x-twin's terms at hand.
+   constexpr int CORNER_UNROLL = ((PART & MDH_PF_PART) || SPEC != 1 || QVIS) ? 1 : MDH_CORNER_UNROLL;
    constexpr int PARK_MAT = MODE == 2 ? MDH_PARK_MAT_DIRECT : MDH_PARK_MAT; // (no probe rows in mode 2: MDH_DIRECT_PARK_ROWS)
    // the second point goes through the whole of pixel_color_probes' lighting (compute_indirect_specular) ...
    const bool full2 = SPEC == 2 && cfg.spec_mode == 3;
@@ -884,7 +891,7 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
                   // y was measured at +0.4 %, DESIGN.md.)
                   f3 s_keep = F3(0.0f, 0.0f, 0.0f);
                   float w_keep = 0.0f;
-#pragma unroll 1
+#pragma unroll CORNER_UNROLL
                   for (int i = 0; i < 8; ++i) {
                      // best probe: a folded corner has the weight of its twin, which is not strictly larger
                      if (MDH_REUSE_FOLDED && !irrp && (i & folded)) continue;
