@@ -36,22 +36,64 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 WORKLOADS = {
     # name: (scene, width, height, probes, screen mode)
     "global_illumination_1080p_ddgi8x8x8": ("global_illumination", 1920, 1080, "gi8", 0),
-    "simple_scene_1080p_direct": ("simple_scene", 1920, 1080, None, 2),
+    "simple_scene_1080p_direct": ("simple_scene", 1920, 1080, None, 2),  # BASELINE config 2: a build-defined subset (direct light + occlusion)
     "light_shafts_1080p": ("light_shafts", 1920, 1080, None, 0),
     "global_illumination_4096sq_ddgi8x8x8": ("global_illumination", 4096, 4096, "gi8", 0),
+    # the reference's examples as they actually run: the renderer's fixed screen macros
+    # (madarch-renderers.adb:136-143: direct specular, mode-2 indirect specular, 3 occlusion steps) with the default
+    # probe settings (madarch-renderers.ads:23-29: 4x3x3 probes as a 6x6 atlas)
+    "simple_scene_1080p_full": ("simple_scene", 1920, 1080, None, 0),  # through the space partition, CPU_Best (examples/simple_scene/main.adb:36-39,122)
+    "global_illumination_1080p_default_probes": ("global_illumination", 1920, 1080, None, 0),  # "report the reference-default 4x3x3 once"
+    # examples/ball_game/main.adb:39-40,196-252: ten balls; every step = physics query + ten Set_Primitive + Update_Partitioning + Render
+    "ball_game_1080p": ("ball_game", 1920, 1080, None, 0),
+    "ball_game_1080p_ddgi8x8x8": ("ball_game", 1920, 1080, "gi8", 0),  # (what scripts/ball_game_bench.py measured in rounds 2 and 3)
     # --rehearse-cpu only: the control flow of this file with N ranks on the CPU (gloo, the oracle as the engine)
     "rehearsal_small": ("global_illumination", 96, 64, None, 0),
 }
 
 
-def make_renderer(workload, binding, device=0):
+def make_renderer(workload, binding, device=0, settle_frames=True):
     from madarch_amd import _binding as B
     from madarch_amd import examples
     scene, W, H, probes, mode = WORKLOADS[workload]
     P = examples.GI_8X8X8_PROBES if probes == "gi8" else None
-    R = examples.SCENES[scene](W, H, Probes=P, Binding=binding, Device=device)
+    if scene == "ball_game":  # the game object rides on the renderer: make_step() below drives its loop body
+        G = examples.ball_game(W, H, Probes=P, Binding=binding, Device=device)
+        for _ in range(10):  # ten balls in the air, thrown from a moving camera (as scripts/ball_game_bench.py did)
+            G.Throw_Ball()
+            G.Move_Camera((0.2, 0.05, 0.0))
+            for _ in range(3):
+                if settle_frames:
+                    G.Frame()
+                else:  # (the CPU baseline: the same ball positions without thirty oracle frames)
+                    G.Step_Physics()
+        if not settle_frames:
+            G.R.Update_Partitioning()
+        R = G.R
+        R.Game = G
+    else:
+        R = examples.SCENES[scene](W, H, Probes=P, Binding=binding, Device=device)
     R.Set_Option(B.OPT_SCREEN_MODE, mode)
     return R
+
+
+def mode_of(R):
+    from madarch_amd import _binding as B
+    return R.Get_Option(B.OPT_SCREEN_MODE)
+
+
+def make_step(R, frame):
+    """One step of the workload: Renderers.Render -- or, for ball_game, the example's whole loop body
+    (examples/ball_game/main.adb:244-252: physics with its distance queries, the scene edits, Update_Partitioning, Render)."""
+    G = getattr(R, "Game", None)
+    if G is None:
+        return frame.Render
+
+    def step():
+        G.Step_Physics()
+        R.Update_Partitioning()
+        frame.Render()
+    return step
 
 
 def algorithmic_bytes_screen(R):
@@ -125,7 +167,7 @@ def cpu_baseline(workload):
     cannot be built here) on the host cores: one warm-up frame, then whole frames for about ten seconds."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle_engine import ORC_OPT_THREADS, oracle_binding
-    R = make_renderer(workload, oracle_binding())
+    R = make_renderer(workload, oracle_binding(), settle_frames=False)
     R.Set_Option(ORC_OPT_THREADS, host_cpu_share())
     cores = R.Get_Option(ORC_OPT_THREADS)
     R.Render()
@@ -263,6 +305,7 @@ def main():
         R.Comm_Init(R.Comm_Unique_Id(), 0, 1)
         how = "rccl"
     frame = sharding.ShardedFrame(R, rank, world, exchange)
+    step = make_step(R, frame)
 
     def sync():  # barrier + device synchronisation: every pass this rank has enqueued is done, then every rank is here
         R.Finish()
@@ -287,12 +330,12 @@ def main():
     t_pre = time.perf_counter()
     while True:
         for _ in range(2 if rehearsal else 25):
-            frame.Render()
+            step()
         R.Finish()
         if vmax(time.perf_counter() - t_pre) >= args.prewarm_s:
             break
     for _ in range(args.warmup):
-        frame.Render()
+        step()
     sync()
     R.Set_Option(B.OPT_TIMING, 1)
     R.Reset_Pass_Times()
@@ -301,7 +344,7 @@ def main():
     for _ in range(args.steps):
         if animate:
             animate()
-        frame.Render()
+        step()
         if args.swap_buffers:  # pixels of the frame before reach the host while this one is drawn
             if _:
                 R.Front_Buffer(copy=False)
@@ -320,6 +363,8 @@ def main():
         return out
 
     passes = pass_times()
+    # N > 1: the exchange's time per frame as the MAX over the ranks (every rank calls this; HIP events on the probe stream)
+    exchange_ms = vmax(passes.get("exchange", {}).get("ms_avg", 0.0)) if world > 1 or "exchange" in passes else None
     overlap = R.Get_Option(B.OPT_FRAME_OVERLAP)
     passes_serial, serial_dt = None, None
     if (overlap or rehearsal) and not args.no_serial_segment:  # (the oracle has no schedule; the rehearsal walks the segment's control flow all the same)
@@ -327,11 +372,11 @@ def main():
         # untimed run of the strictly serial schedule gives each kernel's duration on its own.
         R.Set_Option(B.OPT_FRAME_OVERLAP, 0)
         for _ in range(1 if rehearsal else 3):
-            frame.Render()
+            step()
         sync()
         R.Reset_Pass_Times()
         for _ in range(1 if rehearsal else 10):
-            frame.Render()
+            step()
         sync()
         passes_serial = pass_times()
         # wall time of ONE device-synchronised Renderers.Render (all passes), nothing else in flight
@@ -340,9 +385,24 @@ def main():
         sync()
         ts = time.perf_counter()
         for _ in range(n_serial):
-            frame.Render()
+            step()
             R.Finish()
         serial_dt = vmax((time.perf_counter() - ts) / n_serial)
+        # SURVEY.md 8(d)'s steady-state protocol to the letter: atlases zeroed, 8 warm-up frames, frames 9 .. 40 timed one
+        # by one (each device-synchronised), the MEDIAN reported
+        if not rehearsal and mode_of(R) == 0 and getattr(R, "Game", None) is None:
+            import numpy as np
+            for tex in (B.TEX_RADIANCE, B.TEX_IRRADIANCE):
+                R.Write_Texture(tex, np.zeros(R.Texture_Shape(tex), dtype=np.float32))
+        per_frame = []
+        for f in range(2 if rehearsal else 40):
+            sync()
+            tf = time.perf_counter()
+            step()
+            R.Finish()
+            per_frame.append(vmax(time.perf_counter() - tf))
+        steady = sorted(per_frame[(0 if rehearsal else 8):])
+        steady_median = steady[len(steady) // 2] if len(steady) % 2 else 0.5 * (steady[len(steady) // 2 - 1] + steady[len(steady) // 2])
         R.Set_Option(B.OPT_FRAME_OVERLAP, overlap)
 
     parallelism = "tiles+probes/%d" % world
@@ -373,25 +433,31 @@ def main():
             "metric": "Mpixels/sec at %dx%d %s scene (one Renderers.Render frame: every pass of renderers.adb:302-321)" % (W, H, scene),
             "value": round(value, 3), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic", "schema": 3,
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic", "schema": 4,
             "config": {"workload": args.workload, "scene": scene, "width": W, "height": H,
-                       "probe_grid": "8x8x8" if probes == "gi8" else "4x3x3", "atlas": args.atlas,
+                       "probe_grid": "8x8x8" if probes == "gi8" else "4x3x3 (the reference's default, renderers.ads:23-29)", "atlas": args.atlas,
+                       "step": "physics query + scene edits + Update_Partitioning + Renderers.Render (examples/ball_game/main.adb:244-252)" if scene == "ball_game" else "Renderers.Render",
                        "screen_mode": mode, "parallelism": parallelism, "exchange": how,
                        "frame_overlap": overlap, "animated_light": bool(animate), "swap_buffers": bool(args.swap_buffers),
                        "radiance_order": int(R.Get_Option(B.OPT_RADIANCE_ORDER)), "screen_order": int(R.Get_Option(B.OPT_SCREEN_ORDER)),
                        "numerics": "fast" if R.Get_Option(B.OPT_NUMERICS) else "exact"},
-            "roofline": {"bound": "hbm", "kernel": "k_screen", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": int(alg_bytes), "bytes_per_pixel": per_px,
-                         "kernel_ms_avg": screen_ms_piped, "kernel_ms_source": "timed region, HIP events on the kernel's stream",
-                         # consecutive frames draw on two streams: launches of this kernel overlap one another, each stretched
-                         # by its neighbour -- the rate the chip sustains for the kernel is all launches' bytes over the region
-                         "launches_overlapping": round(screen_ms_piped * 1e-3 * args.steps / dt, 3),
-                         "achieved_all_launches": round(alg_bytes * args.steps / dt / 1e9, 3),
-                         "frac_all_launches": round(alg_bytes * args.steps / dt / 1e9 / HBM_PEAK_GBS, 6),
-                         "note": "the path is fp32-VALU bound (sphere tracing), not HBM bound; see DESIGN.md 'Roofline' and valu_issue below; achieved = algorithmic bytes of one k_screen launch / its average duration in the timed region, where kernels of neighbouring frames share the chip (roofline_serial: the same kernel with the chip to itself)"},
+            # schema 4: `roofline` = the kernel's algorithmic bytes of ALL timed launches over the timed
+            # region -- the figure that follows from the driver-timed `value` (consecutive frames draw on two streams, so
+            # launches of this kernel overlap one another and each is stretched by its neighbours); the per-launch duration
+            # inside the region is under `roofline_per_launch`, the kernel with the chip to itself under `roofline_serial`
+            "roofline": {"bound": "hbm", "kernel": "k_screen", "achieved": round(alg_bytes * args.steps / dt / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(alg_bytes * args.steps / dt / 1e9 / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": int(alg_bytes), "bytes_per_pixel": per_px, "launches": args.steps,
+                         "region_ms": round(dt * 1e3, 4),
+                         "note": "the path is fp32-VALU bound (sphere tracing), not HBM bound; see DESIGN.md 'Roofline' and valu_issue below; achieved = algorithmic bytes of the k_screen launches of the timed region / the region's wall time"},
+            "roofline_per_launch": {"bound": "hbm", "kernel": "k_screen", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                    "frac": round(achieved / HBM_PEAK_GBS, 6), "kernel_ms_avg": screen_ms_piped,
+                                    "kernel_ms_source": "timed region, HIP events on the kernel's stream (launches of neighbouring frames overlap: each is stretched)",
+                                    "launches_overlapping": round(screen_ms_piped * 1e-3 * args.steps / dt, 3)},
             "passes": passes,
         }
+        if exchange_ms is not None:
+            out["exchange"] = {"ms_avg_max_over_ranks": round(exchange_ms, 4), "how": how}
         if passes_serial:
             ach_s = alg_bytes / (screen_ms_serial * 1e-3) / 1e9
             out["roofline_serial"] = {"bound": "hbm", "kernel": "k_screen", "achieved": round(ach_s, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -401,6 +467,9 @@ def main():
             out["value_serial"] = round(W * H / serial_dt / 1e6, 3)
             out["ms_per_step_serial"] = round(serial_dt * 1e3, 4)
             out["serial_note"] = "one device-synchronised Renderers.Render at a time (MDH_OPT_FRAME_OVERLAP = 0, host wait after every frame), averaged over %d frames: SURVEY.md 8(d)'s frame time; `value` keeps consecutive frames in flight" % n_serial
+            out["steady_state"] = {"protocol": "SURVEY.md 8(d): atlases zeroed, 8 warm-up frames, frames 9..40 one device-synchronised frame at a time, median",
+                                   "ms_median": round(steady_median * 1e3, 4), "value_median": round(W * H / steady_median / 1e6, 3),
+                                   "ms_min": round(steady[0] * 1e3, 4), "ms_max": round(steady[-1] * 1e3, 4), "frames": len(steady)}
         valu = measured_valu(args.workload, world, passes_serial or passes)
         if valu:
             out["valu_issue"] = valu

@@ -1525,7 +1525,7 @@ extern "C" int32_t mdh_update_partitioning(mdh_renderer *r, int32_t method)
    HIP_TRY(hipMemcpyAsync(r->d_part_ring[ns], r->d_part_ring[r->part_slot], total * 4, hipMemcpyDeviceToDevice, up));
    HIP_TRY(hipMemsetAsync(r->d_warn, 0, 4, up));
    if (cells > 0) {
-      hipLaunchKernelGGL(k_partition_build, dim3((cells + 63) / 64), dim3(64), lds_bytes(r), up, ks_no_bits(r), a);
+      hipLaunchKernelGGL(k_partition_build, dim3(cells), dim3(64), lds_bytes(r), up, ks_no_bits(r), a); // one wavefront per cell
       HIP_TRY(hipGetLastError());
    }
    // the lists once more as bits, for every cell (cells the builder left alone keep their lists, and so their bits)

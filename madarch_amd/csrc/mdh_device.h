@@ -939,8 +939,70 @@ template <bool INFO, bool CUSTOM, bool FALLBACK = true> MDH_DEV float partitioni
 // lane's last odd candidate is evaluated twice -- the minimum does not change, and the wave waits for its longest list
 // anyway).  Lanes whose rays are in the same cell -- most of an 8 x 8 tile's -- gather the same primitive at the same time
 // (an LDS broadcast).  `t` = the first float4 of the instance bit 0 stands for.
+// ONE square root per lookup for all sphere candidates of a radius and ONE for all box candidates (round 4).
+//
+// simple_scene's cells name 1.8 candidates on average (at most 8), so the pair loops below mostly evaluated one sphere
+// and one box TWICE each -- four correctly rounded square roots (16 instructions each) per march step, 120 of a step's 200
+// vector instructions.  The square root and the IEEE addition behind it are monotonic, so the minimum commutes with them:
+//   spheres of one radius r:  min_i (sqrt (d2_i) - r) = sqrt (min_i d2_i) - r     (bit for bit: fl is non-decreasing)
+//   boxes:  t_i = sqrt (s_i) + u_i with s_i = |max (q_i, 0)|^2 and u_i = min (max (q_i.x, q_i.y, q_i.z), 0).  Outside a box
+//           u_i = 0 and t_i = sqrt (s_i) >= 0; inside, s_i = 0 and t_i = u_i <= 0.  So min_i t_i = sqrt (min_i s_i) + min_i u_i:
+//           with a point inside some box the first term is sqrt (0) = 0 and the second the deepest box; otherwise the
+//           second is 0 and the first the nearest box -- the same formula as one box, the minima taken first.
+//           (A box whose q is all NaN gave 0 + min (NaN, 0) = 0 before and gives s = 0, u = 0 now.)
+// A lane's spheres may have several radii (ball_game: one of 1.0, ten of 0.2): a candidate whose radius differs from the
+// running one first FLUSHES the running minimum through its square root (behind a ballot: skipped by the wave when no
+// lane's radius changes -- never in simple_scene).  And the last root of either kind is culled like the brute-force scan's
+// (closest_primitive above): skipped by the wave when no lane's bound can still lower `closest`.
+#ifndef MDH_PART_MERGE_ROOTS
+#define MDH_PART_MERGE_ROOTS 1
+#endif
+MDH_DEV float walk_spheres_merged(unsigned w, const float4 *t, f3 x, float closest)
+{
+   float S = __builtin_inff(), r_cur = 0.0f;
+   while (w) {
+      MDH_DIAG_STEP(6);
+      const int p = __builtin_ctz(w);
+      w &= w - 1u;
+      const float4 a = t[p];
+      const float d2 = dot2(xyz(a) - x);
+      const bool other = __float_as_int(a.w) != __float_as_int(r_cur);
+      if ((__ballot(other) & __ballot(S < __builtin_inff())) != 0ull) { // (wave-uniform) some lane changes its radius: its minimum so far goes through the root
+         if (other) closest = min_raw(closest, sqrt_(S) - r_cur); // (S = inf: sqrt = inf, no change)
+      }
+      S = min_raw(other ? __builtin_inff() : S, d2);
+      r_cur = a.w; // (unchanged when !other)
+   }
+   const float tsum = closest + r_cur;
+   const bool need = !(tsum < 0.0f) && !(S > (tsum * tsum) * 1.000001f); // (closest_primitive's cull; S = inf: no candidate, never needed)
+   if (!MDH_CULL || __ballot(need) != 0ull) closest = min_raw(closest, sqrt_(S) - r_cur);
+   return closest;
+}
+MDH_DEV float walk_boxes_merged(unsigned w, const float4 *t, f3 x, float closest)
+{
+   float S = __builtin_inff(), U = 0.0f;
+   while (w) {
+      MDH_DIAG_STEP(6);
+      const int p = __builtin_ctz(w);
+      w &= w - 1u;
+      const float4 a = t[2 * p], b = t[2 * p + 1];
+      const f3 q = abs3(xyz(a) - x) - xyz(b); /* boxes.adb:10 */
+      S = min_raw(S, dot2(F3(max0_raw(q.x), max0_raw(q.y), max0_raw(q.z))));
+      U = min_raw(U, min0_raw(max_(q.x, max_(q.y, q.z))));
+   }
+   // sqrt (S) + U: U < 0 means S = 0 and the value is U itself; otherwise it is sqrt (S) >= 0, which cannot lower a negative
+   // `closest` and cannot lower a positive one when S > closest^2 (1 + 1e-6)
+   const bool need = !(U < 0.0f) && !(closest < 0.0f) && !(S > (closest * closest) * 1.000001f);
+   if (!MDH_CULL || __ballot(need) != 0ull) closest = min_raw(closest, sqrt_(S) + U);
+   else closest = min_raw(closest, U < 0.0f ? U : closest);
+   return closest;
+}
 template <int TYPE> MDH_DEV float walk_bits(unsigned w, const float4 *t, f3 x, float closest)
 {
+#if MDH_PART_MERGE_ROOTS
+   if (TYPE == PK_SPHERE) return walk_spheres_merged(w, t, x, closest);
+   if (TYPE == PK_BOX) return walk_boxes_merged(w, t, x, closest);
+#endif
    if (TYPE == PK_TRIANGLE) {
       while (w) { const int pi = __builtin_ctz(w); w &= w - 1u; closest = min_raw(closest, sd_triangle<false>(xyz(t[3 * pi]), xyz(t[3 * pi + 1]), xyz(t[3 * pi + 2]), x)); }
       return closest;

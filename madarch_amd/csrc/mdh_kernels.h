@@ -823,80 +823,110 @@ template <bool ADA_DIV> MDH_DEV float part_dist(const KScene &sc, int k, int i, 
    return prim_dist(type, slot, x);
 }
 
-// One lane per grid cell.  Update_Partitioning_CPU (renderers.adb:551-755) for methods
-// 0/1, partitioning_compute_grid_cell (scenes.adb:1120-1187) for method 2.
+// ONE WAVEFRONT PER GRID CELL (round 4; until round 3 one LANE per cell walked every loop below by itself, its candidate
+// arrays in 784 bytes of scratch memory: 0.49 ms for simple_scene's 2 000 cells on 32 wavefronts, every frame of ball_game).
+// Update_Partitioning_CPU (renderers.adb:551-755) for methods 0/1, partitioning_compute_grid_cell (scenes.adb:1120-1187)
+// for method 2.  The reference's loops are kept as SETS and ORDERS, not as schedules:
+//   * the closest primitive at the cell's centre: lanes = the instances of one kind at a time (a uniform type: no
+//     divergence), a wave minimum -- min is order-free;
+//   * the pre-candidates (closer than closest + the cell's diagonal) in scene order: ballot ranks, kind by kind;
+//   * CPU_Best's 27 sample points (Find_Candidates, renderers.adb:669-723): lane s = sample point s in the reference's
+//     loop order, the pre-candidates walked uniformly (LDS broadcasts) with the reference's strict `<` (the first of
+//     equal distances wins); the points then accept their winners in order, which numbers them as the reference does;
+//   * the lists, kind by kind in acceptance order, cut at Index_Count with one warning per overflowing kind
+//     (Write_Partitioning_Info, renderers.adb:578-608).
+MDH_DEV float wave_min(float v)
+{
+#pragma unroll
+   for (int o = 32; o > 0; o >>= 1) v = min_(v, __shfl_xor(v, o));
+   return v;
+}
 __global__ __launch_bounds__(64) void k_partition_build(KScene sc, PartBuildArgs a)
 {
+   __shared__ unsigned short s_pre[MDH_PART_MAX_PRE]; // (kind << 12) | index, in scene order
+   __shared__ unsigned char s_acc[MDH_PART_MAX_PRE];  // method 0: the candidate's acceptance number (0: not accepted)
+   __shared__ unsigned short s_ord[32];               // method 0: the candidate accepted as number s + 1
    stage_table(sc);
-   const int lin = blockIdx.x * 64 + threadIdx.x;
+   const int lin = blockIdx.x, lane = threadIdx.x;
    if (lin >= a.gx * a.gy * a.gz) return;
    const int X = lin / (a.gy * a.gz), Y = (lin / a.gz) % a.gy, Z = lin % a.gz;
    const int cell = X * a.gy * a.gz + Y * a.gz + Z;
    if (cell >= sc.part_cells) return;
    const f3 sp = F3(a.sp[0], a.sp[1], a.sp[2]), off = F3(a.off[0], a.off[1], a.off[2]);
    const int nk = hdr(H_NK);
-   unsigned short pre[MDH_PART_MAX_PRE]; // (kind << 12) | index
-   int npre = 0;
-   unsigned char accepted[MDH_PART_MAX_PRE];
+   int npre = 0, nacc = 0;
+   // every instance of every kind against `thr` at `center`, appended in scene order
+#define MDH_PART_COLLECT(ADA_, center_, thr_)                                                                                \
+   for (int k = 0; k < nk; ++k) {                                                                                           \
+      const int n = hdr(H_KCOUNT + k);                                                                                      \
+      for (int c = 0; c < n; c += 64) {                                                                                     \
+         const int i = c + lane;                                                                                            \
+         const bool in = i < n;                                                                                             \
+         const float d = part_dist<ADA_>(sc, k, in ? i : 0, center_);                                                       \
+         const bool take = in && d < (thr_);                                                                                \
+         const unsigned long long m = __ballot(take);                                                                       \
+         const int at = npre + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u)); \
+         if (take && at < MDH_PART_MAX_PRE) { s_pre[at] = (unsigned short)((k << 12) | i); s_acc[at] = 0; }                  \
+         npre = min(MDH_PART_MAX_PRE, npre + (int)__popcll(m));                                                             \
+      }                                                                                                                     \
+   }
    if (a.method == 2) {
       const f3 center = (F3((float)X, (float)Y, (float)Z) + F3s(0.5f)) * sp + off;
       const float thr = closest_primitive<true>(sc, center) + a.gpu_diag;
-      for (int k = 0; k < nk; ++k)
-         for (int i = 0; i < hdr(H_KCOUNT + k); ++i)
-            if (part_dist<false>(sc, k, i, center) < thr && npre < MDH_PART_MAX_PRE) { pre[npre] = (unsigned short)((k << 12) | i); accepted[npre++] = 1; }
+      MDH_PART_COLLECT(false, center, thr)
    } else {
       const f3 grid_pos = F3((float)X, (float)Y, (float)Z) * sp + off;
       const float cell_diag = length(sp);
       const f3 center = grid_pos + sp * 0.5f;
       float closest = 1.0e10f;
-      for (int k = 0; k < nk; ++k)
-         for (int i = 0; i < hdr(H_KCOUNT + k); ++i) closest = min_(closest, part_dist<true>(sc, k, i, center));
-      for (int k = 0; k < nk; ++k)
-         for (int i = 0; i < hdr(H_KCOUNT + k); ++i)
-            if (part_dist<true>(sc, k, i, center) < closest + cell_diag && npre < MDH_PART_MAX_PRE) { pre[npre] = (unsigned short)((k << 12) | i); accepted[npre++] = (a.method == 1); }
-      if (a.method == 0) { // Find_Candidates, renderers.adb:669-723: 3x3x3 sample points
-         // acceptance ORDER defines the order of a kind's indices: keep a sequence number
-         int seq = 0;
-         for (int sx = 1; sx <= 3; ++sx)
-            for (int sy = 1; sy <= 3; ++sy)
-               for (int sz = 1; sz <= 3; ++sz) {
-                  f3 offv = (F3((float)sx, (float)sy, (float)sz) - F3s(1.0f)) / (F3s(3.0f) - F3s(1.0f));
-                  f3 pt = offv * sp + grid_pos;
-                  float c = 1.0e10f;
-                  int ci = -1;
-                  for (int q = 0; q < npre; ++q) {
-                     float d = part_dist<true>(sc, pre[q] >> 12, pre[q] & 0xfff, pt);
-                     if (d < c) { c = d; ci = q; }
-                  }
-                  if (ci >= 0 && !accepted[ci]) accepted[ci] = (unsigned char)(++seq);
-               }
+      for (int k = 0; k < nk; ++k) {
+         const int n = hdr(H_KCOUNT + k);
+         for (int c = 0; c < n; c += 64)
+            if (c + lane < n) closest = min_(closest, part_dist<true>(sc, k, c + lane, center));
+      }
+      closest = wave_min(closest);
+      MDH_PART_COLLECT(true, center, closest + cell_diag)
+      if (a.method == 0) { // Find_Candidates, renderers.adb:669-723: 3x3x3 sample points, lane = point
+         const int sx = lane / 9 + 1, sy = (lane / 3) % 3 + 1, sz = lane % 3 + 1;
+         const f3 offv = (F3((float)sx, (float)sy, (float)sz) - F3s(1.0f)) / (F3s(3.0f) - F3s(1.0f));
+         const f3 pt = offv * sp + grid_pos;
+         float c = 1.0e10f;
+         int ci = -1;
+         for (int q = 0; q < npre; ++q) {
+            const int e = __builtin_amdgcn_readfirstlane((int)s_pre[q]);
+            const float d = part_dist<true>(sc, e >> 12, e & 0xfff, pt);
+            if (d < c) { c = d; ci = q; }
+         }
+         // acceptance ORDER defines the order of a kind's indices: the points accept in the reference's loop order
+         // (every lane keeps the same books: its own stores are what it reads back)
+         for (int s = 0; s < 27; ++s) {
+            const int q = __builtin_amdgcn_readlane(ci, s);
+            if (q >= 0 && s_acc[q] == 0) { s_ord[nacc] = (unsigned short)q; s_acc[q] = (unsigned char)(++nacc); }
+         }
       }
    }
+#undef MDH_PART_COLLECT
    // write counts and indices kind by kind (Write_Partitioning_Info, renderers.adb:578-608);
    // the reference only warns when a cell overflows Index_Count, here the list is cut
    int *rec = a.table + (size_t)cell * (nk + sc.part_index_count);
    int written = 0;
+   const int nlist = a.method == 0 ? nacc : npre; // the accepted candidates, in the order their kind's entries keep
    for (int k = 0; k < nk; ++k) {
       int n = 0;
-      if (a.method == 0) {
-         for (int s = 1; s <= 27; ++s)
-            for (int q = 0; q < npre; ++q)
-               if (accepted[q] == s && (pre[q] >> 12) == k) {
-                  if (written + n < sc.part_index_count) rec[nk + written + n] = pre[q] & 0xfff;
-                  ++n;
-               }
-      } else {
-         for (int q = 0; q < npre; ++q)
-            if (accepted[q] && (pre[q] >> 12) == k) {
-               if (written + n < sc.part_index_count) rec[nk + written + n] = pre[q] & 0xfff;
-               ++n;
-            }
+      for (int c = 0; c < nlist; c += 64) {
+         const int j = c + lane;
+         const int e = j < nlist ? (int)s_pre[a.method == 0 ? (int)s_ord[j] : j] : -1;
+         const bool mine = e >= 0 && (e >> 12) == k;
+         const unsigned long long m = __ballot(mine);
+         const int at = written + n + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+         if (mine && at < sc.part_index_count) rec[nk + at] = e & 0xfff;
+         n += (int)__popcll(m);
       }
       if (written + n > sc.part_index_count) {
-         atomicAdd(a.warnings, 1);
+         if (lane == 0) atomicAdd(a.warnings, 1);
          n = sc.part_index_count - written;
       }
-      rec[k] = n;
+      if (lane == 0) rec[k] = n;
       written += n;
    }
 }

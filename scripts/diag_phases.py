@@ -1,10 +1,14 @@
-"""Wall cycles per region of the pixel program (needs a -DMDH_PHASES build selected with MADARCH_HIP_LIBRARY)."""
+"""Wall cycles per region of the pixel program of a bench workload (needs a -DMDH_PHASES build selected with
+MADARCH_HIP_LIBRARY):  python scripts/diag_phases.py [workload]"""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from madarch_amd import examples, _binding as B
+import bench
+from madarch_amd import _binding as B
 hb = B.hip_binding()
-R = examples.global_illumination(1920, 1080, Probes=examples.GI_8X8X8_PROBES, Binding=hb)
+workload = sys.argv[1] if len(sys.argv) > 1 else "global_illumination_1080p_ddgi8x8x8"
+R = bench.make_renderer(workload, hb)
+print(workload)
 buf = (C.c_ulonglong * 16)()
 names = {0: "hit march (primary/reflection)", 1: "hit setup (sdf_info, primitive_info)", 2: "first step + light sampling + BRDF",
          3: "soft shadow march", 4: "probe corner setup", 5: "probe visibility march / queue", 6: "probe weights + atlas taps",

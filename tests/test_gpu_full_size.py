@@ -79,6 +79,45 @@ def test_c2_simple_scene_1080p_direct(hip, orc):
     assert len(np.unique(gb_g[0])) > 20  # planes, most spheres and boxes are in view
 
 
+def test_simple_scene_1080p_full(hip, orc):
+    """The reference's simple_scene AS IT RUNS (examples/simple_scene/main.adb:36-39,122 with the renderer's fixed screen
+    macros, madarch-renderers.adb:136-143): full pixel_color_probes -- direct specular, mode-2 indirect specular, 3
+    occlusion steps -- THROUGH the space partition (CPU_Best) with the default 36 probes (renderers.ads:23-29), at 1080p:
+    two frames of probe feedback, both atlases and the geometry buffer to the bit, the image within 1e-4."""
+    outs = []
+    for b in (hip, orc):
+        R = examples.simple_scene(1920, 1080, Binding=b)
+        R.Set_Option(B.OPT_GBUFFER, 1)
+        for _ in range(2):
+            R.Render()
+        outs.append((R.Read_Framebuffer(), R.Read_Gbuffer(), R.Read_Texture(B.TEX_RADIANCE), R.Read_Texture(B.TEX_IRRADIANCE),
+                     np.asarray(R.Read_Partitioning())))
+        R.Destroy()
+    (img_g, gb_g, rad_g, irr_g, part_g), (img_o, gb_o, rad_o, irr_o, part_o) = outs
+    assert same_bits(part_g, part_o)
+    assert same_bits(rad_g, rad_o), "radiance atlas"
+    assert same_bits(irr_g, irr_o), "irradiance atlas"
+    assert rad_o.max() > 0 and irr_o.max() > 0
+    assert_pixels(img_g, gb_g, img_o, gb_o)
+    assert len(np.unique(gb_g[0])) > 20
+
+
+def test_global_illumination_1080p_default_probes(hip, orc):
+    """global_illumination with the reference's OWN probe settings (4x3x3 probes as a 6x6 atlas, spacing (2, 3, 3):
+    madarch-renderers.ads:23-29; BASELINE config 3 names an 8x8x8 grid instead) at 1080p."""
+    outs = []
+    for b in (hip, orc):
+        R = examples.global_illumination(1920, 1080, Binding=b)
+        R.Set_Option(B.OPT_GBUFFER, 1)
+        for _ in range(2):
+            R.Render()
+        outs.append((R.Read_Framebuffer(), R.Read_Gbuffer(), R.Read_Texture(B.TEX_RADIANCE), R.Read_Texture(B.TEX_IRRADIANCE)))
+        R.Destroy()
+    (img_g, gb_g, rad_g, irr_g), (img_o, gb_o, rad_o, irr_o) = outs
+    assert same_bits(rad_g, rad_o) and same_bits(irr_g, irr_o)
+    assert_pixels(img_g, gb_g, img_o, gb_o)
+
+
 # ------------------------------------------------------------------------------------ C3
 @pytest.fixture(scope="module")
 def gi_oracle(orc):
