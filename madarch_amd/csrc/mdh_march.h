@@ -21,6 +21,9 @@
 #ifndef MDH_TAP_EARLY
 #define MDH_TAP_EARLY 1
 #endif
+#ifndef MDH_TAP_EARLY_PART
+#define MDH_TAP_EARLY_PART 0
+#endif
 #ifndef MDH_SKIP_NULL_RAYS
 #define MDH_SKIP_NULL_RAYS 1
 #endif
@@ -709,6 +712,9 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
    // per lane, the radiance kernel gains nothing): constant corner bits, no loop branch, the x-twin's terms at hand.
    constexpr int CORNER_UNROLL = ((PART & MDH_PF_PART) || SPEC != 1 || QVIS) ? 1 : MDH_CORNER_UNROLL;
    constexpr int PARK_MAT = MODE == 2 ? MDH_PARK_MAT_DIRECT : MDH_PARK_MAT; // (no probe rows in mode 2: MDH_DIRECT_PARK_ROWS)
+   // the irradiance tap of a cage corner issued before its visibility march (its loads land during the march) -- not in the
+   // space-partition variants, whose march needs the registers (MDH_TAP_EARLY_PART)
+   constexpr bool TAP_EARLY = MDH_TAP_EARLY != 0 && (MDH_TAP_EARLY_PART != 0 || !(PART & MDH_PF_PART));
    // the second point goes through the whole of pixel_color_probes' lighting (compute_indirect_specular) ...
    const bool full2 = SPEC == 2 && cfg.spec_mode == 3;
    // ... or is only a position that the cage probes of the FIRST point light (sample_radiance_with_specular)
@@ -910,16 +916,14 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
                      const float dist = length(hvec);
                      f3 vd = hvec / dist; // irrp: dir_to_probe, else: probe_to_spec
                      if (!irrp) vd = -vd; // the visibility ray always runs from the point to the probe
-#if MDH_TAP_EARLY
                      // the irradiance tap of this corner (render_probes.glsl:44-58) depends on the probe and
                      // N only: its texel loads go out now and land while the visibility ray is marched
                      AtlasTap tap;
-                     if (irrp) {
+                     if (TAP_EARLY && irrp) {
                         const f2 rid = parked ? park_load2<MDH_PARK_RIDN>(pk, wb) : rid_n;
                         const f2 base = probe_id_to_coord<P2>(pq, grid_to_probe_id<P2>(pq, q));
                         tap = atlas_tap_issue<P2>(pq.irr, pq.fmt, pq.pcx, pq.pcy, pq.ires, pq.ishift, pq.irr_w, pq.irr_h, base.x + div_pcx<P2>(pq, rid.x), base.y + div_pcy<P2>(pq, rid.y), pq.m_ires);
                      }
-#endif
                      // raycast_visibility, raymarching.glsl:39-56
                      float vis = 1.0f, total = 0.0f;
                      float vmax = dist - MDH_MIN_STEP * 5.0f;
@@ -967,12 +971,14 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
                         wpre = weight;
 #ifdef MDH_ABL_NO_TAPS
                         f3 tx = F3((float)q.x, (float)q.y, N.x);
-#elif MDH_TAP_EARLY
-                        f3 tx = atlas_tap_resolve(pq.irr, pq.fmt, tap, u8_tab);
 #else
-                        const f2 rid = rid_n;
-                        f2 base = probe_id_to_coord<P2>(pq, grid_to_probe_id<P2>(pq, q));
-                        f3 tx = atlas_sample<P2>(pq.irr, pq.fmt, pq.pcx, pq.pcy, pq.ires, pq.ishift, pq.irr_w, pq.irr_h, base.x + div_pcx<P2>(pq, rid.x), base.y + div_pcy<P2>(pq, rid.y), u8_tab, pq.m_ires);
+                        f3 tx;
+                        if (TAP_EARLY) tx = atlas_tap_resolve(pq.irr, pq.fmt, tap, u8_tab);
+                        else { // (the space-partition variants: the tap's eight registers do not live across the visibility march)
+                           const f2 rid = parked ? park_load2<MDH_PARK_RIDN>(pk, wb) : rid_n;
+                           const f2 base = probe_id_to_coord<P2>(pq, grid_to_probe_id<P2>(pq, q));
+                           tx = atlas_sample<P2>(pq.irr, pq.fmt, pq.pcx, pq.pcy, pq.ires, pq.ishift, pq.irr_w, pq.irr_h, base.x + div_pcx<P2>(pq, rid.x), base.y + div_pcy<P2>(pq, rid.y), u8_tab, pq.m_ires);
+                        }
 #endif
 #if MDH_TAP_SQRT_CORE
                         // A bilinear tap of an RGBA8 atlas is 0 or at least 2^-56: its texels are k / 255, its weights products of
