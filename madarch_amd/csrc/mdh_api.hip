@@ -278,6 +278,7 @@ struct mdh_renderer {
    // an open frame (mdh_frame_begin .. mdh_frame_end)
    bool in_frame = false, frame_pipelined = false;
    bool in_frame_passes = false; // run_pass is called for the passes that end an open frame (frame_end_passes)
+   bool fuse_scat_march = false; // the frame's visibility launch also marches the scattering texels' camera rays (k_visibility)
    int frame_cur = 0;
    int scr_parity = 0; // which screen stream / framebuffer the last pipelined frame drew on
    bool main_dirty = true; // work went to `stream` outside a pipelined frame since the probe stream last joined it
@@ -1639,7 +1640,7 @@ static int run_pass(mdh_renderer *r, int pass, hipStream_t st, int src, int dst,
       switch (pass) {
       case MDH_PASS_RADIANCE: snprintf(kname, sizeof kname, "k_radiance<%d, %s>", pf | (pow2 ? MDH_PF_POW2 : 0), rad_small_launch(r) ? "true" : "false"); break;
       case MDH_PASS_VISIBILITY: snprintf(kname, sizeof kname, "k_visibility<%d>", pf); break;
-      case MDH_PASS_SCATTERING: snprintf(kname, sizeof kname, "k_scattering<%d>", pf); break;
+      case MDH_PASS_SCATTERING: snprintf(kname, sizeof kname, MDH_SCAT_SPLIT ? "k_scat_march<%d>" : "k_scattering<%d>", pf); break;
       case MDH_PASS_SCREEN: {
          const bool alt = r->opt_mode == 0 && (r->opt_spec == 1 || r->opt_spec == 3 || (r->opt_spec == 2 && r->opt_mips));
          snprintf(kname, sizeof kname, "k_screen<%d, %d, %s, %s>", pf | (pow2 && r->opt_mode == 0 && !alt ? MDH_PF_POW2 : 0), r->opt_mode, r->opt_gbuffer ? "true" : "false", alt ? "true" : "false");
@@ -1766,13 +1767,21 @@ static int run_pass(mdh_renderer *r, int pass, hipStream_t st, int src, int dst,
       KVolumetrics vol = make_vol(r, true, dst);
       long n = (long)vol.vw * vol.vh * vol.vz;
       if (n > 0) {
+#if MDH_VIS_QUEUE
+         const long per_block = (long)MDH_BLOCK * MDH_VIS_ROUNDS; // every wavefront owns MDH_VIS_ROUNDS x 64 froxels (k_visibility)
+         int blocks = (int)((n + per_block - 1) / per_block);
+#else
          int blocks = (int)((n + MDH_BLOCK - 1) / MDH_BLOCK);
+#endif
+         // inside a frame the launch also marches the scattering texels' camera rays (k_visibility's second part, mdh_kernels.h)
+         const int vis_blocks = blocks;
+         if (MDH_SCAT_SPLIT && r->fuse_scat_march) blocks += (int)(((long)vol.sw * vol.sh + MDH_BLOCK - 1) / MDH_BLOCK);
          if (jit) {
-            struct { KScene sc; KVolumetrics vol; KCamera cam; } args = {r->ks, vol, cam};
+            struct { KScene sc; KVolumetrics vol; KCamera cam; int vis_blocks; } args = {r->ks, vol, cam, vis_blocks};
             int rc = jit_launch(jm->fn[kname], blocks, MDH_BLOCK, lds_bytes(r), st, args);
             if (rc != MDH_OK) return rc;
          } else
-            MDH_LAUNCH_PF(k_visibility, dim3(blocks), dim3(MDH_BLOCK), lds_bytes(r), r->ks, vol, cam);
+            MDH_LAUNCH_PF(k_visibility, dim3(blocks), dim3(MDH_BLOCK), lds_bytes(r), r->ks, vol, cam, vis_blocks);
       }
       break;
    }
@@ -1782,11 +1791,22 @@ static int run_pass(mdh_renderer *r, int pass, hipStream_t st, int src, int dst,
       if (n > 0) {
          int blocks = (int)((n + MDH_BLOCK - 1) / MDH_BLOCK);
          if (jit) {
-            struct { KScene sc; KVolumetrics vol; KCamera cam; } args = {r->ks, vol, cam};
-            int rc = jit_launch(jm->fn[kname], blocks, MDH_BLOCK, lds_bytes(r), st, args);
-            if (rc != MDH_OK) return rc;
+            if (!(MDH_SCAT_SPLIT && r->fuse_scat_march)) {
+               struct { KScene sc; KVolumetrics vol; KCamera cam; } args = {r->ks, vol, cam};
+               int rc = jit_launch(jm->fn[kname], blocks, MDH_BLOCK, lds_bytes(r), st, args);
+               if (rc != MDH_OK) return rc;
+            }
          } else
+#if MDH_SCAT_SPLIT
+            { if (!r->fuse_scat_march) MDH_LAUNCH_PF(k_scat_march, dim3(blocks), dim3(MDH_BLOCK), lds_bytes(r), r->ks, vol, cam); } // (inside a frame the visibility pass's launch has marched them)
+#else
             MDH_LAUNCH_PF(k_scattering, dim3(blocks), dim3(MDH_BLOCK), lds_bytes(r), r->ks, vol, cam);
+#endif
+#if MDH_SCAT_SPLIT
+         // the texels' lengths are in place: their steps, spread over lanes and folded in step order (k_scat_fold, mdh_kernels.h)
+         HIP_TRY(hipGetLastError());
+         hipLaunchKernelGGL(k_scat_fold, dim3((unsigned)((n + MDH_SCAT_TEXELS - 1) / MDH_SCAT_TEXELS)), dim3(MDH_SCAT_BLOCK), 0, st, vol);
+#endif
       }
       break;
    }
@@ -2033,8 +2053,11 @@ static int frame_end_passes(mdh_renderer *r)
    const int cur = r->frame_cur;
    if (!r->frame_pipelined) {
       if (r->opt_mode == 0 && r->vol.enabled) {
-         if ((rc = run_pass(r, MDH_PASS_VISIBILITY, r->stream, cur, cur)) != MDH_OK) return rc;
-         if ((rc = run_pass(r, MDH_PASS_SCATTERING, r->stream, cur, cur)) != MDH_OK) return rc;
+         r->fuse_scat_march = true; // (both passes follow each other: the first one's launch marches the second one's camera rays)
+         rc = run_pass(r, MDH_PASS_VISIBILITY, r->stream, cur, cur);
+         if (rc == MDH_OK) rc = run_pass(r, MDH_PASS_SCATTERING, r->stream, cur, cur);
+         r->fuse_scat_march = false;
+         if (rc != MDH_OK) return rc;
       }
       return run_pass(r, MDH_PASS_SCREEN, r->stream, cur, cur);
    }
@@ -2050,8 +2073,11 @@ static int frame_end_passes(mdh_renderer *r)
       // camera-only passes into this frame's set: on a stream of their own, beside this frame's probe
       // passes and the previous screen pass -- they are a few hundred wavefronts each and wait for nothing the probes make
       hipStream_t vs = MDH_VOL_OWN_STREAM && r->vol_stream ? r->vol_stream : r->probe_stream;
-      if ((rc = run_pass(r, MDH_PASS_VISIBILITY, vs, cur, cur)) != MDH_OK) return rc;
-      if ((rc = run_pass(r, MDH_PASS_SCATTERING, vs, cur, cur)) != MDH_OK) return rc;
+      r->fuse_scat_march = true;
+      rc = run_pass(r, MDH_PASS_VISIBILITY, vs, cur, cur);
+      if (rc == MDH_OK) rc = run_pass(r, MDH_PASS_SCATTERING, vs, cur, cur);
+      r->fuse_scat_march = false;
+      if (rc != MDH_OK) return rc;
       if (vs != r->probe_stream) {
          HIP_TRY(hipEventRecord(r->ev_vol[cur], vs));
          HIP_TRY(hipStreamWaitEvent(screen_stream, r->ev_vol[cur], 0));

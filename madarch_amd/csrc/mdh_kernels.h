@@ -718,15 +718,28 @@ __global__ __launch_bounds__(MDH_IRR_BLOCK) void k_irradiance(KProbes pr, const 
 }
 
 // -------------------------------------------------------------------- visibility pass
-// compute_frustrum_visibility.glsl:8-42: one froxel (x, y, depth slice) per lane
-template <int PART> __global__ __launch_bounds__(MDH_BLOCK) void k_visibility(KScene sc, KVolumetrics vol, KCamera cam)
+// compute_frustrum_visibility.glsl:8-42: one visibility ray per froxel (x, y, depth slice) and light.
+//
+// Round 4: the rays of a wavefront's froxels as a QUEUE WITH REPLACEMENT.  With one froxel per lane in lock step (the form
+// until round 3, kept as MDH_VIS_QUEUE = 0 and in the literal build) a wavefront marched until its longest ray ended:
+// 34 of 64 lanes alive per step (r03_c4_*), half of them blocked within a step or two while their neighbours cross the room.
+// Here a wavefront owns MDH_VIS_ROUNDS x 64 consecutive froxels (in the same 8x8-tile order) and a lane whose ray has ended
+// is SERVED -- its light's term added, the next light started, or the texel stored and the next froxel of the batch taken --
+// as soon as MDH_VIS_REFILL lanes wait (or nobody marches).  Every froxel's arithmetic is what it was, operation for
+// operation: WHICH lane computes a texel and WHEN changes, nothing else.
+#ifndef MDH_VIS_QUEUE
+#define MDH_VIS_QUEUE 0 // (measured on MI355X, light_shafts 1080p: the pass 0.067 -> 0.109 ms on its own and -1.5 % in flight --
+                        //  serving a lane is ~250 instructions under a sparse mask, as much as its march saves: DESIGN.md, dropped)
+#endif
+#ifndef MDH_VIS_ROUNDS
+#define MDH_VIS_ROUNDS 4
+#endif
+#ifndef MDH_VIS_REFILL
+#define MDH_VIS_REFILL 16
+#endif
+// the froxel texel (i, j) at place `lin` of the launch: 8x8 tiles when the sizes allow it, so a wave's rays are neighbours on the image plane
+MDH_DEV void froxel_texel(int W, int H, long lin, int &i, int &j)
 {
-   stage_table(sc);
-   const int W = vol.vw, H = vol.vh * vol.vz;
-   const long lin = (long)blockIdx.x * MDH_BLOCK + threadIdx.x;
-   if (lin >= (long)W * H) return;
-   // 8x8 tiles when the width allows it, so a wave's rays are neighbours on the image plane
-   int i, j;
    if ((W & 7) == 0 && (H & 7) == 0) {
       const long tile = lin >> 6;
       const int l = (int)(lin & 63), tpr = W >> 3;
@@ -736,15 +749,127 @@ template <int PART> __global__ __launch_bounds__(MDH_BLOCK) void k_visibility(KS
       j = (int)(lin / W);
       i = (int)(lin - (long)j * W);
    }
+}
+// its sample point and the direction of its camera ray (compute_frustrum_visibility.glsl:22-37)
+MDH_DEV void froxel_point(const KVolumetrics &vol, const KCamera &cam, int W, int H, int i, int j, f3 &pos, f3 &dir)
+{
    const float px = centre(i, W), py = centre(j, H);
    const float norm_height = (py + 1.0f) * 0.5f;
    const float tex_height = norm_height * (float)vol.vz;
    const float depth = __builtin_floorf(tex_height);
    const float fract_height = tex_height - depth;
    const float frag_height = fract_height * 2.0f - 1.0f;
-   f3 origin, dir;
+   f3 origin;
    camera_ray(cam, px, frag_height, origin, dir);
-   const f3 pos = origin + (dir * depth) * vol.vstep;
+   pos = origin + (dir * depth) * vol.vstep;
+}
+// the texel's ray length: raycast (raymarching.glsl:25-37) without the arg-min -- only the collision point is used here
+template <int PART> MDH_DEV float scattering_length(const KScene &sc, const KVolumetrics &vol, const KCamera &cam, int i, int j)
+{
+   const float px = centre(i, vol.sw), py = centre(j, vol.sh);
+   f3 from, dir;
+   camera_ray(cam, px, py, from, dir);
+   const float max_depth = vol.vstep * (float)vol.vz; // volumetrics.glsl:3-4
+   f3 to = from + dir * max_depth;
+   int steps;
+   float t;
+   if (march_plain<PART>(sc, from, dir, sc.max_dist, t, steps)) to = from + dir * t;
+   return min_(length(to - from), max_depth);
+}
+// `vis_blocks`: the workgroups of the launch that work on froxels; the ones behind them march the camera rays of the
+// SCATTERING texels (k_scat_march's work: the texels' lengths, which depend on the camera and the scene only).  That march is
+// a thousand wavefronts whose longest ray alone takes 40 us: inside this launch it hides under the froxels' rays (frames
+// only: a single visibility pass leaves the scattering texture alone, run_pass).
+template <int PART> __global__ __launch_bounds__(MDH_BLOCK) void k_visibility(KScene sc, KVolumetrics vol, KCamera cam, int vis_blocks)
+{
+   stage_table(sc);
+   if ((int)blockIdx.x >= vis_blocks) { // (workgroup-uniform)
+      const long lin = (long)((int)blockIdx.x - vis_blocks) * MDH_BLOCK + threadIdx.x;
+      if (lin >= (long)vol.sw * vol.sh) return;
+      const int j = (int)(lin / vol.sw), i = (int)(lin - (long)j * vol.sw);
+      vol.scat[(size_t)j * vol.sw + i].w = scattering_length<PART>(sc, vol, cam, i, j);
+      return;
+   }
+   const int W = vol.vw, H = vol.vh * vol.vz;
+   const long n = (long)W * H;
+#if MDH_VIS_QUEUE
+   const long wave_global = (long)blockIdx.x * (MDH_BLOCK / 64) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+   const long begin = wave_global * (64 * MDH_VIS_ROUNDS);
+   if (begin >= n) return; // (wave-uniform)
+   const long end = min(n, begin + 64 * MDH_VIS_ROUNDS);
+   long next = begin; // (wave-uniform) the first froxel of the batch nobody has taken
+   // a lane's froxel (lin < 0: none), its light, its ray
+   long lin = -1;
+   int light = 0;
+   bool marching = false;
+   float vis = 0.0f, total = 0.0f, L_dist = 0.0f;
+   f3 pos = F3(0.0f, 0.0f, 0.0f), dir = pos, L = pos, radiance = pos, result = pos;
+   for (;;) {
+      const unsigned long long mm = __ballot(marching);
+      const bool waiting = !marching && (lin >= 0 || next < end); // a ray that has ended, or an empty lane while froxels are left
+      const unsigned long long wm = __ballot(waiting);
+      if (mm == 0ull && wm == 0ull) break;
+      if (mm == 0ull || __popcll(wm) >= MDH_VIS_REFILL) {
+         if (waiting) {
+            if (lin >= 0) { // sample_lights :8-19: the ended ray's term, in light order
+               const f3 L_in = radiance * (exp_(-L_dist * MDH_TAU) * vis);
+               result = result + (L_in * MDH_TAU) * henvey_greenstein_phase(L, dir);
+               ++light;
+            }
+            if (lin >= 0 && light >= sc.total_lights) {
+               int i, j;
+               froxel_texel(W, H, lin, i, j);
+               float *o = vol.vis + ((size_t)j * W + i) * 3;
+               o[0] = result.x; o[1] = result.y; o[2] = result.z;
+               lin = -1;
+            }
+         }
+         { // empty lanes take the next froxels of the batch, in lane order
+            const bool empty = waiting && lin < 0;
+            const unsigned long long em = __ballot(empty);
+            if (empty) {
+               const long mine = next + (long)__builtin_amdgcn_mbcnt_hi((unsigned)(em >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)em, 0u));
+               if (mine < end) {
+                  lin = mine;
+                  int i, j;
+                  froxel_texel(W, H, lin, i, j);
+                  froxel_point(vol, cam, W, H, i, j, pos, dir);
+                  result = F3(0.0f, 0.0f, 0.0f);
+                  light = 0;
+                  if (sc.total_lights <= 0) { // no light: the texel is 0
+                     float *o = vol.vis + ((size_t)j * W + i) * 3;
+                     o[0] = 0.0f; o[1] = 0.0f; o[2] = 0.0f;
+                     lin = -1;
+                  }
+               }
+            }
+            next = min(end, next + (long)__popcll(em));
+         }
+         if (waiting && lin >= 0) { // the next light's ray (raycast_visibility, raymarching.glsl:39-56, from its first test on)
+            radiance = sample_light<(PART & MDH_PF_CUSTOM) != 0>(sc, light, pos, F3(1.0f, 0.0f, 0.0f), L, L_dist); // compute_frustrum_visibility.glsl:12
+            MDH_WORK(0);
+            total = 0.0f;
+            vis = 1.0f;
+            marching = total < L_dist; // (a loop that is never entered: visible)
+         }
+      }
+      if (marching) {
+         MDH_WORK(1);
+         const float dist = sdf<PART>(sc, pos + L * total);
+         if (dist < MDH_EPS) { vis = 0.0f; marching = false; }
+         else {
+            total += dist;
+            if (!(total < L_dist)) marching = false;
+         }
+      }
+   }
+#else
+   const long lin = (long)blockIdx.x * MDH_BLOCK + threadIdx.x;
+   if (lin >= n) return;
+   int i, j;
+   froxel_texel(W, H, lin, i, j);
+   f3 pos, dir;
+   froxel_point(vol, cam, W, H, i, j, pos, dir);
    f3 result = F3(0.0f, 0.0f, 0.0f);
    for (int l = 0; l < sc.total_lights; ++l) { // sample_lights :8-19
       f3 L;
@@ -756,10 +881,122 @@ template <int PART> __global__ __launch_bounds__(MDH_BLOCK) void k_visibility(KS
    }
    float *o = vol.vis + ((size_t)j * W + i) * 3;
    o[0] = result.x; o[1] = result.y; o[2] = result.z;
+#endif
 }
 
 // -------------------------------------------------------------------- scattering pass
-// accumulate_scattering.glsl:9-48
+// accumulate_scattering.glsl:9-48.  Round 4: two kernels.
+//   k_scat_march  one lane per scattering texel: the camera ray's collision point -> len (the texel's fourth component)
+//   k_scat_fold   a texel's steps SPREAD OVER LANES.  Until round 3 one lane walked its texel's <= 100 froxel taps by itself
+//                 (batches of 8 in flight): 980 wavefronts on 1 024 SIMDs, 142 VGPRs, 10.8 % of the VALU issue peak.  A step's
+//                 tap and its exp (-f tau) factor depend on the texel and the step only, and f runs through the same values
+//                 for every texel (f_0 = 0, f_k+1 = f_k + step in fp32): a workgroup takes MDH_SCAT_TEXELS texels, computes
+//                 f_k, floor (f_k / froxel step) and exp (-f_k tau) once per step into LDS, then every (texel, step) pair's
+//                 product tap * factor -- one lane each, all in flight together -- and finally one lane per texel and CHANNEL
+//                 adds its products IN STEP ORDER (the same additions in the same order: the same bits).
+#ifndef MDH_SCAT_SPLIT
+#define MDH_SCAT_SPLIT 1
+#endif
+#ifndef MDH_SCAT_TEXELS
+#define MDH_SCAT_TEXELS 16 // texels per workgroup of k_scat_fold (a power of two, at most 64)
+#endif
+#ifndef MDH_SCAT_CHUNK
+#define MDH_SCAT_CHUNK 128 // steps whose products are in LDS together (16 texels x 128 steps x 12 B = 24 KB)
+#endif
+#ifndef MDH_SCAT_BLOCK
+#define MDH_SCAT_BLOCK 256 // threads of k_scat_fold (measured 1 024: two workgroups per CU, the pass 0.045 -> 0.172 ms)
+#endif
+template <int PART> __global__ __launch_bounds__(MDH_BLOCK) void k_scat_march(KScene sc, KVolumetrics vol, KCamera cam)
+{
+   stage_table(sc);
+   const int W = vol.sw, H = vol.sh;
+   const long lin = (long)blockIdx.x * MDH_BLOCK + threadIdx.x;
+   if (lin >= (long)W * H) return;
+   const int j = (int)(lin / W), i = (int)(lin - (long)j * W);
+   vol.scat[(size_t)j * W + i].w = scattering_length<PART>(sc, vol, cam, i, j);
+}
+#ifndef MDH_JIT
+__global__ __launch_bounds__(MDH_SCAT_BLOCK) void k_scat_fold(KVolumetrics vol)
+{
+   constexpr int T = MDH_SCAT_TEXELS, CH = MDH_SCAT_CHUNK;
+   __shared__ float s_f[CH], s_rel[CH], s_e[CH]; // per step of the chunk: f, floor (f / froxel step), exp (-f tau)
+   __shared__ float s_len[T];
+   __shared__ int s_n[T];                        // steps of each texel: the k with f_k < len
+   __shared__ float s_prod[CH][3][T];
+   const int W = vol.sw, H = vol.sh, tid = threadIdx.x;
+   const long first = (long)blockIdx.x * T, n_tex = (long)W * H;
+   const float max_depth = vol.vstep * (float)vol.vz;
+   if (tid < T) {
+      const long lin = first + tid;
+      s_len[tid] = lin < n_tex ? vol.scat[lin].w : 0.0f; // (k_scat_march)
+      s_n[tid] = 0;
+   }
+   // lanes of the fold: channel c of texel t
+   const int fc = tid / T, ft = tid % T;
+   const bool folder = tid < 3 * T && first + ft < n_tex;
+   float acc = 0.0f;
+   for (int c0 = 0;; c0 += CH) {
+      // the chunk's steps: f by the loop's own additions (every texel's loop runs through these values)
+      if (tid < T) s_n[tid] = 0; // (steps of this chunk: set by the pair that holds the texel's last one)
+      if (tid < CH) {
+         float f = 0.0f;
+         for (int q = 0; q < c0 + tid; ++q) f += vol.sstep;
+         s_f[tid] = f;
+         s_rel[tid] = __builtin_floorf(f / vol.vstep); // sample_visibility :9-15
+         s_e[tid] = exp_(-f * MDH_TAU);
+      }
+      __syncthreads();
+      if (!(s_f[0] < max_depth)) break; // (len <= max_depth: no texel has a step here; uniform)
+      // (texel, step) pairs: the tap and its factor, one lane each -- four pairs per lane and turn, their 48 texel loads all in
+      // flight together (pairs without a step -- f past the texel's length, a texel past the image -- load nothing: sampled
+      // all the same, as the one-kernel form did, they double the pass's loads and it takes 0.066 instead of 0.045 ms)
+      for (int p0 = tid; p0 < T * CH; p0 += 4 * MDH_SCAT_BLOCK) {
+         float tx[4][3];
+         bool live[4];
+#pragma unroll
+         for (int u = 0; u < 4; ++u) {
+            const int p = p0 + u * MDH_SCAT_BLOCK;
+            const int t = p % T, k = min(p / T, CH - 1);
+            const long lin = min(first + t, n_tex - 1);
+            live[u] = p < T * CH && first + t < n_tex && s_f[k] < s_len[t];
+            tx[u][0] = tx[u][1] = tx[u][2] = 0.0f;
+            if (live[u]) {
+               const int j = (int)(lin / W), i = (int)(lin - (long)j * W);
+               const f2 norm_pos = F2(0.5f * (centre(i, W) + 1.0f), 0.5f * (centre(j, H) + 1.0f));
+               tex_sample<3>(vol.vis, vol.vw, vol.vh * vol.vz, norm_pos.x, (norm_pos.y + s_rel[k]) / (float)vol.vz, tx[u]);
+               // (the last of the texel's steps in this chunk says how many there are: f grows, the steps are a prefix)
+               if (k + 1 == CH || !(s_f[k + 1] < s_len[t])) s_n[t] = k + 1;
+            }
+         }
+#pragma unroll
+         for (int u = 0; u < 4; ++u) {
+            const int p = p0 + u * MDH_SCAT_BLOCK;
+            const int t = p % T, k = min(p / T, CH - 1);
+            if (live[u]) {
+               const f3 pr = F3(tx[u][0], tx[u][1], tx[u][2]) * s_e[k];
+               s_prod[k][0][t] = pr.x; s_prod[k][1][t] = pr.y; s_prod[k][2][t] = pr.z;
+            }
+         }
+      }
+      __syncthreads();
+      if (folder) { // L = L + tap * factor, step by step (eight products on their way from LDS at a time)
+         const int m = s_n[ft];
+         int k = 0;
+         for (; k + 8 <= m; k += 8) {
+            float v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = s_prod[k + q][fc][ft];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc = acc + v[q];
+         }
+         for (; k < m; ++k) acc = acc + s_prod[k][fc][ft];
+      }
+      if (!__syncthreads_or(tid < T && s_n[tid] == CH)) break; // some texel filled the chunk: its loop goes on
+   }
+   if (folder) ((float *)&vol.scat[first + ft])[fc] = acc * vol.sstep;
+}
+#endif
+// (the one-kernel form of rounds 1 to 3: MDH_SCAT_SPLIT = 0 and the literal build)
 template <int PART> __global__ __launch_bounds__(MDH_BLOCK) void k_scattering(KScene sc, KVolumetrics vol, KCamera cam)
 {
    stage_table(sc);
@@ -768,16 +1005,8 @@ template <int PART> __global__ __launch_bounds__(MDH_BLOCK) void k_scattering(KS
    if (lin >= (long)W * H) return;
    const int j = (int)(lin / W), i = (int)(lin - (long)j * W);
    const float px = centre(i, W), py = centre(j, H);
-   f3 from, dir;
-   camera_ray(cam, px, py, from, dir);
    const f2 norm_pos = F2(0.5f * (px + 1.0f), 0.5f * (py + 1.0f));
-   const float max_depth = vol.vstep * (float)vol.vz; // volumetrics.glsl:3-4
-   f3 to = from + dir * max_depth;
-   int steps;
-   float t;
-   // raycast (raymarching.glsl:25-37) without the arg-min: only the collision point is used here
-   if (march_plain<PART>(sc, from, dir, sc.max_dist, t, steps)) to = from + dir * t;
-   const float len = min_(length(to - from), max_depth);
+   const float len = scattering_length<PART>(sc, vol, cam, i, j);
    f3 L = F3(0.0f, 0.0f, 0.0f);
    // The froxel taps of consecutive steps are independent, but each costs a trip to L2/HBM and the
    // pass has one wavefront per SIMD: steps go in batches of MDH_SCAT_BATCH whose loads are all in
