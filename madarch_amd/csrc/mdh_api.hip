@@ -1751,6 +1751,8 @@ static int run_pass(mdh_renderer *r, int pass, hipStream_t st, int src, int dst,
       if (pr.ires * pr.ires <= 64) lds += (size_t)4 * 64 * sizeof(float4); // (the experiment's fold: all taps staged, four partial sums per texel)
       else
 #endif
+      if (MDH_IRR_WPRE && pr.ires * pr.ires <= 64 && MDH_IRR_BLOCK == 256) lds = MDH_IRR_WPRE_LDS; // (k_irradiance: the weights' pipeline)
+      else
       if (MDH_IRR_CHUNK && pr.ires * pr.ires <= 64 && lds > (size_t)4 * MDH_IRR_CHUNK * sizeof(float4)) lds = (size_t)4 * MDH_IRR_CHUNK * sizeof(float4); // two chunk buffers
       if (lds > 64 * 1024) { // radiance tiles beyond 45 x 45 texels: up to the whole 160 KiB of a CU (70 x 70)
          if (lds > 160 * 1024) return seterr(MDH_E_INVALID, "radiance resolution too large for the irradiance pass (160 KiB of LDS: at most 70)");

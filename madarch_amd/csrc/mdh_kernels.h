@@ -534,6 +534,21 @@ __global__ __launch_bounds__(256) void k_order_floor(unsigned char *keys, int n,
 #ifndef MDH_IRR_CHUNK
 #define MDH_IRR_CHUNK 256 // taps per LDS buffer when one wavefront folds (0 = all taps staged at once)
 #endif
+#ifndef MDH_IRR_WPRE
+// the taps' weights computed by the wavefronts beside the folding one (k_irradiance, round 4: VERDICT r03 item 3).  Built, bit-exact,
+// and NOT faster: 0.0368 - 0.0417 ms against 0.0370 (profiles/r04_x_irradiance_weights_pipeline.log) -- the folding
+// wavefront needs 74 cycles per tap for two LDS reads and seven plain fp32 operations just as it needed them for two reads and
+// thirteen operations; a lone workgroup takes 30 us whatever its instruction count.  Off.
+#define MDH_IRR_WPRE 0
+#endif
+#ifndef MDH_IRR_ABL
+#define MDH_IRR_ABL 0 // (timing experiments only: 1 no fold, 2 no tap evaluation, 3 no weights -- wrong results)
+#endif
+#ifndef MDH_IRR_WCHUNK
+#define MDH_IRR_WCHUNK 64 // taps per pipeline stage of that form (at most 64: one wavefront evaluates a chunk's taps)
+#endif
+// LDS of that form: three radiance and two direction buffers of a chunk's taps, two buffers of its weights for 64 texels
+#define MDH_IRR_WPRE_LDS ((size_t)5 * MDH_IRR_WCHUNK * sizeof(float4) + (size_t)2 * MDH_IRR_WCHUNK * 64 * sizeof(float))
 typedef float pk2 __attribute__((ext_vector_type(2))); // two fp32 per VALU instruction (v_pk_mul_f32 / v_pk_add_f32: IEEE per component)
 // `prev`, `hyst`: MDH_OPT_HYSTERESIS_PERMILLE (not in the reference; 0 = off): the texel is stored as
 // mix (fresh, what the previous frame's atlas holds, hyst)
@@ -590,6 +605,155 @@ __global__ __launch_bounds__(MDH_IRR_BLOCK) void k_irradiance(KProbes pr, const 
          const float4 a = part[lane], b = part[64 + lane], c = part[128 + lane], d = part[192 + lane];
          const f3 sum = F3((a.x + b.x) + (c.x + d.x), (a.y + b.y) + (c.y + d.y), (a.z + b.z) + (c.z + d.z));
          const f3 irradiance = sum / ((a.w + b.w) + (c.w + d.w));
+         const unsigned idx = atlas_index(pr.pcx, pr.ires, pr.ishift, i, j);
+         atlas_store(pr.irr, pr.fmt, idx, irradiance_blend(pr, prev, hyst, idx, irradiance));
+      }
+      return;
+   }
+#endif
+#if MDH_IRR_WPRE
+   if (pr.ires * pr.ires <= 64 && MDH_IRR_BLOCK == 256) {
+      // Round 4: the weights off the fold's critical path.  A tap's weight for a texel, w = max (dot (irr_dir, rad_dir), 0), is
+      // five instructions of the fold's thirteen and depends on nothing the fold produces: the wavefronts that used to wait for
+      // the folding one compute it, a lane per texel, into LDS.  Chunks of 64 taps run through a three-stage pipeline, one
+      // barrier per chunk:      wavefront 1     evaluates the taps of chunk c + 2 (bilinear fetch, octahedral decode: one lane per tap)
+      //                         wavefronts 2, 3 the weights of chunk c + 1 for all 64 texels (tap by tap, LDS broadcast reads)
+      //                         wavefront 0     folds chunk c: per tap one per-lane weight, one broadcast radiance, two v_pk_mul
+      //                                         and two v_pk_add -- the reference's additions in the reference's order
+      // -- about 380 issue slots per chunk on every wavefront instead of 1 000 on the folding one.
+      constexpr int CH = MDH_IRR_WCHUNK;
+      float4 *s_rad = s_taps;                      // [3][CH] {rad.xyz, 1}
+      float4 *s_dir = s_taps + 3 * CH;             // [2][CH] {dir.xyz, -}
+      float *s_w = (float *)(s_taps + 5 * CH);     // [2][CH][64]
+      const int nchunks = (ntaps + CH - 1) / CH;
+      const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+      const int ntex = pr.ires * pr.ires;
+      const int x = lane % pr.ires, y = lane / pr.ires; // (a lane's texel, in the weight and fold wavefronts)
+      const int i = tx * pr.ires + x, j = ty * pr.ires + y;
+      const f2 nc = F2((centre(i, pr.pcx * pr.ires) + 1.0f) * 0.5f, (centre(j, pr.pcy * pr.ires) + 1.0f) * 0.5f);
+      const f3 irr_dir = ray_id_to_ray_dir(F2(fract_(nc.x * pcx), fract_(nc.y * pcy)));
+      float acc_x = 0.0f, acc_y = 0.0f, acc_z = 0.0f, acc_w = 0.0f;
+#define MDH_IRR_TAP_COORD(tap_, cc_)                                                                                     \
+      const int yy_ = (tap_) / pr.rres, xx_ = (tap_) - yy_ * pr.rres;                                                    \
+      const f2 cc_ = F2(clamp_(rad_coord.x + (float)xx_ * step.x, step.x, 1.0f - step.x), clamp_(rad_coord.y + (float)yy_ * step.y, step.y, 1.0f - step.y))
+#define MDH_IRR_TAP_STORE(rad_, cc_, c_, slot_)                                                                          \
+      do {                                                                                                               \
+         const f3 rad_dir_ = ray_id_to_ray_dir(F2(fract_((cc_).x * pcx), fract_((cc_).y * pcy)));                         \
+         s_rad[((c_) % 3) * CH + (slot_)] = make_float4((rad_).x, (rad_).y, (rad_).z, 1.0f);                              \
+         s_dir[((c_) & 1) * CH + (slot_)] = make_float4(rad_dir_.x, rad_dir_.y, rad_dir_.z, 0.0f);                        \
+      } while (0)
+      // the weights of chunk c_: taps t0, t0 + stride, ... of it, eight directions on their way from LDS at a time
+#define MDH_IRR_WEIGHTS(c_, t0_, stride_)                                                                                 \
+      do {                                                                                                               \
+         const int nh_ = min(CH, ntaps - (c_) * CH);                                                                      \
+         const float4 *db_ = s_dir + ((c_) & 1) * CH;                                                                     \
+         float *wb_ = s_w + ((c_) & 1) * CH * 64 + lane;                                                                  \
+         if (lane < ntex) {                                                                                              \
+            int t = (t0_);                                                                                               \
+            _Pragma("unroll 1") for (; t + 7 * (stride_) < nh_; t += 8 * (stride_)) {                                      \
+               float4 d8[8];                                                                                             \
+               _Pragma("unroll") for (int q = 0; q < 8; ++q) d8[q] = db_[t + q * (stride_)];                              \
+               _Pragma("unroll") for (int q = 0; q < 8; ++q)                                                              \
+                  wb_[(t + q * (stride_)) * 64] = max_((irr_dir.x * d8[q].x + irr_dir.y * d8[q].y) + irr_dir.z * d8[q].z, 0.0f); \
+            }                                                                                                            \
+            for (; t < nh_; t += (stride_)) {                                                                             \
+               const float4 d = db_[t];                                                                                  \
+               wb_[t * 64] = max_((irr_dir.x * d.x + irr_dir.y * d.y) + irr_dir.z * d.z, 0.0f);                           \
+            }                                                                                                            \
+         }                                                                                                               \
+      } while (0)
+      // (LDS only: a wavefront's loads from the atlas stay in flight across it -- __syncthreads would wait for them)
+#define MDH_IRR_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+      // prologue: the taps of chunks 0 and 1 (all wavefronts); wavefront 1 asks for the texels of chunk 2; the weights of chunk 0
+      for (int t = threadIdx.x; t < min(2 * CH, ntaps); t += MDH_IRR_BLOCK) {
+         MDH_IRR_TAP_COORD(t, cc);
+         const f3 rad = atlas_sample(pr.rad, pr.fmt, pr.pcx, pr.pcy, pr.rres, pr.rshift, pr.rad_w, pr.rad_h, cc.x, cc.y, -1);
+         MDH_IRR_TAP_STORE(rad, cc, t / CH, t % CH);
+      }
+      __syncthreads();
+      AtlasTap tap_next;
+      tap_next.t00 = tap_next.t10 = tap_next.t01 = tap_next.t11 = 0u; tap_next.fx = tap_next.fy = 0.0f;
+      if (wv == 1 && 2 * CH + lane < ntaps && lane < CH) {
+         MDH_IRR_TAP_COORD(2 * CH + lane, cc);
+         tap_next = atlas_tap_issue(pr.rad, pr.fmt, pr.pcx, pr.pcy, pr.rres, pr.rshift, pr.rad_w, pr.rad_h, cc.x, cc.y);
+      }
+      MDH_IRR_WEIGHTS(0, wv, 4);
+      MDH_IRR_BARRIER();
+#ifdef MDH_PHASES
+      unsigned long long ph_work = 0ull, ph_wait = 0ull; // (diagnostic: cycles of this wavefront in its stage and at the barrier)
+#endif
+      for (int c = 0; c < nchunks; ++c) {
+#ifdef MDH_PHASES
+         const unsigned long long ph_t0 = __builtin_amdgcn_s_memtime();
+#endif
+         if (wv == 0) {
+#if MDH_IRR_ABL != 1
+            if (lane < ntex) {
+               const int nh = min(CH, ntaps - c * CH);
+               const float4 *rb = s_rad + (c % 3) * CH;
+               const float *wb = s_w + (c & 1) * CH * 64 + lane;
+               int t = 0;
+               // groups of four taps, two groups in flight: while one is added the next one is on its way from LDS (registers
+               // A and B alternate: no copies)
+#define MDH_IRR_LOAD4(R_, W_, t_) _Pragma("unroll") for (int q = 0; q < 4; ++q) { R_[q] = rb[(t_) + q]; W_[q] = wb[((t_) + q) * 64]; }
+#define MDH_IRR_ADD4(R_, W_) _Pragma("unroll") for (int q = 0; q < 4; ++q) { acc_x = acc_x + R_[q].x * W_[q]; acc_y = acc_y + R_[q].y * W_[q]; acc_z = acc_z + R_[q].z * W_[q]; acc_w = acc_w + R_[q].w * W_[q]; }
+               // (plain fp32 operations, and the tap's fourth component is 1: 1 * w = w)
+               if (nh >= 8) {
+                  float4 ra[4], rb4[4];
+                  float wa[4], wb4[4];
+                  MDH_IRR_LOAD4(ra, wa, 0)
+#pragma unroll 1
+                  for (; t + 8 <= nh; t += 8) {
+                     MDH_IRR_LOAD4(rb4, wb4, t + 4)
+                     MDH_IRR_ADD4(ra, wa)
+                     if (t + 12 <= nh) { MDH_IRR_LOAD4(ra, wa, t + 8) }
+                     MDH_IRR_ADD4(rb4, wb4)
+                  }
+                  if (t + 4 <= nh) { MDH_IRR_ADD4(ra, wa) t += 4; } // (a last group of four already loaded)
+               }
+#undef MDH_IRR_LOAD4
+#undef MDH_IRR_ADD4
+               for (; t < nh; ++t) {
+                  const float4 r = rb[t];
+                  const float w = wb[t * 64];
+                  acc_x = acc_x + r.x * w; acc_y = acc_y + r.y * w; acc_z = acc_z + r.z * w;
+                  acc_w = acc_w + w;
+               }
+            }
+#endif
+         } else if (wv == 1) { // the taps of chunk c + 2 from the texels asked for one chunk ago; then the texels of chunk c + 3
+            if (lane < CH && MDH_IRR_ABL != 2) {
+               const int tap = (c + 2) * CH + lane;
+               if (c + 2 < nchunks && tap < ntaps) {
+                  MDH_IRR_TAP_COORD(tap, cc);
+                  const f3 rad = atlas_tap_resolve(pr.rad, pr.fmt, tap_next, -1);
+                  MDH_IRR_TAP_STORE(rad, cc, c + 2, lane);
+               }
+               const int tap3 = (c + 3) * CH + lane;
+               if (c + 3 < nchunks && tap3 < ntaps) {
+                  MDH_IRR_TAP_COORD(tap3, cc);
+                  tap_next = atlas_tap_issue(pr.rad, pr.fmt, pr.pcx, pr.pcy, pr.rres, pr.rshift, pr.rad_w, pr.rad_h, cc.x, cc.y);
+               }
+            }
+         } else if (c + 1 < nchunks && MDH_IRR_ABL != 3)
+            MDH_IRR_WEIGHTS(c + 1, wv - 2, 2);
+#ifdef MDH_PHASES
+         const unsigned long long ph_t1 = __builtin_amdgcn_s_memtime();
+#endif
+         MDH_IRR_BARRIER();
+#ifdef MDH_PHASES
+         ph_work += ph_t1 - ph_t0; ph_wait += __builtin_amdgcn_s_memtime() - ph_t1;
+#endif
+      }
+#ifdef MDH_PHASES
+      if (lane == 0) { atomicAdd(&g_phase[2 * wv], ph_work); atomicAdd(&g_phase[2 * wv + 1], ph_wait); }
+#endif
+#undef MDH_IRR_TAP_COORD
+#undef MDH_IRR_TAP_STORE
+#undef MDH_IRR_BARRIER
+#undef MDH_IRR_WEIGHTS
+      if (wv == 0 && lane < ntex) {
+         const f3 irradiance = F3(acc_x, acc_y, acc_z) / acc_w;
          const unsigned idx = atlas_index(pr.pcx, pr.ires, pr.ishift, i, j);
          atlas_store(pr.irr, pr.fmt, idx, irradiance_blend(pr, prev, hyst, idx, irradiance));
       }
