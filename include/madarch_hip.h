@@ -379,6 +379,25 @@ int32_t mdh_comm_barrier(mdh_renderer *r);
 int32_t mdh_comm_max_f64(mdh_renderer *r, double *value);
 int32_t mdh_comm_reduce_framebuffer(mdh_renderer *r, int32_t root);
 
+/* ---- the same sharded frame WITHOUT a collective library: the peer exchange ("a hand-rolled P2P
+ * fan-out").  Every rank exports the interprocess handles of its radiance atlases (hipIpcGetMemHandle), of one
+ * interprocess event per atlas set and the name of a small shared-memory block; the host hands every rank's 512 bytes
+ * to every rank (a file, a pipe, whatever it used for the communicator id); mdh_peer_init opens the peers' handles.
+ * From then on mdh_render is the sharded frame of mdh_comm_init, its exchange step being COPIES: behind its radiance
+ * pass a rank records its event and publishes the frame's number in its shared-memory block; it then waits (on the
+ * probe stream) for each peer's event and copies that peer's slice out of the peer's atlas into its own --
+ * hipMemcpyAsync, device to device, no kernel of the library and no CU of the chip.  The irradiance pass runs for all
+ * probes on every rank (MDH_OPT_IRRADIANCE_ALL must be on).  It is the fall-back between RCCL and the exchange through
+ * host memory, and the one device-resident exchange that several processes can run on ONE GPU (RCCL refuses two ranks
+ * of a communicator on one device).  The ranks must be processes of one node; every rank must render the same frames.
+ *   mdh_peer_export   this rank's handles (MDH_PEER_BLOB_BYTES bytes)
+ *   mdh_peer_init     every rank, with all ranks' blobs in rank order; sets MDH_OPT_RANK / MDH_OPT_WORLD
+ *   mdh_comm_destroy / mdh_comm_abort   leave (as for a communicator); mdh_comm_barrier, mdh_comm_max_f64 and
+ *                     mdh_comm_reduce_framebuffer need a communicator and return MDH_E_STATE here */
+#define MDH_PEER_BLOB_BYTES 512
+int32_t mdh_peer_export(mdh_renderer *r, uint8_t blob_out[MDH_PEER_BLOB_BYTES]);
+int32_t mdh_peer_init(mdh_renderer *r, const uint8_t *blobs /* world x MDH_PEER_BLOB_BYTES */, int32_t rank, int32_t world);
+
 /* replaces Swap_Buffers (renderers.adb:320): linear RGB floats, H*W*3, row 0 = top.
  * In a sharded run only this rank's tiles are written, the rest is 0. */
 int32_t mdh_read_framebuffer(mdh_renderer *r, float *rgb_out);

@@ -26,6 +26,7 @@ OPT_INDIRECT_SPECULAR, OPT_HYSTERESIS_PERMILLE, OPT_RADIANCE_ORDER, OPT_SCREEN_O
 PASS_RADIANCE, PASS_IRRADIANCE, PASS_VISIBILITY, PASS_SCATTERING, PASS_SCREEN, PASS_EXCHANGE = range(6)
 PASS_NAMES = ("radiance", "irradiance", "visibility", "scattering", "screen", "exchange")
 COMM_ID_BYTES = 128
+PEER_BLOB_BYTES = 512
 TEX_RADIANCE, TEX_IRRADIANCE, TEX_VISIBILITY, TEX_SCATTERING = range(4)
 TEX_RADIANCE_MIP0 = 16  # + l: level l >= 1 of the radiance atlas (OPT_RADIANCE_MIPS), Read_Texture only
 
@@ -132,6 +133,9 @@ HIP_ONLY_ABI = {
     "comm_barrier": (_I, [_P]),
     "comm_max_f64": (_I, [_P, C.POINTER(C.c_double)]),
     "comm_reduce_framebuffer": (_I, [_P, _I]),
+    # the peer exchange: the same sharded frame with device-to-device copies between processes of one node
+    "peer_export": (_I, [_P, _P]),
+    "peer_init": (_I, [_P, _P, _I, _I]),
     "atlas_device_ptr": (_I, [_P, _I, C.POINTER(_P), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
                               C.POINTER(C.c_int64)]),
     "stream": (_I, [_P, C.POINTER(_P)]),

@@ -10,6 +10,12 @@
 #include "mdh_jit_sources.inc" // the three device headers as string literals (Makefile), for the hiprtc build of user-defined kinds
 
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <chrono>
+#include <thread>
 #include <hip/hiprtc.h> // types only: the library is opened on first use (no link-time dependency)
 #include <rccl/rccl.h>  // types only, likewise: librccl is opened by the first mdh_comm_* call
 
@@ -328,6 +334,7 @@ struct mdh_renderer {
    // exchange of the atlas slices itself, on the probe stream, between the probe passes.
    ncclComm_t comm = nullptr;
    double *d_comm_scratch = nullptr; // barrier / max reductions
+   struct PeerState *peer = nullptr; // the peer exchange (mdh_peer_init): the same sharded frame, its exchange as copies
    bool irr_lds_granted = false; // k_irradiance may use up to 160 KiB of dynamic LDS on this renderer's device
 };
 
@@ -793,6 +800,8 @@ static int build_rad_mips(mdh_renderer *r, int set, hipStream_t st)
 }
 
 static int rccl_api_destroy(ncclComm_t c); // (mdh_comm_* below)
+static void peer_drop(mdh_renderer *r);      // (mdh_peer_* below)
+static bool peer_active(const mdh_renderer *r);
 extern "C" int32_t mdh_destroy(mdh_renderer *r)
 {
    if (!r) return MDH_OK;
@@ -804,6 +813,7 @@ extern "C" int32_t mdh_destroy(mdh_renderer *r)
    if (r->vol_stream) (void)hipStreamSynchronize(r->vol_stream);
    if (r->comm) { ncclComm_t c = r->comm; r->comm = nullptr; (void)rccl_api_destroy(c); }
    if (r->d_comm_scratch) (void)hipFree(r->d_comm_scratch);
+   peer_drop(r);
    void *ptrs[] = {r->d_table_ring[0], r->d_table_ring[1], r->d_table_ring[2], r->d_table_ring[3], r->d_part_ring[0], r->d_part_ring[1], r->d_part_ring[2], r->d_part_ring[3], r->d_warn, r->d_query, r->d_rad_steps, r->d_rad_order, r->d_rad_hist, r->d_scr_cost, r->d_scr_order[0], r->d_scr_order[1], r->d_scr_hist, r->d_fb2[0], r->d_fb2[1], r->d_gb2[0][0], r->d_gb2[0][1], r->d_gb2[0][2], r->d_gb2[1][0], r->d_gb2[1][1], r->d_gb2[1][2]};
    for (void *p : ptrs)
       if (p) (void)hipFree(p);
@@ -981,11 +991,13 @@ extern "C" int32_t mdh_set_option(mdh_renderer *r, int32_t option, int32_t value
    if (r->in_frame && (option == MDH_OPT_ATLAS_FORMAT || option == MDH_OPT_RANK || option == MDH_OPT_WORLD || option == MDH_OPT_FRAME_OVERLAP ||
                        option == MDH_OPT_SCREEN_MODE))
       return seterr(MDH_E_STATE, "a frame is open");
-   if (r->comm && (option == MDH_OPT_RANK || option == MDH_OPT_WORLD)) return seterr(MDH_E_STATE, "rank and world belong to the communicator (mdh_comm_init)");
+   if ((r->comm || peer_active(r)) && (option == MDH_OPT_RANK || option == MDH_OPT_WORLD)) return seterr(MDH_E_STATE, "rank and world belong to the communicator (mdh_comm_init / mdh_peer_init)");
+   if (peer_active(r) && option == MDH_OPT_IRRADIANCE_ALL && !value) return seterr(MDH_E_STATE, "the peer exchange moves radiance slices only: MDH_OPT_IRRADIANCE_ALL stays on");
    switch (option) {
    case MDH_OPT_ATLAS_FORMAT:
       if (value != 0 && value != 1) return seterr(MDH_E_INVALID, "atlas format is 0 (RGB8) or 1 (fp32)");
       if (value != r->opt_atlas) {
+         if (r->peer) return seterr(MDH_E_STATE, "the peers hold handles of this renderer's atlases (mdh_peer_export): leave first (mdh_comm_destroy)");
          HIP_TRY(hipSetDevice(r->device));
          { int jr = join_main(r); if (jr != MDH_OK) return jr; }
          HIP_TRY(hipStreamSynchronize(r->stream));
@@ -2164,6 +2176,221 @@ static int rccl_ready()
    return rccl_api().ok ? MDH_OK : seterr(MDH_E_COMM, "librccl.so.1 cannot be loaded (or lacks a symbol): no communicator; MADARCH_HIP_RCCL_LIBRARY names another file");
 }
 
+// ------------------------------------------------------------------ the peer exchange (include/madarch_hip.h)
+// The sharded frame's exchange as device-to-device COPIES between processes of one node.  What a rank shares, per atlas set s:
+// its radiance atlas (hipIpcMemHandle), an interprocess event recorded on its probe stream behind its radiance pass, and
+// -- in a POSIX shared-memory block of its own -- the number of the last frame of set s whose event it has RECORDED.  A
+// stream wait on another process's event only sees records that have been enqueued already, so the host of the waiting
+// rank first spins on that number (the hosts enqueue at the same pace; nothing waits for the GPU there), then enqueues the
+// wait and the copy of the peer's slice out of the peer's atlas into its own.  Everything stays on the probe stream: the
+// screen pass of the previous frame runs beside it, frames stay in flight.
+//
+// Why reading a peer's slice is safe against the peer's NEXT radiance pass into the same set (three frames on): that
+// pass comes behind the peer's irradiance pass of the frame before it, which waited for this rank's slice of that
+// frame, which this rank's probe stream produced behind this copy.
+struct PeerBlob { // MDH_PEER_BLOB_BYTES on the wire
+   uint32_t magic, version;
+   int32_t pid, device, nsets;
+   uint64_t rad_bytes;
+   hipIpcMemHandle_t rad[MDH_ATLAS_SETS];
+   hipIpcEventHandle_t ev[MDH_ATLAS_SETS];
+   char shm_name[48];
+};
+static_assert(sizeof(PeerBlob) <= MDH_PEER_BLOB_BYTES, "MDH_PEER_BLOB_BYTES holds a rank's handles");
+struct PeerShm { volatile long long recorded[MDH_ATLAS_SETS]; volatile long long left; };
+struct PeerState {
+   bool active = false, aborted = false;
+   int rank = 0, world = 1;
+   bool exported = false;
+   hipEvent_t ev[MDH_ATLAS_SETS] = {nullptr};
+   long long seq[MDH_ATLAS_SETS] = {0};
+   char shm_name[48] = "";
+   PeerShm *shm = nullptr;
+   struct Peer {
+      void *rad[MDH_ATLAS_SETS] = {nullptr};
+      hipEvent_t ev[MDH_ATLAS_SETS] = {nullptr};
+      PeerShm *shm = nullptr;
+   };
+   std::vector<Peer> peers;
+   bool host_sync = false; // MADARCH_HIP_PEER_SYNC=host: no interprocess events -- a rank publishes a frame when its slice IS complete (a host wait per frame)
+};
+static bool peer_active(const mdh_renderer *r) { return r->peer && r->peer->active; }
+static void peer_close_peers(PeerState *p)
+{
+   for (auto &q : p->peers) {
+      for (int s = 0; s < MDH_ATLAS_SETS; ++s) {
+         if (q.rad[s]) (void)hipIpcCloseMemHandle(q.rad[s]);
+         if (q.ev[s]) (void)hipEventDestroy(q.ev[s]);
+         q.rad[s] = nullptr; q.ev[s] = nullptr;
+      }
+      if (q.shm) munmap((void *)q.shm, sizeof(PeerShm));
+      q.shm = nullptr;
+   }
+   p->peers.clear();
+}
+// leave the exchange: the peers' handles are closed, this rank is rank 0 of 1 again (its own exports stay valid until mdh_destroy)
+static void peer_leave(mdh_renderer *r)
+{
+   PeerState *p = r->peer;
+   if (!p) return;
+   if (p->shm) p->shm->left = 1;
+   peer_close_peers(p);
+   if (p->active) {
+      p->active = false;
+      r->opt_rank = 0;
+      r->opt_world = 1;
+      r->rad_order_rays = 0;
+      r->fb_owner[0][0] = r->fb_owner[1][0] = -1;
+   }
+}
+static void peer_abort(mdh_renderer *r) // (from a watchdog thread: only a flag -- the spinning host returns MDH_E_COMM)
+{
+   if (r->peer) r->peer->aborted = true;
+}
+static void peer_drop(mdh_renderer *r)
+{
+   PeerState *p = r->peer;
+   if (!p) return;
+   peer_leave(r);
+   for (int s = 0; s < MDH_ATLAS_SETS; ++s)
+      if (p->ev[s]) (void)hipEventDestroy(p->ev[s]);
+   if (p->shm) munmap((void *)p->shm, sizeof(PeerShm));
+   if (p->shm_name[0]) shm_unlink(p->shm_name);
+   delete p;
+   r->peer = nullptr;
+}
+extern "C" int32_t mdh_peer_export(mdh_renderer *r, uint8_t blob_out[MDH_PEER_BLOB_BYTES])
+{
+   if (!r || !blob_out) return seterr(MDH_E_INVALID, "bad argument");
+   if (r->in_frame) return seterr(MDH_E_STATE, "a frame is open");
+   if (r->comm) return seterr(MDH_E_STATE, "the renderer has a communicator");
+   HIP_TRY(hipSetDevice(r->device));
+   if (!r->peer) r->peer = new PeerState();
+   PeerState *p = r->peer;
+   if (!p->exported) {
+      for (int s = 0; s < MDH_ATLAS_SETS; ++s)
+         if (!p->ev[s]) HIP_TRY(hipEventCreateWithFlags(&p->ev[s], hipEventDisableTiming | hipEventInterprocess));
+      static int serial = 0;
+      snprintf(p->shm_name, sizeof p->shm_name, "/mdh_peer_%d_%d", (int)getpid(), ++serial);
+      const int fd = shm_open(p->shm_name, O_CREAT | O_EXCL | O_RDWR, 0600);
+      if (fd < 0) { p->shm_name[0] = 0; return seterr(MDH_E_COMM, "shm_open failed"); }
+      if (ftruncate(fd, sizeof(PeerShm)) != 0) { close(fd); return seterr(MDH_E_COMM, "ftruncate of the shared-memory block failed"); }
+      void *m = mmap(nullptr, sizeof(PeerShm), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+      close(fd);
+      if (m == MAP_FAILED) return seterr(MDH_E_COMM, "mmap of the shared-memory block failed");
+      p->shm = (PeerShm *)m;
+      memset((void *)p->shm, 0, sizeof(PeerShm));
+      p->exported = true;
+   }
+   PeerBlob b;
+   memset(&b, 0, sizeof b);
+   b.magic = 0x5045484du; b.version = 1;
+   b.pid = (int32_t)getpid(); b.device = r->device; b.nsets = MDH_ATLAS_SETS;
+   b.rad_bytes = atlas_bytes(r, MDH_TEX_RADIANCE);
+   for (int s = 0; s < MDH_ATLAS_SETS; ++s) {
+      HIP_TRY(hipIpcGetMemHandle(&b.rad[s], r->d_rad2[s]));
+      HIP_TRY(hipIpcGetEventHandle(&b.ev[s], p->ev[s]));
+   }
+   memcpy(b.shm_name, p->shm_name, sizeof b.shm_name);
+   memset(blob_out, 0, MDH_PEER_BLOB_BYTES);
+   memcpy(blob_out, &b, sizeof b);
+   return MDH_OK;
+}
+extern "C" int32_t mdh_peer_init(mdh_renderer *r, const uint8_t *blobs, int32_t rank, int32_t world)
+{
+   if (!r || !blobs) return seterr(MDH_E_INVALID, "bad argument");
+   if (world < 1 || rank < 0 || rank >= world) return seterr(MDH_E_INVALID, "rank is not below world");
+   if (r->in_frame) return seterr(MDH_E_STATE, "a frame is open");
+   if (r->comm || peer_active(r)) return seterr(MDH_E_STATE, "the renderer already has a communicator");
+   PeerState *p = r->peer;
+   if (!p || !p->exported) return seterr(MDH_E_STATE, "mdh_peer_export comes first");
+   if (!r->opt_irr_all) return seterr(MDH_E_STATE, "the peer exchange moves radiance slices only: MDH_OPT_IRRADIANCE_ALL must be on");
+   HIP_TRY(hipSetDevice(r->device));
+   { int jr = join_main(r); if (jr != MDH_OK) return jr; }
+   HIP_TRY(hipStreamSynchronize(r->stream));
+   static const bool host_sync_env = [] { const char *e = getenv("MADARCH_HIP_PEER_SYNC"); return e && strcmp(e, "host") == 0; }();
+   p->host_sync = host_sync_env;
+   p->peers.assign((size_t)world, PeerState::Peer());
+   for (int q = 0; q < world; ++q) {
+      PeerBlob b;
+      memcpy(&b, blobs + (size_t)q * MDH_PEER_BLOB_BYTES, sizeof b);
+      if (b.magic != 0x5045484du || b.version != 1 || b.nsets != MDH_ATLAS_SETS) { peer_close_peers(p); return seterr(MDH_E_INVALID, "not a peer blob of this library"); }
+      if (b.rad_bytes != atlas_bytes(r, MDH_TEX_RADIANCE)) { peer_close_peers(p); return seterr(MDH_E_INVALID, "a peer's radiance atlas has another size: the ranks' probe settings and atlas formats must agree"); }
+      if (q == rank) {
+         if (b.pid != (int32_t)getpid() || strncmp(b.shm_name, p->shm_name, sizeof b.shm_name) != 0) { peer_close_peers(p); return seterr(MDH_E_INVALID, "the blob at this rank's place is not this renderer's"); }
+         continue;
+      }
+      if (b.pid == (int32_t)getpid()) { peer_close_peers(p); return seterr(MDH_E_INVALID, "two ranks of a peer exchange in one process: a process cannot open its own interprocess handles"); }
+      PeerState::Peer &pe = p->peers[(size_t)q];
+      for (int s = 0; s < MDH_ATLAS_SETS; ++s) {
+         if (hipIpcOpenMemHandle(&pe.rad[s], b.rad[s], hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); peer_close_peers(p); return seterr(MDH_E_COMM, "hipIpcOpenMemHandle failed on a peer's radiance atlas"); }
+         if (!p->host_sync && hipIpcOpenEventHandle(&pe.ev[s], b.ev[s]) != hipSuccess) { (void)hipGetLastError(); peer_close_peers(p); return seterr(MDH_E_COMM, "hipIpcOpenEventHandle failed on a peer's event (MADARCH_HIP_PEER_SYNC=host does without)"); }
+      }
+      const int fd = shm_open(b.shm_name, O_RDONLY, 0);
+      if (fd < 0) { peer_close_peers(p); return seterr(MDH_E_COMM, "a peer's shared-memory block cannot be opened: the ranks must be processes of one node"); }
+      void *m = mmap(nullptr, sizeof(PeerShm), PROT_READ, MAP_SHARED, fd, 0);
+      close(fd);
+      if (m == MAP_FAILED) { peer_close_peers(p); return seterr(MDH_E_COMM, "mmap of a peer's shared-memory block failed"); }
+      pe.shm = (PeerShm *)m;
+   }
+   for (int s = 0; s < MDH_ATLAS_SETS; ++s) { p->seq[s] = 0; p->shm->recorded[s] = 0; }
+   p->shm->left = 0;
+   p->rank = rank; p->world = world;
+   p->aborted = false;
+   p->active = true;
+   r->opt_rank = rank;
+   r->opt_world = world;
+   r->rad_order_rays = 0;
+   return MDH_OK;
+}
+#ifndef MDH_PEER_TIMEOUT_S
+#define MDH_PEER_TIMEOUT_S 60.0
+#endif
+static int peer_exchange(mdh_renderer *r, int tex)
+{
+   PeerState *p = r->peer;
+   if (tex != MDH_TEX_RADIANCE) return r->opt_irr_all ? MDH_OK : seterr(MDH_E_STATE, "the peer exchange moves radiance slices only: MDH_OPT_IRRADIANCE_ALL must be on");
+   hipStream_t st = frame_probe_stream(r);
+   const int s = r->frame_cur;
+   const size_t per = (size_t)r->probes.radiance_resolution * r->probes.radiance_resolution * texel_bytes(r);
+   const long long P = probe_total(r), world = p->world;
+   hipEvent_t e0 = nullptr, e1 = nullptr;
+   if (r->opt_timing) {
+      e0 = get_event(r);
+      e1 = get_event(r);
+      if (!e0 || !e1) return seterr(MDH_E_DEVICE, "hipEventCreate failed");
+      HIP_TRY(hipEventRecord(e0, st));
+   }
+   // my slice of set s is complete behind everything the probe stream holds: say so
+   const long long n = ++p->seq[s];
+   if (p->host_sync) HIP_TRY(hipStreamSynchronize(st));
+   else HIP_TRY(hipEventRecord(p->ev[s], st));
+   __atomic_store_n(&p->shm->recorded[s], n, __ATOMIC_RELEASE);
+   char *mine = (char *)r->d_rad2[s];
+   const auto t0 = std::chrono::steady_clock::now();
+   for (long long k = 1; k < world; ++k) { // (peers in a rotated order: the ranks do not all read the same peer at once)
+      const long long q = (p->rank + k) % world;
+      const long long b = P * q / world, e = P * (q + 1) / world; // own_probes () of rank q
+      if (e <= b) continue;
+      PeerState::Peer &pe = p->peers[(size_t)q];
+      for (unsigned spin = 0; __atomic_load_n(&pe.shm->recorded[s], __ATOMIC_ACQUIRE) < n; ++spin) {
+         if (p->aborted) return seterr(MDH_E_COMM, "the peer exchange was aborted");
+         if (pe.shm->left) return seterr(MDH_E_COMM, "a peer has left the exchange");
+         if ((spin & 1023u) == 1023u) {
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > MDH_PEER_TIMEOUT_S) return seterr(MDH_E_COMM, "a peer did not reach this frame's exchange in time");
+            std::this_thread::yield();
+         }
+      }
+      if (!p->host_sync) HIP_TRY(hipStreamWaitEvent(st, pe.ev[s], 0));
+      HIP_TRY(hipMemcpyAsync(mine + per * (size_t)b, (const char *)pe.rad[s] + per * (size_t)b, per * (size_t)(e - b), hipMemcpyDeviceToDevice, st));
+   }
+   if (r->opt_timing) {
+      HIP_TRY(hipEventRecord(e1, st));
+      r->pending.push_back({MDH_PASS_EXCHANGE, e0, e1});
+   }
+   return MDH_OK;
+}
+
 extern "C" int32_t mdh_comm_unique_id(uint8_t id_out[MDH_COMM_ID_BYTES])
 {
    static_assert(sizeof(ncclUniqueId) == MDH_COMM_ID_BYTES, "MDH_COMM_ID_BYTES is the size of ncclUniqueId");
@@ -2180,7 +2407,7 @@ extern "C" int32_t mdh_comm_init(mdh_renderer *r, const uint8_t id_in[MDH_COMM_I
    if (!r || !id_in) return seterr(MDH_E_INVALID, "bad argument");
    if (world < 1 || rank < 0 || rank >= world) return seterr(MDH_E_INVALID, "rank is not below world");
    if (r->in_frame) return seterr(MDH_E_STATE, "a frame is open");
-   if (r->comm) return seterr(MDH_E_STATE, "the renderer already has a communicator");
+   if (r->comm || peer_active(r)) return seterr(MDH_E_STATE, "the renderer already has a communicator");
    int rc = rccl_ready();
    if (rc != MDH_OK) return rc;
    HIP_TRY(hipSetDevice(r->device)); // (the communicator binds to the current device)
@@ -2218,6 +2445,7 @@ extern "C" int32_t mdh_comm_destroy(mdh_renderer *r)
    if (r->in_frame) return seterr(MDH_E_STATE, "a frame is open");
    HIP_TRY(hipSetDevice(r->device));
    { int dr = drain_streams(r); if (dr != MDH_OK) return dr; } // collectives in flight end first
+   if (r->peer) { peer_leave(r); return MDH_OK; }
    return comm_drop(r, false);
 }
 // what a watchdog of the host calls (from any thread) when a collective never returns: no wait for anything
@@ -2226,6 +2454,7 @@ extern "C" int32_t mdh_comm_abort(mdh_renderer *r)
    if (!r) return seterr(MDH_E_INVALID, "null renderer");
    (void)hipSetDevice(r->device);
    if (r->in_frame) { r->in_frame = false; r->main_dirty = true; }
+   if (r->peer) { peer_abort(r); return MDH_OK; } // (a host spinning for a peer's frame number gives up; the handles are closed by mdh_comm_destroy / mdh_destroy)
    return comm_drop(r, true);
 }
 // an asynchronous failure of the communicator (a peer died, a transport error) surfaces here
@@ -2250,6 +2479,7 @@ extern "C" int32_t mdh_frame_exchange(mdh_renderer *r, int32_t tex)
    if (!r) return seterr(MDH_E_INVALID, "null renderer");
    if (tex != MDH_TEX_RADIANCE && tex != MDH_TEX_IRRADIANCE) return seterr(MDH_E_INVALID, "not an atlas");
    if (!r->in_frame) return seterr(MDH_E_STATE, "no open frame");
+   if (peer_active(r)) return r->opt_mode != 0 ? MDH_OK : peer_exchange(r, tex);
    if (!r->comm || r->opt_mode != 0) return MDH_OK;
    const RcclApi &n = rccl_api();
    hipStream_t st = frame_probe_stream(r);
@@ -2290,6 +2520,7 @@ extern "C" int32_t mdh_comm_barrier(mdh_renderer *r)
    if (!r) return seterr(MDH_E_INVALID, "null renderer");
    if (r->in_frame) return seterr(MDH_E_STATE, "a frame is open");
    int rc = mdh_finish(r);
+   if (rc == MDH_OK && peer_active(r)) return seterr(MDH_E_STATE, "the peer exchange has no collectives: the host's own channel is the barrier");
    if (rc != MDH_OK || !r->comm) return rc;
    HIP_TRY(hipMemsetAsync(r->d_comm_scratch, 0, sizeof(double), r->stream));
    RCCL_TRY(rccl_api().AllReduce(r->d_comm_scratch, r->d_comm_scratch, 1, ncclFloat64, ncclSum, r->comm, r->stream));
@@ -2300,6 +2531,7 @@ extern "C" int32_t mdh_comm_max_f64(mdh_renderer *r, double *value)
 {
    if (!r || !value) return seterr(MDH_E_INVALID, "bad argument");
    if (r->in_frame) return seterr(MDH_E_STATE, "a frame is open");
+   if (peer_active(r)) return seterr(MDH_E_STATE, "the peer exchange has no collectives");
    if (!r->comm) return MDH_OK;
    HIP_TRY(hipSetDevice(r->device));
    { int jr = join_main(r); if (jr != MDH_OK) return jr; }
@@ -2313,6 +2545,7 @@ extern "C" int32_t mdh_comm_reduce_framebuffer(mdh_renderer *r, int32_t root)
 {
    if (!r) return seterr(MDH_E_INVALID, "null renderer");
    if (r->in_frame) return seterr(MDH_E_STATE, "a frame is open");
+   if (peer_active(r)) return seterr(MDH_E_STATE, "the peer exchange has no collectives: read every rank's framebuffer and add them");
    if (!r->comm) return MDH_OK;
    if (root < 0 || root >= r->opt_world) return seterr(MDH_E_INVALID, "root is not a rank");
    HIP_TRY(hipSetDevice(r->device));

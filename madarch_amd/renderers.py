@@ -145,6 +145,21 @@ class Renderer:
         buf = (C.c_uint8 * B.COMM_ID_BYTES).from_buffer_copy(Id)
         self._b.check(self._b.comm_init(self._h, buf, int(Rank), int(World)))
 
+    def Peer_Export(self):
+        """this rank's interprocess handles (radiance atlases, events, a shared-memory block): 512 bytes for every rank"""
+        buf = (C.c_uint8 * B.PEER_BLOB_BYTES)()
+        self._b.check(self._b.peer_export(self._h, buf))
+        return bytes(buf)
+
+    def Peer_Init(self, Blobs, Rank, World):
+        """every rank, with all ranks' Peer_Export blobs in rank order: Render is then the sharded frame, its exchange
+        being device-to-device copies out of the peers' atlases (Comm_Destroy leaves)"""
+        Blobs = b"".join(Blobs) if not isinstance(Blobs, (bytes, bytearray)) else bytes(Blobs)
+        if len(Blobs) != B.PEER_BLOB_BYTES * int(World):
+            raise ValueError("one %d-byte blob per rank" % B.PEER_BLOB_BYTES)
+        buf = (C.c_uint8 * len(Blobs)).from_buffer_copy(Blobs)
+        self._b.check(self._b.peer_init(self._h, buf, int(Rank), int(World)))
+
     def Comm_Destroy(self):
         self._b.check(self._b.comm_destroy(self._h))
 

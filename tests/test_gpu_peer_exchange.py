@@ -1,0 +1,92 @@
+"""The sharded frame with the PEER exchange (mdh_peer_export / mdh_peer_init): several PROCESSES on the one GPU of the test
+box, each a rank with its own renderer, exchanging their radiance slices device to device (hipIpcMemHandle, interprocess
+events, no collective library and no host copy).  RCCL refuses two ranks of a communicator on one device; this backend is
+the device-resident exchange that more than one process can run here.  The ranks' framebuffers must add up to the whole
+frame and every rank's atlases must be the whole frame's, bit for bit, with frames in flight."""
+import multiprocessing as mp
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _rank(rank, world, probes_name, overlap, frames, sync, conn):
+    """a fresh process: one rank of the exchange (handles travel through the parent's pipes)"""
+    try:
+        sys.path.insert(0, ROOT)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        if sync:
+            os.environ["MADARCH_HIP_PEER_SYNC"] = sync
+        import helpers
+        from madarch_amd import _binding as B
+        hip = B.hip_binding()
+        R = helpers.make("global_illumination", 96, 64, hip, probes=getattr(helpers, probes_name))
+        R.Set_Option(B.OPT_FRAME_OVERLAP, overlap)
+        conn.send(R.Peer_Export())
+        blobs = conn.recv()
+        R.Peer_Init(blobs, rank, world)
+        assert (R.Get_Option(B.OPT_RANK), R.Get_Option(B.OPT_WORLD)) == (rank, world)
+        R.Set_Option(B.OPT_TIMING, 1)
+        for _ in range(frames):
+            R.Render()
+        R.Finish()
+        ms, n = R.Pass_Time(B.PASS_EXCHANGE)
+        out = {"image": R.Read_Framebuffer(), "radiance": R.Read_Texture(B.TEX_RADIANCE), "irradiance": R.Read_Texture(B.TEX_IRRADIANCE),
+               "exchange_ms": ms / max(n, 1), "exchanges": n}
+        conn.send(out)
+        conn.recv()  # every rank has read its results: leave together
+        R.Comm_Destroy()
+        R.Render(); R.Finish()  # a whole frame again, alone
+        R.Destroy()
+        conn.send("left")
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        conn.send("ERROR " + repr(e) + "\n" + traceback.format_exc())
+
+
+@pytest.mark.parametrize("world,probes_name,overlap,sync", [(2, "SMALL_PROBES", 2, None), (2, "ODD_PROBES", 2, None), (3, "SMALL_PROBES", 0, None),
+                                                            (2, "SMALL_PROBES", 2, "host")])
+def test_peer_exchange_between_processes_on_one_gpu(hip, world, probes_name, overlap, sync):
+    import helpers
+    frames = 4
+    want = helpers.snapshot(helpers.make("global_illumination", 96, 64, hip, probes=getattr(helpers, probes_name)), frames)
+    ctx = mp.get_context("spawn")  # fresh processes: nothing of this process's GPU state is inherited
+    pipes, procs = [], []
+    for rank in range(world):
+        a, b = ctx.Pipe()
+        p = ctx.Process(target=_rank, args=(rank, world, probes_name, overlap, frames, sync, b), daemon=True)
+        p.start()
+        pipes.append(a); procs.append(p)
+
+    def get(c, what):
+        assert c.poll(240), "a rank did not send its " + what
+        v = c.recv()
+        assert not (isinstance(v, str) and v.startswith("ERROR")), v
+        return v
+    try:
+        blobs = [get(c, "handles") for c in pipes]
+        assert all(len(b) == 512 for b in blobs)
+        for c in pipes:
+            c.send(b"".join(blobs))
+        outs = [get(c, "results") for c in pipes]
+        for c in pipes:
+            c.send("go")
+        for c in pipes:
+            assert get(c, "goodbye") == "left"
+    finally:
+        for p in procs:
+            p.join(30)
+            if p.is_alive():
+                p.kill()
+    image = np.sum([o["image"] for o in outs], axis=0)
+    assert helpers.same_bits(image, want["image"]), "the ranks' tiles do not add up to the whole frame"
+    for rank, o in enumerate(outs):
+        assert helpers.same_bits(o["radiance"], want["radiance"]), "radiance atlas of rank %d" % rank
+        assert helpers.same_bits(o["irradiance"], want["irradiance"]), "irradiance atlas of rank %d" % rank
+        assert o["exchanges"] == frames and o["exchange_ms"] >= 0.0
+    print("peer exchange, %d ranks on one GPU: %s ms per frame" % (world, ", ".join("%.4f" % o["exchange_ms"] for o in outs)))
