@@ -240,6 +240,8 @@ def main():
     ap.add_argument("--numerics", default="exact", choices=("exact", "fast"), help="fast = the LABELLED EXPERIMENT build (make -C madarch_amd/csrc fast: hardware sqrt / rcp / log / exp, tolerance only); the line then carries config.numerics = fast and is no result of the product")
     ap.add_argument("--screen-order", type=int, default=None, help="MDH_OPT_SCREEN_ORDER value (default: the library's)")
     ap.add_argument("--comm-timeout-s", type=float, default=120.0, help="watchdog of the communicator's join and trial frames (N > 1)")
+    ap.add_argument("--exchange", default="auto", choices=("auto", "rccl", "peer", "host"), help="N > 1: the exchange backend (auto: rccl, then the peer exchange, then host memory; each falls back to the next)")
+    ap.add_argument("--one-device", action="store_true", help="REHEARSAL: every rank on device 0 (a one-GPU box: the peer exchange between processes sharing the chip); the line says so")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -283,7 +285,7 @@ def main():
         R = make_renderer(args.workload, oracle_binding())
         R.Set_Option(ORC_OPT_THREADS, 2)
     else:
-        R = make_renderer(args.workload, B.hip_binding(), device=local_rank)
+        R = make_renderer(args.workload, B.hip_binding(), device=0 if args.one_device else local_rank)
     R.Set_Option(B.OPT_ATLAS_FORMAT, 0 if args.atlas == "rgb8" else 1)
     if args.mode is not None:
         R.Set_Option(B.OPT_SCREEN_MODE, args.mode)
@@ -299,7 +301,8 @@ def main():
     # control plane -- in this process, and the line says so.
     exchange, how = None, "single rank"
     if world > 1:
-        exchange, how = sharding.establish(R, rank, world, dist, timeout_s=args.comm_timeout_s,
+        order = {"auto": ("rccl", "peer", "host"), "rccl": ("rccl", "peer", "host"), "peer": ("peer", "host"), "host": ("host",)}[args.exchange]
+        exchange, how = sharding.establish(R, rank, world, dist, timeout_s=args.comm_timeout_s, backends=order,
                                            log=lambda m: print(m, file=sys.stderr, flush=True))
     elif args.rehearse_rccl:
         R.Comm_Init(R.Comm_Unique_Id(), 0, 1)
@@ -408,8 +411,12 @@ def main():
     parallelism = "tiles+probes/%d" % world
     if how == "rccl":
         parallelism += ", RCCL all-gather inside libmadarch_hip" + (" (one-rank rehearsal)" if world == 1 else "")
+    elif how == "peer":
+        parallelism += ", peer exchange inside libmadarch_hip (device-to-device copies between the ranks' processes, ordered by frame numbers polled on the device)"
     elif world > 1:
         parallelism += ", HOST EXCHANGE FALL-BACK over gloo (%s)" % how
+    if args.one_device and world > 1:
+        parallelism += " -- REHEARSAL: ALL %d RANKS ON ONE GPU" % world
     if rehearsal:
         img = frame.Gather_Framebuffer(dist)
         if rank == 0:
@@ -483,6 +490,10 @@ def main():
     # leave in order: the communicator while every rank is still here, then the renderer, then the control plane
     if how == "rccl":
         R.Comm_Barrier()
+        R.Comm_Destroy()
+    elif how == "peer":
+        R.Finish()
+        dist.barrier()  # (nobody closes handles a peer still copies from)
         R.Comm_Destroy()
     if dist is not None:
         dist.barrier()

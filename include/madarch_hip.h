@@ -372,6 +372,8 @@ int32_t mdh_finish(mdh_renderer *r);
  *                        a frame; a host that presents the image calls it, a benchmark does not. */
 #define MDH_COMM_ID_BYTES 128
 int32_t mdh_comm_unique_id(uint8_t id_out[MDH_COMM_ID_BYTES]);
+/* MDH_OK when this process can load librccl (what the ranks other than 0 ask before everybody enters mdh_comm_init) */
+int32_t mdh_comm_available(void);
 int32_t mdh_comm_init(mdh_renderer *r, const uint8_t id[MDH_COMM_ID_BYTES], int32_t rank, int32_t world);
 int32_t mdh_comm_destroy(mdh_renderer *r);
 int32_t mdh_comm_abort(mdh_renderer *r);
@@ -380,17 +382,19 @@ int32_t mdh_comm_max_f64(mdh_renderer *r, double *value);
 int32_t mdh_comm_reduce_framebuffer(mdh_renderer *r, int32_t root);
 
 /* ---- the same sharded frame WITHOUT a collective library: the peer exchange ("a hand-rolled P2P
- * fan-out").  Every rank exports the interprocess handles of its radiance atlases (hipIpcGetMemHandle), of one
- * interprocess event per atlas set and the name of a small shared-memory block; the host hands every rank's 512 bytes
- * to every rank (a file, a pipe, whatever it used for the communicator id); mdh_peer_init opens the peers' handles.
- * From then on mdh_render is the sharded frame of mdh_comm_init, its exchange step being COPIES: behind its radiance
- * pass a rank records its event and publishes the frame's number in its shared-memory block; it then waits (on the
- * probe stream) for each peer's event and copies that peer's slice out of the peer's atlas into its own --
- * hipMemcpyAsync, device to device, no kernel of the library and no CU of the chip.  The irradiance pass runs for all
- * probes on every rank (MDH_OPT_IRRADIANCE_ALL must be on).  It is the fall-back between RCCL and the exchange through
- * host memory, and the one device-resident exchange that several processes can run on ONE GPU (RCCL refuses two ranks
- * of a communicator on one device).  The ranks must be processes of one node; every rank must render the same frames.
- *   mdh_peer_export   this rank's handles (MDH_PEER_BLOB_BYTES bytes)
+ * fan-out").  Every rank exports the interprocess handles (hipIpcGetMemHandle) of its radiance atlases and of a block of
+ * frame numbers in device memory; the host hands every rank's 512 bytes to every rank (a file, a pipe, whatever it used
+ * for the communicator id); mdh_peer_init opens the peers' handles.  From then on mdh_render is the sharded frame of
+ * mdh_comm_init, its exchange step being COPIES ordered on the device: behind its radiance pass a rank stores the
+ * frame's number into its block; for each peer it enqueues one wavefront that polls the peer's number until it has
+ * reached this frame's, and behind it the copy of the peer's slice out of the peer's atlas into its own
+ * (hipMemcpyAsync, device to device) -- all on the probe stream, no host waits, frames stay in flight.  The irradiance
+ * pass runs for all probes on every rank (MDH_OPT_IRRADIANCE_ALL must be on).  It is the fall-back between RCCL and the
+ * exchange through host memory, and the one device-resident exchange that several processes can run on ONE GPU (RCCL
+ * refuses two ranks of a communicator on one device).  The ranks must be processes of one node (one process per rank)
+ * and must all render the same frames; a peer that never arrives ends the wait after a few seconds and the next
+ * mdh_render / mdh_finish returns MDH_E_COMM.
+ *   mdh_peer_export   this rank's handles (MDH_PEER_BLOB_BYTES bytes); starts a new session at frame 0
  *   mdh_peer_init     every rank, with all ranks' blobs in rank order; sets MDH_OPT_RANK / MDH_OPT_WORLD
  *   mdh_comm_destroy / mdh_comm_abort   leave (as for a communicator); mdh_comm_barrier, mdh_comm_max_f64 and
  *                     mdh_comm_reduce_framebuffer need a communicator and return MDH_E_STATE here */

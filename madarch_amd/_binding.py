@@ -127,6 +127,7 @@ ABI = {
 HIP_ONLY_ABI = {
     "frame_exchange": (_I, [_P, _I]),
     "comm_unique_id": (_I, [_P]),
+    "comm_available": (_I, []),
     "comm_init": (_I, [_P, _P, _I, _I]),
     "comm_destroy": (_I, [_P]),
     "comm_abort": (_I, [_P]),

@@ -10,12 +10,7 @@
 #include "mdh_jit_sources.inc" // the three device headers as string literals (Makefile), for the hiprtc build of user-defined kinds
 
 #include <dlfcn.h>
-#include <fcntl.h>
-#include <sys/mman.h>
-#include <sys/stat.h>
 #include <unistd.h>
-#include <chrono>
-#include <thread>
 #include <hip/hiprtc.h> // types only: the library is opened on first use (no link-time dependency)
 #include <rccl/rccl.h>  // types only, likewise: librccl is opened by the first mdh_comm_* call
 
@@ -802,6 +797,7 @@ static int build_rad_mips(mdh_renderer *r, int set, hipStream_t st)
 static int rccl_api_destroy(ncclComm_t c); // (mdh_comm_* below)
 static void peer_drop(mdh_renderer *r);      // (mdh_peer_* below)
 static bool peer_active(const mdh_renderer *r);
+static int peer_check(mdh_renderer *r);
 extern "C" int32_t mdh_destroy(mdh_renderer *r)
 {
    if (!r) return MDH_OK;
@@ -2177,13 +2173,18 @@ static int rccl_ready()
 }
 
 // ------------------------------------------------------------------ the peer exchange (include/madarch_hip.h)
-// The sharded frame's exchange as device-to-device COPIES between processes of one node.  What a rank shares, per atlas set s:
-// its radiance atlas (hipIpcMemHandle), an interprocess event recorded on its probe stream behind its radiance pass, and
-// -- in a POSIX shared-memory block of its own -- the number of the last frame of set s whose event it has RECORDED.  A
-// stream wait on another process's event only sees records that have been enqueued already, so the host of the waiting
-// rank first spins on that number (the hosts enqueue at the same pace; nothing waits for the GPU there), then enqueues the
-// wait and the copy of the peer's slice out of the peer's atlas into its own.  Everything stays on the probe stream: the
-// screen pass of the previous frame runs beside it, frames stay in flight.
+// The sharded frame's exchange as device-to-device COPIES between processes of one node, ordered ON THE DEVICE.  What a rank
+// shares: its radiance atlases (one hipIpcMemHandle per atlas set) and a block of FRAME NUMBERS in device memory, one per
+// set.  Behind its radiance pass a rank stores the frame's number into its own block (k_peer_publish, on the probe stream);
+// a rank that needs a peer's slice enqueues k_peer_wait -- one wavefront that polls the peer's number through the mapped
+// handle until it has reached this frame's (system-scope loads; bounded: a peer that never arrives ends the wait with an
+// error word in host memory instead of a hung queue) -- and behind it the copy of the slice out of the peer's atlas into
+// its own (hipMemcpyAsync, device to device).  No host of any rank waits for anything: frames stay in flight, the screen
+// pass of the previous frame runs beside the exchange.
+// (Round 4 first used interprocess EVENTS for the ordering.  They work -- tests of 4 frames passed -- and fail: after some
+// tens of frames hipStreamWaitEvent on a peer's event returned hipErrorInvalidValue, and HIP implements such waits as host
+// callbacks.  hipStreamWaitValue32 enqueued before the peer's write stalled the peer's first HIP call in the probe
+// (scripts/probes/ipc_probe.cpp, mode 2).  A polling wavefront needs nothing but memory.)
 //
 // Why reading a peer's slice is safe against the peer's NEXT radiance pass into the same set (three frames on): that
 // pass comes behind the peer's irradiance pass of the frame before it, which waited for this rank's slice of that
@@ -2193,38 +2194,51 @@ struct PeerBlob { // MDH_PEER_BLOB_BYTES on the wire
    int32_t pid, device, nsets;
    uint64_t rad_bytes;
    hipIpcMemHandle_t rad[MDH_ATLAS_SETS];
-   hipIpcEventHandle_t ev[MDH_ATLAS_SETS];
-   char shm_name[48];
+   hipIpcMemHandle_t flags;
+   uint64_t serial; // (of this export: a blob of an earlier session of the same process is refused)
 };
 static_assert(sizeof(PeerBlob) <= MDH_PEER_BLOB_BYTES, "MDH_PEER_BLOB_BYTES holds a rank's handles");
-struct PeerShm { volatile long long recorded[MDH_ATLAS_SETS]; volatile long long left; };
 struct PeerState {
-   bool active = false, aborted = false;
+   bool active = false;
    int rank = 0, world = 1;
    bool exported = false;
-   hipEvent_t ev[MDH_ATLAS_SETS] = {nullptr};
-   long long seq[MDH_ATLAS_SETS] = {0};
-   char shm_name[48] = "";
-   PeerShm *shm = nullptr;
+   uint64_t serial = 0;
+   unsigned *d_flags = nullptr;         // [MDH_ATLAS_SETS] the number of the last frame whose slice of set s is complete (device memory, shared)
+   unsigned seq[MDH_ATLAS_SETS] = {0};
+   unsigned *h_err = nullptr;           // pinned host word: a wait gave up
    struct Peer {
       void *rad[MDH_ATLAS_SETS] = {nullptr};
-      hipEvent_t ev[MDH_ATLAS_SETS] = {nullptr};
-      PeerShm *shm = nullptr;
+      unsigned *flags = nullptr;
    };
    std::vector<Peer> peers;
-   bool host_sync = false; // MADARCH_HIP_PEER_SYNC=host: no interprocess events -- a rank publishes a frame when its slice IS complete (a host wait per frame)
 };
+#ifndef MDH_PEER_SPIN_LIMIT
+#define MDH_PEER_SPIN_LIMIT (1u << 23) // polls of k_peer_wait, about a microsecond each
+#endif
+__global__ void k_peer_publish(unsigned *flag, unsigned n)
+{
+   __hip_atomic_store(flag, n, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__global__ void k_peer_wait(const unsigned *flag, unsigned n, unsigned *err)
+{
+   if (threadIdx.x != 0) return;
+   for (unsigned spin = 0; spin < MDH_PEER_SPIN_LIMIT; ++spin) {
+      // (frame numbers only grow; the difference as a signed number survives the counter's wrap)
+      if ((int)(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - n) >= 0) return;
+      __builtin_amdgcn_s_sleep(32);
+   }
+   __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); // the copy behind this wait reads a stale slice: the host is told
+}
 static bool peer_active(const mdh_renderer *r) { return r->peer && r->peer->active; }
 static void peer_close_peers(PeerState *p)
 {
    for (auto &q : p->peers) {
       for (int s = 0; s < MDH_ATLAS_SETS; ++s) {
          if (q.rad[s]) (void)hipIpcCloseMemHandle(q.rad[s]);
-         if (q.ev[s]) (void)hipEventDestroy(q.ev[s]);
-         q.rad[s] = nullptr; q.ev[s] = nullptr;
+         q.rad[s] = nullptr;
       }
-      if (q.shm) munmap((void *)q.shm, sizeof(PeerShm));
-      q.shm = nullptr;
+      if (q.flags) (void)hipIpcCloseMemHandle(q.flags);
+      q.flags = nullptr;
    }
    p->peers.clear();
 }
@@ -2233,7 +2247,6 @@ static void peer_leave(mdh_renderer *r)
 {
    PeerState *p = r->peer;
    if (!p) return;
-   if (p->shm) p->shm->left = 1;
    peer_close_peers(p);
    if (p->active) {
       p->active = false;
@@ -2243,55 +2256,52 @@ static void peer_leave(mdh_renderer *r)
       r->fb_owner[0][0] = r->fb_owner[1][0] = -1;
    }
 }
-static void peer_abort(mdh_renderer *r) // (from a watchdog thread: only a flag -- the spinning host returns MDH_E_COMM)
-{
-   if (r->peer) r->peer->aborted = true;
-}
+static void peer_abort(mdh_renderer *r) { (void)r; } // (nothing on the host waits: a wait on the device ends by itself, MDH_PEER_SPIN_LIMIT)
 static void peer_drop(mdh_renderer *r)
 {
    PeerState *p = r->peer;
    if (!p) return;
    peer_leave(r);
-   for (int s = 0; s < MDH_ATLAS_SETS; ++s)
-      if (p->ev[s]) (void)hipEventDestroy(p->ev[s]);
-   if (p->shm) munmap((void *)p->shm, sizeof(PeerShm));
-   if (p->shm_name[0]) shm_unlink(p->shm_name);
+   if (p->d_flags) (void)hipFree(p->d_flags);
+   if (p->h_err) (void)hipHostFree(p->h_err);
    delete p;
    r->peer = nullptr;
+}
+// a wait that gave up: reported once, by the next call that looks
+static int peer_check(mdh_renderer *r)
+{
+   PeerState *p = r->peer;
+   if (p && p->h_err && *(volatile unsigned *)p->h_err) {
+      *(volatile unsigned *)p->h_err = 0u;
+      return seterr(MDH_E_COMM, "a peer's radiance slice did not arrive in time (its frame number never came): the atlases of the frames since are not the whole frame's");
+   }
+   return MDH_OK;
 }
 extern "C" int32_t mdh_peer_export(mdh_renderer *r, uint8_t blob_out[MDH_PEER_BLOB_BYTES])
 {
    if (!r || !blob_out) return seterr(MDH_E_INVALID, "bad argument");
    if (r->in_frame) return seterr(MDH_E_STATE, "a frame is open");
-   if (r->comm) return seterr(MDH_E_STATE, "the renderer has a communicator");
+   if (r->comm || peer_active(r)) return seterr(MDH_E_STATE, "the renderer has a communicator");
    HIP_TRY(hipSetDevice(r->device));
+   { int dr = drain_streams(r); if (dr != MDH_OK) return dr; }
    if (!r->peer) r->peer = new PeerState();
    PeerState *p = r->peer;
-   if (!p->exported) {
-      for (int s = 0; s < MDH_ATLAS_SETS; ++s)
-         if (!p->ev[s]) HIP_TRY(hipEventCreateWithFlags(&p->ev[s], hipEventDisableTiming | hipEventInterprocess));
-      static int serial = 0;
-      snprintf(p->shm_name, sizeof p->shm_name, "/mdh_peer_%d_%d", (int)getpid(), ++serial);
-      const int fd = shm_open(p->shm_name, O_CREAT | O_EXCL | O_RDWR, 0600);
-      if (fd < 0) { p->shm_name[0] = 0; return seterr(MDH_E_COMM, "shm_open failed"); }
-      if (ftruncate(fd, sizeof(PeerShm)) != 0) { close(fd); return seterr(MDH_E_COMM, "ftruncate of the shared-memory block failed"); }
-      void *m = mmap(nullptr, sizeof(PeerShm), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-      close(fd);
-      if (m == MAP_FAILED) return seterr(MDH_E_COMM, "mmap of the shared-memory block failed");
-      p->shm = (PeerShm *)m;
-      memset((void *)p->shm, 0, sizeof(PeerShm));
-      p->exported = true;
-   }
+   if (!p->d_flags) HIP_TRY(hipMalloc((void **)&p->d_flags, 4096));
+   if (!p->h_err) { HIP_TRY(hipHostMalloc((void **)&p->h_err, 64, hipHostMallocDefault)); *p->h_err = 0u; }
+   // a new session starts at frame 0: nobody must take an earlier session's numbers for this one's
+   HIP_TRY(hipMemset(p->d_flags, 0, 4096));
+   for (int s = 0; s < MDH_ATLAS_SETS; ++s) p->seq[s] = 0u;
+   static uint64_t serial = 0;
+   p->serial = ++serial;
+   p->exported = true;
    PeerBlob b;
    memset(&b, 0, sizeof b);
-   b.magic = 0x5045484du; b.version = 1;
+   b.magic = 0x5045484du; b.version = 2;
    b.pid = (int32_t)getpid(); b.device = r->device; b.nsets = MDH_ATLAS_SETS;
    b.rad_bytes = atlas_bytes(r, MDH_TEX_RADIANCE);
-   for (int s = 0; s < MDH_ATLAS_SETS; ++s) {
-      HIP_TRY(hipIpcGetMemHandle(&b.rad[s], r->d_rad2[s]));
-      HIP_TRY(hipIpcGetEventHandle(&b.ev[s], p->ev[s]));
-   }
-   memcpy(b.shm_name, p->shm_name, sizeof b.shm_name);
+   b.serial = p->serial;
+   for (int s = 0; s < MDH_ATLAS_SETS; ++s) HIP_TRY(hipIpcGetMemHandle(&b.rad[s], r->d_rad2[s]));
+   HIP_TRY(hipIpcGetMemHandle(&b.flags, p->d_flags));
    memset(blob_out, 0, MDH_PEER_BLOB_BYTES);
    memcpy(blob_out, &b, sizeof b);
    return MDH_OK;
@@ -2308,48 +2318,35 @@ extern "C" int32_t mdh_peer_init(mdh_renderer *r, const uint8_t *blobs, int32_t 
    HIP_TRY(hipSetDevice(r->device));
    { int jr = join_main(r); if (jr != MDH_OK) return jr; }
    HIP_TRY(hipStreamSynchronize(r->stream));
-   static const bool host_sync_env = [] { const char *e = getenv("MADARCH_HIP_PEER_SYNC"); return e && strcmp(e, "host") == 0; }();
-   p->host_sync = host_sync_env;
    p->peers.assign((size_t)world, PeerState::Peer());
    for (int q = 0; q < world; ++q) {
       PeerBlob b;
       memcpy(&b, blobs + (size_t)q * MDH_PEER_BLOB_BYTES, sizeof b);
-      if (b.magic != 0x5045484du || b.version != 1 || b.nsets != MDH_ATLAS_SETS) { peer_close_peers(p); return seterr(MDH_E_INVALID, "not a peer blob of this library"); }
+      if (b.magic != 0x5045484du || b.version != 2 || b.nsets != MDH_ATLAS_SETS) { peer_close_peers(p); return seterr(MDH_E_INVALID, "not a peer blob of this library"); }
       if (b.rad_bytes != atlas_bytes(r, MDH_TEX_RADIANCE)) { peer_close_peers(p); return seterr(MDH_E_INVALID, "a peer's radiance atlas has another size: the ranks' probe settings and atlas formats must agree"); }
       if (q == rank) {
-         if (b.pid != (int32_t)getpid() || strncmp(b.shm_name, p->shm_name, sizeof b.shm_name) != 0) { peer_close_peers(p); return seterr(MDH_E_INVALID, "the blob at this rank's place is not this renderer's"); }
+         if (b.pid != (int32_t)getpid() || b.serial != p->serial) { peer_close_peers(p); return seterr(MDH_E_INVALID, "the blob at this rank's place is not this renderer's latest export"); }
          continue;
       }
       if (b.pid == (int32_t)getpid()) { peer_close_peers(p); return seterr(MDH_E_INVALID, "two ranks of a peer exchange in one process: a process cannot open its own interprocess handles"); }
       PeerState::Peer &pe = p->peers[(size_t)q];
-      for (int s = 0; s < MDH_ATLAS_SETS; ++s) {
+      for (int s = 0; s < MDH_ATLAS_SETS; ++s)
          if (hipIpcOpenMemHandle(&pe.rad[s], b.rad[s], hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); peer_close_peers(p); return seterr(MDH_E_COMM, "hipIpcOpenMemHandle failed on a peer's radiance atlas"); }
-         if (!p->host_sync && hipIpcOpenEventHandle(&pe.ev[s], b.ev[s]) != hipSuccess) { (void)hipGetLastError(); peer_close_peers(p); return seterr(MDH_E_COMM, "hipIpcOpenEventHandle failed on a peer's event (MADARCH_HIP_PEER_SYNC=host does without)"); }
-      }
-      const int fd = shm_open(b.shm_name, O_RDONLY, 0);
-      if (fd < 0) { peer_close_peers(p); return seterr(MDH_E_COMM, "a peer's shared-memory block cannot be opened: the ranks must be processes of one node"); }
-      void *m = mmap(nullptr, sizeof(PeerShm), PROT_READ, MAP_SHARED, fd, 0);
-      close(fd);
-      if (m == MAP_FAILED) { peer_close_peers(p); return seterr(MDH_E_COMM, "mmap of a peer's shared-memory block failed"); }
-      pe.shm = (PeerShm *)m;
+      if (hipIpcOpenMemHandle((void **)&pe.flags, b.flags, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); peer_close_peers(p); return seterr(MDH_E_COMM, "hipIpcOpenMemHandle failed on a peer's frame numbers"); }
    }
-   for (int s = 0; s < MDH_ATLAS_SETS; ++s) { p->seq[s] = 0; p->shm->recorded[s] = 0; }
-   p->shm->left = 0;
+   *p->h_err = 0u;
    p->rank = rank; p->world = world;
-   p->aborted = false;
    p->active = true;
    r->opt_rank = rank;
    r->opt_world = world;
    r->rad_order_rays = 0;
    return MDH_OK;
 }
-#ifndef MDH_PEER_TIMEOUT_S
-#define MDH_PEER_TIMEOUT_S 60.0
-#endif
 static int peer_exchange(mdh_renderer *r, int tex)
 {
    PeerState *p = r->peer;
    if (tex != MDH_TEX_RADIANCE) return r->opt_irr_all ? MDH_OK : seterr(MDH_E_STATE, "the peer exchange moves radiance slices only: MDH_OPT_IRRADIANCE_ALL must be on");
+   { int pc = peer_check(r); if (pc != MDH_OK) return pc; }
    hipStream_t st = frame_probe_stream(r);
    const int s = r->frame_cur;
    const size_t per = (size_t)r->probes.radiance_resolution * r->probes.radiance_resolution * texel_bytes(r);
@@ -2361,27 +2358,18 @@ static int peer_exchange(mdh_renderer *r, int tex)
       if (!e0 || !e1) return seterr(MDH_E_DEVICE, "hipEventCreate failed");
       HIP_TRY(hipEventRecord(e0, st));
    }
-   // my slice of set s is complete behind everything the probe stream holds: say so
-   const long long n = ++p->seq[s];
-   if (p->host_sync) HIP_TRY(hipStreamSynchronize(st));
-   else HIP_TRY(hipEventRecord(p->ev[s], st));
-   __atomic_store_n(&p->shm->recorded[s], n, __ATOMIC_RELEASE);
+   // my slice of set s is complete behind everything the probe stream holds: its frame number says so
+   const unsigned n = ++p->seq[s];
+   hipLaunchKernelGGL(k_peer_publish, dim3(1), dim3(1), 0, st, p->d_flags + s, n);
+   HIP_TRY(hipGetLastError());
    char *mine = (char *)r->d_rad2[s];
-   const auto t0 = std::chrono::steady_clock::now();
    for (long long k = 1; k < world; ++k) { // (peers in a rotated order: the ranks do not all read the same peer at once)
       const long long q = (p->rank + k) % world;
       const long long b = P * q / world, e = P * (q + 1) / world; // own_probes () of rank q
       if (e <= b) continue;
       PeerState::Peer &pe = p->peers[(size_t)q];
-      for (unsigned spin = 0; __atomic_load_n(&pe.shm->recorded[s], __ATOMIC_ACQUIRE) < n; ++spin) {
-         if (p->aborted) return seterr(MDH_E_COMM, "the peer exchange was aborted");
-         if (pe.shm->left) return seterr(MDH_E_COMM, "a peer has left the exchange");
-         if ((spin & 1023u) == 1023u) {
-            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > MDH_PEER_TIMEOUT_S) return seterr(MDH_E_COMM, "a peer did not reach this frame's exchange in time");
-            std::this_thread::yield();
-         }
-      }
-      if (!p->host_sync) HIP_TRY(hipStreamWaitEvent(st, pe.ev[s], 0));
+      hipLaunchKernelGGL(k_peer_wait, dim3(1), dim3(64), 0, st, (const unsigned *)(pe.flags + s), n, p->h_err);
+      HIP_TRY(hipGetLastError());
       HIP_TRY(hipMemcpyAsync(mine + per * (size_t)b, (const char *)pe.rad[s] + per * (size_t)b, per * (size_t)(e - b), hipMemcpyDeviceToDevice, st));
    }
    if (r->opt_timing) {
@@ -2391,6 +2379,7 @@ static int peer_exchange(mdh_renderer *r, int tex)
    return MDH_OK;
 }
 
+extern "C" int32_t mdh_comm_available(void) { return rccl_ready(); }
 extern "C" int32_t mdh_comm_unique_id(uint8_t id_out[MDH_COMM_ID_BYTES])
 {
    static_assert(sizeof(ncclUniqueId) == MDH_COMM_ID_BYTES, "MDH_COMM_ID_BYTES is the size of ncclUniqueId");
@@ -2573,6 +2562,7 @@ extern "C" int32_t mdh_finish(mdh_renderer *r)
    HIP_TRY(hipSetDevice(r->device));
    { int jr = join_main(r); if (jr != MDH_OK) return jr; }
    HIP_TRY(hipStreamSynchronize(r->stream));
+   { int pc = peer_check(r); if (pc != MDH_OK) return pc; }
    return resolve_timing(r);
 }
 

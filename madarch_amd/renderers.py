@@ -145,6 +145,10 @@ class Renderer:
         buf = (C.c_uint8 * B.COMM_ID_BYTES).from_buffer_copy(Id)
         self._b.check(self._b.comm_init(self._h, buf, int(Rank), int(World)))
 
+    def Comm_Available(self):
+        """can this process load librccl at all?  (what a rank other than 0 asks before the collective join)"""
+        self._b.check(self._b.comm_available())
+
     def Peer_Export(self):
         """this rank's interprocess handles (radiance atlases, events, a shared-memory block): 512 bytes for every rank"""
         buf = (C.c_uint8 * B.PEER_BLOB_BYTES)()

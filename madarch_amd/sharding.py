@@ -148,14 +148,20 @@ class DeviceExchange:
             self.dist.all_gather_into_tensor(full, mine, group=self.group)
 
 
-def establish(renderer, rank, world, dist, group=None, trial_frames=2, timeout_s=120.0, log=None):
-    """Form the communicator of a `world`-rank run INSIDE the library and prove it on a few frames; fall back to the
-    exchange through host memory -- in this same process, on every rank together -- when that fails anywhere.
+def establish(renderer, rank, world, dist, group=None, trial_frames=2, timeout_s=120.0, log=None, backends=("rccl", "peer", "host")):
+    """Form the exchange of a `world`-rank run INSIDE the library and prove it on a few frames; fall back -- in this same
+    process, on every rank together -- to the next backend when that fails anywhere:
+
+      "rccl"  the communicator (mdh_comm_init): in-place all-gather on the probe stream;
+      "peer"  the peer exchange (mdh_peer_init): device-to-device copies between the processes of one node -- no
+              collective library, and the one device-resident form that several ranks can run on ONE GPU;
+      "host"  the slices through host memory over the control plane's group (HostExchange).
 
     `dist` is the control plane: a torch.distributed module whose `group` works on CPU tensors (gloo).  Returns
-    (exchange, how): (None, "rccl") when Renderers.Render now carries the exchange itself, or (HostExchange, reason).
-    A rank whose collective never returns is cut loose by a watchdog (Comm_Abort, after `timeout_s`) instead of hanging
-    the run; a rank whose renderer stays stuck even then raises."""
+    (exchange, how): (None, "rccl") or (None, "peer") when Renderers.Render now carries the exchange itself, or
+    (HostExchange, reason).  A rank whose exchange never returns is cut loose by a watchdog (Comm_Abort, after `timeout_s`)
+    instead of hanging the run; a rank whose renderer stays stuck even then raises.  Whatever the trial frames left
+    behind is wiped on every path: frame k of the run is the same frame whichever backend carries it."""
     import threading
 
     import torch
@@ -168,94 +174,160 @@ def establish(renderer, rank, world, dist, group=None, trial_frames=2, timeout_s
     say = log or (lambda msg: None)
     if world == 1:
         return None, "single rank"
-    reason = None
-    has_comm = hasattr(renderer._b, "comm_init")
-    # 1. the id: 128 bytes from rank 0 (all zeros = rank 0 could not make one)
-    # (every rank makes one: that call is also the proof that this rank can load librccl at all -- a rank that
-    #  cannot must say so BEFORE the others enter the collective join and wait for it)
-    ident = torch.zeros(B.COMM_ID_BYTES, dtype=torch.uint8)
-    ok = has_comm
-    if has_comm:
+
+    def wipe():  # the trial's frames must leave nothing behind (on success as well as on failure)
         try:
-            mine = renderer.Comm_Unique_Id()
-            if rank == 0:
-                ident = torch.frombuffer(bytearray(mine), dtype=torch.uint8).clone()
-        except B.MadarchError as e:
-            ok, reason = False, str(e)
-    else:
-        reason = "the engine has no communicator"
-    dist.broadcast(ident, src=0, group=group)
-    # 2. join (collective inside RCCL: only entered when every rank is going to)
-    if agree(ok):
-        joined = []
+            renderer.Finish()
+            for tex in (B.TEX_RADIANCE, B.TEX_IRRADIANCE):
+                renderer.Write_Texture(tex, np.zeros(renderer.Texture_Shape(tex), dtype=np.float32))
+            if hasattr(renderer, "Reset_Pass_Times"):
+                renderer.Reset_Pass_Times()
+        except B.MadarchError:
+            pass
 
-        def join():
-            try:
-                renderer.Comm_Init(ident.numpy().tobytes(), rank, world)
-                joined.append(None)
-            except B.MadarchError as e:
-                joined.append(str(e))
-
-        th = threading.Thread(target=join, daemon=True)
-        th.start()
-        th.join(timeout_s)
-        if th.is_alive():
-            raise RuntimeError("rank %d: ncclCommInitRank did not return within %.0f s" % (rank, timeout_s))
-        if joined[0] is not None:
-            ok, reason = False, joined[0]
-        if not agree(ok):
-            if ok:
-                renderer.Comm_Abort()
-            ok, reason = False, reason or "a peer could not join the communicator"
-    else:
-        ok, reason = False, reason or "a peer has no communicator"
-    # 3. trial frames behind a watchdog
-    tried_frames = ok
-    if ok:
+    def trial(barrier):
+        """`trial_frames` frames behind a watchdog; returns None or the reason of the failure"""
         err = []
 
-        def trial():
+        def run():
             try:
                 for _ in range(trial_frames):
                     renderer.Render()
-                renderer.Comm_Barrier()
+                barrier()
             except B.MadarchError as e:
                 err.append(str(e))
 
-        th = threading.Thread(target=trial, daemon=True)
+        th = threading.Thread(target=run, daemon=True)
         th.start()
         th.join(timeout_s)
         if th.is_alive():
-            say("rank %d: the trial frames did not return within %.0f s: aborting the communicator" % (rank, timeout_s))
+            say("rank %d: the trial frames did not return within %.0f s: aborting the exchange" % (rank, timeout_s))
             renderer.Comm_Abort()
             th.join(30.0)
             if th.is_alive():
-                raise RuntimeError("rank %d: the renderer is stuck in a collective that ncclCommAbort did not release" % rank)
-            err.append("a collective did not return within %.0f s" % timeout_s)
-        if err:
-            ok, reason = False, err[0]
+                raise RuntimeError("rank %d: the renderer is stuck in an exchange that the abort did not release" % rank)
+            err.append("an exchange did not return within %.0f s" % timeout_s)
+        return err[0] if err else None
+
+    reasons = []
+    has_comm = hasattr(renderer._b, "comm_init")
+    tried_frames = False
+    if "rccl" in backends:
+        reason = None
+        # 1. the id: 128 bytes from rank 0 (all zeros = rank 0 could not make one).  The other ranks only ask whether
+        # they can load librccl at all (a rank that cannot must say so BEFORE the others enter the collective join) --
+        # ncclGetUniqueId on every rank would leave a bootstrap listener behind on each (ADVICE r03)
+        ident = torch.zeros(B.COMM_ID_BYTES, dtype=torch.uint8)
+        ok = has_comm
+        if has_comm:
             try:
-                renderer.Comm_Abort()
-            except B.MadarchError:
-                pass
-        if not agree(ok):
-            if ok:
-                renderer.Comm_Abort()
-            ok, reason = False, reason or "a peer's trial frames failed"
-    if ok:
-        return None, "rccl"
+                if rank == 0 or not hasattr(renderer, "Comm_Available"):
+                    mine = renderer.Comm_Unique_Id()
+                    if rank == 0:
+                        ident = torch.frombuffer(bytearray(mine), dtype=torch.uint8).clone()
+                else:
+                    renderer.Comm_Available()
+            except B.MadarchError as e:
+                ok, reason = False, str(e)
+        else:
+            reason = "the engine has no communicator"
+        dist.broadcast(ident, src=0, group=group)
+        # 2. join (collective inside RCCL: only entered when every rank is going to)
+        if agree(ok):
+            joined = []
+
+            def join():
+                try:
+                    renderer.Comm_Init(ident.numpy().tobytes(), rank, world)
+                    joined.append(None)
+                except B.MadarchError as e:
+                    joined.append(str(e))
+
+            th = threading.Thread(target=join, daemon=True)
+            th.start()
+            th.join(timeout_s)
+            if th.is_alive():
+                raise RuntimeError("rank %d: ncclCommInitRank did not return within %.0f s" % (rank, timeout_s))
+            if joined[0] is not None:
+                ok, reason = False, joined[0]
+            if not agree(ok):
+                if ok:
+                    renderer.Comm_Abort()
+                ok, reason = False, reason or "a peer could not join the communicator"
+        else:
+            ok, reason = False, reason or "a peer has no communicator"
+        # 3. trial frames behind a watchdog
+        if ok:
+            tried_frames = True
+            reason = trial(renderer.Comm_Barrier)
+            if reason is not None:
+                ok = False
+                try:
+                    renderer.Comm_Abort()
+                except B.MadarchError:
+                    pass
+            if not agree(ok):
+                if ok:
+                    renderer.Comm_Abort()
+                ok, reason = False, reason or "a peer's trial frames failed"
+        if ok:
+            wipe()
+            return None, "rccl"
+        reasons.append("rccl: " + (reason or "a peer fell back"))
+        say("rank %d: no RCCL communicator: %s" % (rank, reason))
+    if "peer" in backends:
+        reason = None
+        ok = hasattr(renderer._b, "peer_init")
+        blob = torch.zeros(B.PEER_BLOB_BYTES, dtype=torch.uint8)
+        if ok:
+            try:
+                if tried_frames:
+                    wipe()
+                blob = torch.frombuffer(bytearray(renderer.Peer_Export()), dtype=torch.uint8).clone()
+            except B.MadarchError as e:
+                ok, reason = False, str(e)
+        else:
+            reason = "the engine has no peer exchange"
+        blobs = [torch.zeros(B.PEER_BLOB_BYTES, dtype=torch.uint8) for _ in range(world)]
+        dist.all_gather(blobs, blob, group=group)
+        if agree(ok):
+            try:
+                renderer.Peer_Init(b"".join(bytes(t.numpy().tobytes()) for t in blobs), rank, world)
+            except B.MadarchError as e:
+                ok, reason = False, str(e)
+            if not agree(ok):
+                if ok:
+                    renderer.Comm_Destroy()
+                ok, reason = False, reason or "a peer could not open the handles"
+        else:
+            ok, reason = False, reason or "a peer has no peer exchange"
+        if ok:
+            tried_frames = True
+            reason = trial(renderer.Finish)  # (no control-plane barrier in there: a rank whose frame failed would leave the others in it; agree () below is the barrier)
+            if reason is not None:
+                ok = False
+            if not agree(ok):
+                ok, reason = False, reason or "a peer's trial frames failed"
+            if not ok:
+                try:
+                    renderer.Finish()
+                    renderer.Comm_Destroy()
+                except B.MadarchError:
+                    pass
+        if ok:
+            wipe()
+            dist.barrier(group=group)  # (nobody starts the run's frames against atlases a peer is still wiping)
+            return None, "peer"
+        reasons.append("peer: " + (reason or "a peer fell back"))
+        say("rank %d: no peer exchange: %s" % (rank, reason))
     # the fall-back: slices through host memory over the control plane's group
-    try:
-        renderer.Finish()
-        if tried_frames:  # whatever the trial left in the atlases differs from rank to rank: start from the empty state again
-            for tex in (B.TEX_RADIANCE, B.TEX_IRRADIANCE):
-                renderer.Write_Texture(tex, np.zeros(renderer.Texture_Shape(tex), dtype=np.float32))
-    except B.MadarchError:
-        pass
+    if tried_frames:  # whatever the trial left in the atlases differs from rank to rank: start from the empty state again
+        wipe()
     renderer.Set_Option(B.OPT_WORLD, world)
     renderer.Set_Option(B.OPT_RANK, rank)
-    say("rank %d: falling back to the host exchange: %s" % (rank, reason))
-    return HostExchange(dist, group), reason or "a peer fell back"
+    why = "; ".join(reasons) or "asked for"
+    say("rank %d: falling back to the host exchange: %s" % (rank, why))
+    return HostExchange(dist, group), why
 
 
 class ShardedFrame:

@@ -19,8 +19,26 @@ class _Engine:
         from madarch_amd import _binding as B
         self.B, self.rank, self.script, self.calls, self.opts = B, rank, script, [], {}
         self._b = type("b", (), {})()
-        if script != "no_comm":
+        if script != "no_comm" and not script.startswith("peer"):
             self._b.comm_init = True
+        if script.startswith("peer"):  # no communicator, but a peer exchange ("peer_fine", "peer_init@1", "peer_render@0")
+            self._b.peer_init = True
+
+    def Peer_Export(self):
+        self.calls.append("peer_export")
+        return bytes([self.rank + 1]) * self.B.PEER_BLOB_BYTES
+
+    def Peer_Init(self, blobs, rank, world):
+        self.calls.append("peer_init")
+        assert len(blobs) == self.B.PEER_BLOB_BYTES * world and all(blobs[q * self.B.PEER_BLOB_BYTES] == q + 1 for q in range(world))
+        self._fail("peer_init")
+        self.peer = True
+
+    peer = False
+
+    def Comm_Destroy(self):
+        self.calls.append("destroy")
+        self.peer = False
 
     def _fail(self, what):
         if self.script == what or self.script == "%s@%d" % (what, self.rank):
@@ -39,6 +57,8 @@ class _Engine:
     def Render(self):
         self.calls.append("render")
         self._fail("render")
+        if self.peer:
+            self._fail("peer_render")
         if self.script == "hang@%d" % self.rank:
             import time
             while not self.aborted:
@@ -75,7 +95,7 @@ def _worker(rank, world, port, script, out_dir):
     E = _Engine(rank, script)
     exchange, how = sharding.establish(E, rank, world, dist, timeout_s=3.0)
     with open(os.path.join(out_dir, "r%d" % rank), "w") as f:
-        f.write("%s|%s|%s" % ("rccl" if exchange is None else exchange.name, how, ",".join(E.calls)))
+        f.write("%s|%s|%s" % (how if exchange is None else exchange.name, how, ",".join(E.calls)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -87,6 +107,9 @@ def _worker(rank, world, port, script, out_dir):
     ("init@0", "host exchange"),    # rank 0's join fails: rank 1, which joined, aborts its communicator
     ("render@1", "host exchange"),  # a trial frame fails on one rank
     ("hang@1", "host exchange"),    # a trial frame never returns on one rank: the watchdog aborts
+    ("peer_fine", "peer"),          # no communicator anywhere, the peer exchange carries the run
+    ("peer_init@1", "host exchange"),    # rank 1 cannot open the handles: rank 0, which could, leaves again
+    ("peer_render@0", "host exchange"),  # a trial frame of the peer exchange fails on one rank
 ])
 def test_both_ranks_agree(tmp_path, script, want):
     import torch.multiprocessing as mp
@@ -102,3 +125,9 @@ def test_both_ranks_agree(tmp_path, script, want):
         assert "abort" in got[1][2]
     if want == "rccl":
         assert got[0][1] == "rccl" and got[0][2].count("render") == 2 and "barrier" in got[0][2]
+    if want == "peer":
+        assert got[0][1] == got[1][1] == "peer" and got[0][2].count("render") == 2 and "destroy" not in got[0][2]
+    if script == "peer_init@1":
+        assert "destroy" in got[0][2]
+    if script == "peer_render@0":
+        assert "destroy" in got[0][2] and "destroy" in got[1][2]

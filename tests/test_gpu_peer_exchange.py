@@ -1,6 +1,6 @@
 """The sharded frame with the PEER exchange (mdh_peer_export / mdh_peer_init): several PROCESSES on the one GPU of the test
 box, each a rank with its own renderer, exchanging their radiance slices device to device (hipIpcMemHandle, interprocess
-events, no collective library and no host copy).  RCCL refuses two ranks of a communicator on one device; this backend is
+frame numbers polled on the device, no collective library and no host copy).  RCCL refuses two ranks of a communicator on one device; this backend is
 the device-resident exchange that more than one process can run here.  The ranks' framebuffers must add up to the whole
 frame and every rank's atlases must be the whole frame's, bit for bit, with frames in flight."""
 import multiprocessing as mp
@@ -50,10 +50,10 @@ def _rank(rank, world, probes_name, overlap, frames, sync, conn):
 
 
 @pytest.mark.parametrize("world,probes_name,overlap,sync", [(2, "SMALL_PROBES", 2, None), (2, "ODD_PROBES", 2, None), (3, "SMALL_PROBES", 0, None),
-                                                            (2, "SMALL_PROBES", 2, "host")])
+                                                            (4, "ODD_PROBES", 2, None)])
 def test_peer_exchange_between_processes_on_one_gpu(hip, world, probes_name, overlap, sync):
     import helpers
-    frames = 4
+    frames = 70  # (more than any ring of signals a runtime might keep per event: round 4's first form failed after some tens)
     want = helpers.snapshot(helpers.make("global_illumination", 96, 64, hip, probes=getattr(helpers, probes_name)), frames)
     ctx = mp.get_context("spawn")  # fresh processes: nothing of this process's GPU state is inherited
     pipes, procs = [], []
