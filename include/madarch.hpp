@@ -12,6 +12,10 @@
 
 #include "madarch_hip.h"
 
+#include <cstdlib>
+#include <algorithm>
+#include <sys/stat.h>
+#include <atomic>
 #include <array>
 #include <chrono>
 #include <cstdio>
@@ -359,28 +363,63 @@ class Renderer {
    // ---- one frame on the N GPUs of a node, one process per GPU (include/madarch_hip.h, mdh_comm_*): after Join_Node,
    // Render of every rank is one frame of the sharded schedule.  The 128-byte communicator id travels from rank 0 to
    // the others through `Id_File` (written under a temporary name and renamed, so a reader never sees half of it).
-   void Join_Node(int Rank, int World, const std::string &Id_File, double Timeout_S = 120.0) const
+   // A file left by an earlier run must never be taken for this one's: rank 0 removes it (and its temporary) BEFORE it
+   // makes the new id and again once every rank has joined; the others only accept a file that is no older than their
+   // own call (minus `Timeout_S`: the ranks of a run start within that) and, when the launcher hands every rank the same
+   // `Nonce`, one that carries it.  The collective join itself runs under the same timeout: a rank whose peers never
+   // arrive reports that and leaves the process (ncclCommInitRank cannot be cancelled) instead of hanging for ever.
+   void Join_Node(int Rank, int World, const std::string &Id_File, double Timeout_S = 120.0, const std::string &Nonce = "") const
    {
       uint8_t id[MDH_COMM_ID_BYTES];
+      const std::string tmp = Id_File + ".tmp";
+      const auto wall0 = std::chrono::system_clock::now();
       if (Rank == 0) {
+         std::remove(Id_File.c_str());
+         std::remove(tmp.c_str());
          Check(mdh_comm_unique_id(id));
-         const std::string tmp = Id_File + ".tmp";
          FILE *f = fopen(tmp.c_str(), "wb");
-         if (!f || fwrite(id, 1, sizeof id, f) != sizeof id) throw Program_Error("cannot write the communicator id file");
+         if (!f || fwrite(id, 1, sizeof id, f) != sizeof id || (!Nonce.empty() && fwrite(Nonce.data(), 1, Nonce.size(), f) != Nonce.size())) throw Program_Error("cannot write the communicator id file");
          fclose(f);
          if (rename(tmp.c_str(), Id_File.c_str()) != 0) throw Program_Error("cannot publish the communicator id file");
       } else {
          const auto t0 = std::chrono::steady_clock::now();
          for (;;) {
-            FILE *f = fopen(Id_File.c_str(), "rb");
-            const size_t n = f ? fread(id, 1, sizeof id, f) : 0;
-            if (f) fclose(f);
-            if (n == sizeof id) break;
-            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > Timeout_S) throw Program_Error("rank 0 never published the communicator id file");
+            bool fresh = false;
+            struct stat sb;
+            if (stat(Id_File.c_str(), &sb) == 0) {
+               const double age_before_call = std::chrono::duration<double>(wall0 - std::chrono::system_clock::from_time_t(sb.st_mtime)).count();
+               fresh = age_before_call <= Timeout_S;
+            }
+            if (fresh) {
+               std::vector<uint8_t> buf(sizeof id + Nonce.size() + 1);
+               FILE *f = fopen(Id_File.c_str(), "rb");
+               const size_t n = f ? fread(buf.data(), 1, buf.size(), f) : 0;
+               if (f) fclose(f);
+               if (n == sizeof id + Nonce.size() && std::equal(Nonce.begin(), Nonce.end(), buf.begin() + sizeof id)) { std::copy(buf.begin(), buf.begin() + sizeof id, id); break; }
+            }
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > Timeout_S) throw Program_Error("rank 0 never published the communicator id file of this run");
             std::this_thread::sleep_for(std::chrono::milliseconds(20));
          }
       }
-      Check(mdh_comm_init(h_.get(), id, Rank, World));
+      // the join under a watchdog
+      std::atomic<int> state{0}; // 0 joining, 1 joined, 2 failed
+      std::string error;
+      mdh_renderer *h = h_.get();
+      std::thread joiner([&] {
+         const int32_t rc = mdh_comm_init(h, id, Rank, World);
+         if (rc != 0) error = mdh_last_error();
+         state = rc == 0 ? 1 : 2;
+      });
+      const auto t1 = std::chrono::steady_clock::now();
+      while (state == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count() <= Timeout_S) std::this_thread::sleep_for(std::chrono::milliseconds(5));
+      if (state == 0) {
+         fprintf(stderr, "rank %d: the ranks of the node did not all join within %.0f s: leaving\n", Rank, Timeout_S);
+         (void)mdh_comm_abort(h);
+         std::_Exit(70);
+      }
+      joiner.join();
+      if (Rank == 0) std::remove(Id_File.c_str()); // (every rank holds the id: the collective join has returned)
+      if (state == 2) throw Program_Error(error);
    }
    void Leave_Node() const { Check(mdh_comm_destroy(h_.get())); }
    void Barrier() const { Check(mdh_comm_barrier(h_.get())); }

@@ -14,6 +14,7 @@
 #include <hip/hiprtc.h> // types only: the library is opened on first use (no link-time dependency)
 #include <rccl/rccl.h>  // types only, likewise: librccl is opened by the first mdh_comm_* call
 
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -328,6 +329,11 @@ struct mdh_renderer {
    // the communicator of a sharded run (mdh_comm_init): one rank per process and GPU.  With it mdh_render runs the
    // exchange of the atlas slices itself, on the probe stream, between the probe passes.
    ncclComm_t comm = nullptr;
+   // mdh_comm_abort may come from a watchdog thread while the owning thread is inside a collective: the
+   // watchdog then only aborts (ncclCommAbort, once) and raises the flag; the owning thread forgets the handle when its
+   // call returns.  With nobody inside, the aborting thread owns the state and drops everything itself.
+   std::atomic<bool> comm_aborted{false};
+   std::atomic<int> comm_busy{0};
    double *d_comm_scratch = nullptr; // barrier / max reductions
    struct PeerState *peer = nullptr; // the peer exchange (mdh_peer_init): the same sharded frame, its exchange as copies
    bool irr_lds_granted = false; // k_irradiance may use up to 160 KiB of dynamic LDS on this renderer's device
@@ -1650,7 +1656,8 @@ static int run_pass(mdh_renderer *r, int pass, hipStream_t st, int src, int dst,
       case MDH_PASS_VISIBILITY: snprintf(kname, sizeof kname, "k_visibility<%d>", pf); break;
       case MDH_PASS_SCATTERING: snprintf(kname, sizeof kname, MDH_SCAT_SPLIT ? "k_scat_march<%d>" : "k_scattering<%d>", pf); break;
       case MDH_PASS_SCREEN: {
-         const bool alt = r->opt_mode == 0 && (r->opt_spec == 1 || r->opt_spec == 3 || (r->opt_spec == 2 && r->opt_mips));
+         // (the predicate of launch_screen_m below: mode 2 runs the variant of the optional paths only when a mip chain really exists)
+         const bool alt = r->opt_mode == 0 && (r->opt_spec == 1 || r->opt_spec == 3 || (r->opt_spec == 2 && r->opt_mips && r->d_rad_mips[dst]));
          snprintf(kname, sizeof kname, "k_screen<%d, %d, %s, %s>", pf | (pow2 && r->opt_mode == 0 && !alt ? MDH_PF_POW2 : 0), r->opt_mode, r->opt_gbuffer ? "true" : "false", alt ? "true" : "false");
          break;
       }
@@ -1897,6 +1904,11 @@ static int run_pass(mdh_renderer *r, int pass, hipStream_t st, int src, int dst,
       }
       if (sort_after) { // later passes' order from this pass's durations, into the buffer no pass in flight reads
          HIP_TRY(hipGetLastError());
+         if (r->opt_timing && e1) { // (the sort is no part of the pass's time: ADVICE r03)
+            HIP_TRY(hipEventRecord(e1, st));
+            r->pending.push_back({pass, e0, e1});
+            e0 = e1 = nullptr;
+         }
          const int nb = r->scr_order_cur == 0 ? 1 : 0;
          // (passes that read that buffer were launched before the previous sort; on the other screen stream nothing
          //  orders them against this stream when no probe passes run: wait for what that stream holds)
@@ -1944,7 +1956,7 @@ static int run_pass(mdh_renderer *r, int pass, hipStream_t st, int src, int dst,
       int trc = table_release(r, st);
       if (trc != MDH_OK) return trc;
    }
-   if (r->opt_timing) {
+   if (r->opt_timing && e1) {
       HIP_TRY(hipEventRecord(e1, st));
       r->pending.push_back({pass, e0, e1}); // (folded at frame boundaries: bound_timing)
    }
@@ -1979,13 +1991,14 @@ extern "C" int32_t mdh_render_pass(mdh_renderer *r, int32_t pass)
 // independent of each other.  Every kernel of a frame ends in a tail of a few slow wavefronts
 // (the radiance pass spends more than half of its time below 20 % occupancy; the irradiance pass
 // fills a fraction of the chip), so serial frames leave the chip idle a good part of the time.
-// Pipelined frames use three HIP streams, two atlas sets and two framebuffers; frame N, parity c:
-//    probe stream: wait screen(N-2) (last reader of atlas set c)
-//                  -> radiance(irr[c^1] -> rad[c]) -> irradiance(rad[c] -> irr[c]) -> ev_probe[c]
-//    screen stream c (main / alternate): wait ev_probe[c] -> screen(atlas set c -> framebuffer c)
-// so that screen(N+1) starts while screen(N) drains and the probe passes of N+2 fill in behind.
-// With volumetrics or the geometry buffer (single buffers) all screen passes stay on the main
-// stream.  Anything outside a pipelined frame first orders the main stream after the others
+// Pipelined frames use three HIP streams (four with volumetrics), MDH_ATLAS_SETS = 3 atlas sets and two framebuffers;
+// frame N works on set c = N mod 3 and reads the irradiance of set `last` = (N - 1) mod 3, its screen pass draws on
+// stream and framebuffer p = N mod 2:
+//    probe stream: wait screen(N-3) (the last reader of atlas set c)
+//                  -> radiance(irr[last] -> rad[c]) -> [exchange] -> irradiance(rad[c] -> irr[c]) -> ev_probe[c]
+//    volumetric stream (renderers with volumetrics): wait screen(N-3) -> visibility, scattering of set c -> ev_vol[c]
+//    screen stream p (main / alternate): wait ev_probe[c] (and ev_vol[c]) -> screen(atlas set c -> framebuffer p)
+// so that screen(N+1) starts while screen(N) drains and the probe passes of N+2 fill in behind.  Anything outside a pipelined frame first orders the main stream after the others
 // (join_main), and the next pipelined frame orders the others after the main stream: results are
 // those of the serial order bit for bit.
 // A frame in three steps, for callers that put work of their own between the passes (the
@@ -2415,19 +2428,38 @@ extern "C" int32_t mdh_comm_init(mdh_renderer *r, const uint8_t id_in[MDH_COMM_I
    r->rad_order_rays = 0; // (the stored ray order is of another slice)
    return MDH_OK;
 }
-static int comm_drop(mdh_renderer *r, bool abort)
+// the renderer is rank 0 of 1 again (the handle itself is the caller's business)
+static void comm_forget(mdh_renderer *r)
 {
-   if (!r->comm) return MDH_OK;
-   ncclComm_t c = r->comm;
    r->comm = nullptr;
+   r->comm_aborted = false;
    r->opt_rank = 0;
    r->opt_world = 1;
    r->rad_order_rays = 0;
    r->fb_owner[0][0] = r->fb_owner[1][0] = -1; // (the framebuffers hold a rank's tiles: cleared before they are drawn whole)
-   if (abort) RCCL_TRY(rccl_api().CommAbort(c));
-   else RCCL_TRY(rccl_api().CommDestroy(c));
+}
+static int comm_drop(mdh_renderer *r, bool abort)
+{
+   if (!r->comm) return MDH_OK;
+   ncclComm_t c = r->comm;
+   if (r->comm_aborted) { comm_forget(r); return MDH_OK; } // (a watchdog has aborted -- and thereby freed -- it already)
+   if (abort) { comm_forget(r); RCCL_TRY(rccl_api().CommAbort(c)); return MDH_OK; }
+   RCCL_TRY(rccl_api().CommDestroy(c)); // (a failed destroy keeps the handle: the caller may abort it)
+   comm_forget(r);
    return MDH_OK;
 }
+// the owning thread's view of a watchdog's abort: the handle is gone
+static int comm_gone(mdh_renderer *r)
+{
+   comm_forget(r);
+   if (r->in_frame) { r->in_frame = false; r->main_dirty = true; }
+   return seterr(MDH_E_COMM, "the communicator was aborted (mdh_comm_abort)");
+}
+struct CommBusy { // the owning thread is inside RCCL with r->comm
+   mdh_renderer *r;
+   explicit CommBusy(mdh_renderer *r_) : r(r_) { ++r->comm_busy; }
+   ~CommBusy() { --r->comm_busy; }
+};
 extern "C" int32_t mdh_comm_destroy(mdh_renderer *r)
 {
    if (!r) return seterr(MDH_E_INVALID, "null renderer");
@@ -2442,13 +2474,20 @@ extern "C" int32_t mdh_comm_abort(mdh_renderer *r)
 {
    if (!r) return seterr(MDH_E_INVALID, "null renderer");
    (void)hipSetDevice(r->device);
+   if (r->peer && !r->comm) { peer_abort(r); if (r->in_frame) { r->in_frame = false; r->main_dirty = true; } return MDH_OK; }
+   ncclComm_t c = r->comm;
+   if (!c) return MDH_OK;
+   if (r->comm_busy.load() > 0) { // another thread is inside a collective: abort only, that thread forgets the handle when its call returns
+      if (!r->comm_aborted.exchange(true)) RCCL_TRY(rccl_api().CommAbort(c));
+      return MDH_OK;
+   }
    if (r->in_frame) { r->in_frame = false; r->main_dirty = true; }
-   if (r->peer) { peer_abort(r); return MDH_OK; } // (a host spinning for a peer's frame number gives up; the handles are closed by mdh_comm_destroy / mdh_destroy)
    return comm_drop(r, true);
 }
 // an asynchronous failure of the communicator (a peer died, a transport error) surfaces here
 static int comm_check(mdh_renderer *r)
 {
+   if (r->comm_aborted) return comm_gone(r);
    ncclResult_t ae = ncclSuccess;
    RCCL_TRY(rccl_api().CommGetAsyncError(r->comm, &ae));
    if (ae != ncclSuccess && ae != ncclInProgress) {
@@ -2470,6 +2509,8 @@ extern "C" int32_t mdh_frame_exchange(mdh_renderer *r, int32_t tex)
    if (!r->in_frame) return seterr(MDH_E_STATE, "no open frame");
    if (peer_active(r)) return r->opt_mode != 0 ? MDH_OK : peer_exchange(r, tex);
    if (!r->comm || r->opt_mode != 0) return MDH_OK;
+   if (r->comm_aborted) return comm_gone(r);
+   CommBusy busy(r);
    const RcclApi &n = rccl_api();
    hipStream_t st = frame_probe_stream(r);
    char *buf = (char *)(tex == MDH_TEX_RADIANCE ? r->d_rad2[r->frame_cur] : r->d_irr2[r->frame_cur]);
@@ -2484,20 +2525,30 @@ extern "C" int32_t mdh_frame_exchange(mdh_renderer *r, int32_t tex)
       HIP_TRY(hipEventRecord(e0, st));
    }
    static const bool force_bcast = [] { const char *e = getenv("MADARCH_HIP_EXCHANGE"); return e && strcmp(e, "broadcast") == 0; }();
+   // (a failed collective hands its timing events back: ADVICE r03)
+   auto failed = [&](const char *what, ncclResult_t e) {
+      if (e0) r->free_events.push_back(e0);
+      if (e1) r->free_events.push_back(e1);
+      snprintf(g_err, sizeof g_err, "%s failed: %s", what, n.GetErrorString(e));
+      return r->comm_aborted ? comm_gone(r) : (int)MDH_E_COMM;
+   };
    if (P % world == 0 && !force_bcast) {
       const size_t count = per * (size_t)(P / world);
-      RCCL_TRY(n.AllGather(buf + count * (size_t)r->opt_rank, buf, count, ncclChar, r->comm, st));
+      const ncclResult_t ar = n.AllGather(buf + count * (size_t)r->opt_rank, buf, count, ncclChar, r->comm, st);
+      if (ar != ncclSuccess) return failed("ncclAllGather", ar);
    } else {
-      RCCL_TRY(n.GroupStart());
+      ncclResult_t gr = n.GroupStart();
+      if (gr != ncclSuccess) return failed("ncclGroupStart", gr);
       for (long long q = 0; q < world; ++q) {
          const long long b = P * q / world, e = P * (q + 1) / world; // own_probes () of rank q
          if (e > b) {
             ncclResult_t br = n.Broadcast(buf + per * (size_t)b, buf + per * (size_t)b, per * (size_t)(e - b), ncclChar, (int)q, r->comm, st);
-            if (br != ncclSuccess) { (void)n.GroupEnd(); snprintf(g_err, sizeof g_err, "ncclBroadcast failed: %s", n.GetErrorString(br)); return MDH_E_COMM; }
+            if (br != ncclSuccess) { (void)n.GroupEnd(); return failed("ncclBroadcast", br); }
          }
       }
-      RCCL_TRY(n.GroupEnd());
+      if ((gr = n.GroupEnd()) != ncclSuccess) return failed("ncclGroupEnd", gr);
    }
+   if (r->comm_aborted) { if (e0) r->free_events.push_back(e0); if (e1) r->free_events.push_back(e1); return comm_gone(r); }
    if (r->opt_timing) {
       HIP_TRY(hipEventRecord(e1, st));
       r->pending.push_back({MDH_PASS_EXCHANGE, e0, e1});
@@ -2511,6 +2562,8 @@ extern "C" int32_t mdh_comm_barrier(mdh_renderer *r)
    int rc = mdh_finish(r);
    if (rc == MDH_OK && peer_active(r)) return seterr(MDH_E_STATE, "the peer exchange has no collectives: the host's own channel is the barrier");
    if (rc != MDH_OK || !r->comm) return rc;
+   if (r->comm_aborted) return comm_gone(r);
+   CommBusy busy(r);
    HIP_TRY(hipMemsetAsync(r->d_comm_scratch, 0, sizeof(double), r->stream));
    RCCL_TRY(rccl_api().AllReduce(r->d_comm_scratch, r->d_comm_scratch, 1, ncclFloat64, ncclSum, r->comm, r->stream));
    HIP_TRY(hipStreamSynchronize(r->stream));
@@ -2522,6 +2575,8 @@ extern "C" int32_t mdh_comm_max_f64(mdh_renderer *r, double *value)
    if (r->in_frame) return seterr(MDH_E_STATE, "a frame is open");
    if (peer_active(r)) return seterr(MDH_E_STATE, "the peer exchange has no collectives");
    if (!r->comm) return MDH_OK;
+   if (r->comm_aborted) return comm_gone(r);
+   CommBusy busy(r);
    HIP_TRY(hipSetDevice(r->device));
    { int jr = join_main(r); if (jr != MDH_OK) return jr; }
    HIP_TRY(hipMemcpyAsync(r->d_comm_scratch + 1, value, sizeof(double), hipMemcpyHostToDevice, r->stream));
@@ -2537,6 +2592,8 @@ extern "C" int32_t mdh_comm_reduce_framebuffer(mdh_renderer *r, int32_t root)
    if (peer_active(r)) return seterr(MDH_E_STATE, "the peer exchange has no collectives: read every rank's framebuffer and add them");
    if (!r->comm) return MDH_OK;
    if (root < 0 || root >= r->opt_world) return seterr(MDH_E_INVALID, "root is not a rank");
+   if (r->comm_aborted) return comm_gone(r);
+   CommBusy busy(r);
    HIP_TRY(hipSetDevice(r->device));
    { int jr = join_main(r); if (jr != MDH_OK) return jr; }
    r->main_dirty = true;

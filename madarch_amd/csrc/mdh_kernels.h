@@ -102,7 +102,7 @@ struct ScreenArgs {
    const unsigned *order; // [n_own] the own index at every place of the launch, or null: image order
    unsigned char *cost;   // [n_own] written by the pass when not null: the tile's wavefront duration as a sort key
 };
-// a wavefront's duration in shader clocks as a key of the counting sort (k_rad_hist ...)
+// a wavefront's duration in ticks of s_memtime (which need not be the shader clock) as a key of the counting sort (k_rad_hist ...)
 #ifndef MDH_TILE_COST_SHIFT
 #define MDH_TILE_COST_SHIFT 12
 #endif
@@ -155,6 +155,11 @@ __global__ __launch_bounds__(MDH_BLOCK, MDH_OCC(PART, MODE)) void k_screen(KScen
    }
 #if MDH_RELOAD_ARGS
    struct KArgs { KScene sc; KProbes pr; KVolumetrics vol; KCamera cam; ScreenArgs a; };
+   // (the kernel argument segment lays the by-value arguments out like this struct: each at its natural alignment, all of
+   //  them 8-byte aligned aggregates of 4- and 8-byte members -- checked here rather than assumed)
+   static_assert(alignof(KScene) == 8 && alignof(KProbes) == 8 && alignof(KVolumetrics) == 8 && alignof(ScreenArgs) == 8 && alignof(KCamera) == 4, "kernel argument alignments");
+   static_assert(__builtin_offsetof(KArgs, pr) == sizeof(KScene) && __builtin_offsetof(KArgs, vol) == sizeof(KScene) + sizeof(KProbes) &&
+                 __builtin_offsetof(KArgs, cam) == sizeof(KScene) + sizeof(KProbes) + sizeof(KVolumetrics) && __builtin_offsetof(KArgs, a) % 8 == 0, "KArgs is the kernel argument segment of k_screen");
    typedef const KArgs __attribute__((address_space(4))) *KArgsPtr; // constant address space: scalar loads
    KArgsPtr ka = (KArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
    asm volatile("" : "+s"(ka));
@@ -333,6 +338,8 @@ template <int PART, bool SMALL = false> __global__ __launch_bounds__(MDH_BLOCK, 
    // cannot trace: the same integer operations on the same inputs.
    {
       struct KArgs { KScene sc; KProbes pr; int first_round; RadOrder ro; };
+      static_assert(alignof(RadOrder) == 8 && __builtin_offsetof(KArgs, pr) == sizeof(KScene) && __builtin_offsetof(KArgs, first_round) == sizeof(KScene) + sizeof(KProbes) &&
+                    __builtin_offsetof(KArgs, ro) == sizeof(KScene) + sizeof(KProbes) + 8, "KArgs is the kernel argument segment of k_radiance");
       typedef const KArgs __attribute__((address_space(4))) *KArgsPtr;
       KArgsPtr ka = (KArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
       asm volatile("" : "+s"(ka));
