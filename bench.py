@@ -237,7 +237,7 @@ def main():
     ap.add_argument("--animate-light", action="store_true", help="set the light anew before every frame, as the example's main loop does (global_illumination/main.adb:219-232)")
     ap.add_argument("--rehearse-rccl", action="store_true", help="one rank, but with a (one-rank) communicator: every frame runs the library's RCCL exchange (rehearsal of the N > 1 code path on one GPU)")
     ap.add_argument("--rehearse-cpu", action="store_true", help="TEST ONLY: this file's N-rank control flow on the CPU -- gloo, the oracle as the engine, a tiny frame; prints a line marked as a rehearsal, never a result")
-    ap.add_argument("--numerics", default="exact", choices=("exact", "fast"), help="fast = the LABELLED EXPERIMENT build (make -C madarch_amd/csrc fast: hardware sqrt / rcp / log / exp, tolerance only); the line then carries config.numerics = fast and is no result of the product")
+    ap.add_argument("--numerics", default="exact", choices=("exact", "fast", "hybrid"), help="hybrid = the second labelled experiment (exact march loops, hardware arithmetic in shading only); fast = the LABELLED EXPERIMENT build (make -C madarch_amd/csrc fast: hardware sqrt / rcp / log / exp, tolerance only); the line then carries config.numerics = fast and is no result of the product")
     ap.add_argument("--screen-order", type=int, default=None, help="MDH_OPT_SCREEN_ORDER value (default: the library's)")
     ap.add_argument("--comm-timeout-s", type=float, default=120.0, help="watchdog of the communicator's join and trial frames (N > 1)")
     ap.add_argument("--exchange", default="auto", choices=("auto", "rccl", "peer", "host"), help="N > 1: the exchange backend (auto: rccl, then the peer exchange, then host memory; each falls back to the next)")
@@ -272,8 +272,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    if args.numerics == "fast":  # (selected before the binding reads the variable)
-        os.environ["MADARCH_HIP_LIBRARY"] = os.path.join(ROOT, "madarch_amd", "csrc", "libmadarch_hip_fast.so")
+    if args.numerics != "exact":  # (selected before the binding reads the variable)
+        os.environ["MADARCH_HIP_LIBRARY"] = os.path.join(ROOT, "madarch_amd", "csrc", "libmadarch_hip_%s.so" % args.numerics)
     from madarch_amd import _binding as B
     from madarch_amd import sharding
 
@@ -447,7 +447,7 @@ def main():
                        "screen_mode": mode, "parallelism": parallelism, "exchange": how,
                        "frame_overlap": overlap, "animated_light": bool(animate), "swap_buffers": bool(args.swap_buffers),
                        "radiance_order": int(R.Get_Option(B.OPT_RADIANCE_ORDER)), "screen_order": int(R.Get_Option(B.OPT_SCREEN_ORDER)),
-                       "numerics": "fast" if R.Get_Option(B.OPT_NUMERICS) else "exact"},
+                       "numerics": ("exact", "fast", "hybrid")[R.Get_Option(B.OPT_NUMERICS)]},
             # schema 4: `roofline` = the kernel's algorithmic bytes of ALL timed launches over the timed
             # region -- the figure that follows from the driver-timed `value` (consecutive frames draw on two streams, so
             # launches of this kernel overlap one another and each is stretched by its neighbours); the per-launch duration

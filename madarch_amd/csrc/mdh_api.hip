@@ -42,8 +42,10 @@ static int seterr(int code, const char *msg)
 extern "C" const char *mdh_last_error(void) { return g_err; }
 #if MDH_FAST_NUMERICS
 extern "C" const char *mdh_version(void) { return "madarch-hip 0.3 (gfx950) FAST-NUMERICS EXPERIMENT BUILD: tolerance only, not the oracle's bits"; }
+#elif MDH_HYBRID_NUMERICS
+extern "C" const char *mdh_version(void) { return "madarch-hip 0.4 (gfx950) HYBRID-NUMERICS EXPERIMENT BUILD: exact march loops and primary ray, hardware rcp / sqrt / exp / log in shading"; }
 #else
-extern "C" const char *mdh_version(void) { return "madarch-hip 0.3 (gfx950)"; }
+extern "C" const char *mdh_version(void) { return "madarch-hip 0.4 (gfx950)"; }
 #endif
 
 // ------------------------------------------------------------------ std140 layout
@@ -1031,7 +1033,7 @@ extern "C" int32_t mdh_set_option(mdh_renderer *r, int32_t option, int32_t value
    case MDH_OPT_HYSTERESIS_PERMILLE: if (value < 0 || value > 999) return seterr(MDH_E_INVALID, "hysteresis is 0 .. 999 per mille"); r->opt_hyst = value; break;
    case MDH_OPT_RADIANCE_ORDER: r->opt_rad_order = value ? 1 : 0; r->rad_order_rays = 0; break;
    case MDH_OPT_SCREEN_ORDER: r->opt_scr_order = value ? 1 : 0; r->scr_order_cur = -1; break;
-   case MDH_OPT_NUMERICS: if (value != MDH_FAST_NUMERICS) return seterr(MDH_E_STATE, "the numerics are a property of the library build (make fast builds the experiment)"); break;
+   case MDH_OPT_NUMERICS: if (value != (MDH_FAST_NUMERICS ? 1 : (MDH_HYBRID_NUMERICS ? 2 : 0))) return seterr(MDH_E_STATE, "the numerics are a property of the library build (make fast builds the experiment)"); break;
    case MDH_OPT_RADIANCE_MIPS: {
       const int res = r->probes.radiance_resolution;
       if (value && (res & (res - 1)) != 0) return seterr(MDH_E_INVALID, "radiance mips need a power-of-two radiance resolution");
@@ -1068,7 +1070,7 @@ extern "C" int32_t mdh_get_option(mdh_renderer *r, int32_t option, int32_t *valu
    case MDH_OPT_HYSTERESIS_PERMILLE: *value = r->opt_hyst; break;
    case MDH_OPT_RADIANCE_ORDER: *value = r->opt_rad_order; break;
    case MDH_OPT_SCREEN_ORDER: *value = r->opt_scr_order; break;
-   case MDH_OPT_NUMERICS: *value = MDH_FAST_NUMERICS; break;
+   case MDH_OPT_NUMERICS: *value = MDH_FAST_NUMERICS ? 1 : (MDH_HYBRID_NUMERICS ? 2 : 0); break; // 0 exact (shipped), 1 / 2 the labelled experiments
    case MDH_OPT_RADIANCE_MIPS: *value = r->opt_mips; break;
    default: return seterr(MDH_E_INVALID, "unknown option");
    }

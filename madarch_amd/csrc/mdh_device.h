@@ -262,6 +262,24 @@ MDH_DEV float sqrt_(float x)
    return __builtin_sqrtf(x);
 #endif
 }
+// MDH_HYBRID_NUMERICS: the second LABELLED EXPERIMENT (`make -C madarch_amd/csrc hybrid`; never the shipped
+// library): every operation INSIDE a march loop and the whole primary ray (geometry buffer: index, t, steps) stay as exact
+// as in the shipped build; what SHADES a point behind a hit -- normals, the BRDF, light attenuation, probe directions and
+// weights, the square roots of the irradiance taps, occlusion's quotient, fog, the tone map -- uses the hardware's
+// reciprocal / square root / exp2 / log2 and fused multiply-adds.  In the shipped build the s* helpers below ARE the exact
+// expressions they replace.
+#ifndef MDH_HYBRID_NUMERICS
+#define MDH_HYBRID_NUMERICS 0
+#endif
+#if MDH_HYBRID_NUMERICS
+#define MDH_SHADING_FP _Pragma("clang fp contract(fast)")
+MDH_DEV float sdiv(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+MDH_DEV float ssqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+#else
+#define MDH_SHADING_FP
+MDH_DEV float sdiv(float a, float b) { return a / b; }
+MDH_DEV float ssqrt(float x) { return sqrt_(x); }
+#endif
 MDH_DEV float clamp_(float x, float lo, float hi) { return min_(max_(x, lo), hi); }
 MDH_DEV int iclamp_(int x, int lo, int hi) { return min(max(x, lo), hi); }
 // x / d for 0 <= x < 65536 through the host's magic number m = floor (2^32 / d) + 1: mulhi (x, m) is the exact quotient
@@ -293,6 +311,14 @@ MDH_DEV float dot(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 MDH_DEV float dot2(f3 a) { return dot(a, a); } // maths.glsl:5-7
 MDH_DEV float length(f3 a) { return sqrt_(dot2(a)); }
 MDH_DEV f3 normalize(f3 a) { return a / length(a); } // support/math_utils.ads:81-83
+#if MDH_HYBRID_NUMERICS
+MDH_DEV f3 sdiv3(f3 a, float s) { const float r = __builtin_amdgcn_rcpf(s); return F3(a.x * r, a.y * r, a.z * r); }
+MDH_DEV f3 snormalize(f3 a) { const float r = __builtin_amdgcn_rsqf(dot2(a)); return F3(a.x * r, a.y * r, a.z * r); }
+#else
+MDH_DEV f3 sdiv3(f3 a, float s) { return a / s; }
+MDH_DEV f3 snormalize(f3 a) { return normalize(a); }
+#endif
+MDH_DEV f3 ssqrt3(f3 a) { return F3(ssqrt(a.x), ssqrt(a.y), ssqrt(a.z)); }
 MDH_DEV f3 cross(f3 a, f3 b) { return F3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
 MDH_DEV f3 reflect(f3 i, f3 n) { return i - n * (2.0f * dot(n, i)); }
 
@@ -408,6 +434,13 @@ MDH_DEV float pow_(float x, float y)
    if (x > 3.40282347e+38f) return x;
    return exp2_(y * log2_(x));
 }
+#if MDH_HYBRID_NUMERICS
+MDH_DEV float sexp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269502162933349609375f); }
+MDH_DEV float spow(float x, float y) { return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x)); }
+#else
+MDH_DEV float sexp(float x) { return exp_(x); }
+MDH_DEV float spow(float x, float y) { return pow_(x, y); }
+#endif
 MDH_DEV float pow5_(float x) { float x2 = x * x; return (x2 * x2) * x; }                 // cook_torrance_brdf.glsl:2
 MDH_DEV float pow8_(float x) { float x2 = x * x; float x4 = x2 * x2; return x4 * x4; } // spot_lights.adb:18
 MDH_DEV float pow1_5_(float x) { return x * sqrt_(x); }                        // volumetrics.glsl:25-28
@@ -485,7 +518,7 @@ MDH_DEV f3 nrm_box(float4 a, float4 b, f3 p)
    f3 n = F3(((rx > ry - e ? 1.0f : 0.0f) * (rx > rz - e ? 1.0f : 0.0f)) * sign_(d.x),
              ((ry > rx - e ? 1.0f : 0.0f) * (ry > rz - e ? 1.0f : 0.0f)) * sign_(d.y),
              ((rz > rx - e ? 1.0f : 0.0f) * (rz > ry - e ? 1.0f : 0.0f)) * sign_(d.z));
-   return normalize(n);
+   return snormalize(n);
 }
 // madarch-primitives-triangles.adb:50-56 + madarch-exprs-derivatives.adb:12-45
 template <bool ADA_DIV> MDH_TRI f3 nrm_triangle(f3 a, f3 b, f3 c, f3 p)
@@ -843,7 +876,7 @@ template <bool CUSTOM> MDH_DEV void primitive_info(const KScene &sc, int index, 
          material_id = tab_int(hdr(H_KMAT + k) + index);
          float4 a = s_tab[slot];
          switch (type) {
-         case PK_SPHERE: normal = normalize(pos - xyz(a)); break; // spheres.ads:16-17
+         case PK_SPHERE: normal = snormalize(pos - xyz(a)); break; // spheres.ads:16-17
          case PK_PLANE: normal = xyz(a); break;                   // planes.ads:16-17
          case PK_BOX: normal = nrm_box(a, s_tab[slot + 1], pos); break;
          default: normal = nrm_triangle<false>(xyz(a), xyz(s_tab[slot + 1]), xyz(s_tab[slot + 2]), pos); break;
@@ -1175,16 +1208,16 @@ template <bool CUSTOM> MDH_DEV f3 sample_light(const KScene &sc, int index, f3 p
             dir = xyz(s_tab[s]) - pos;
             dist = length(dir);
             dir = dir / dist;
-            return xyz(s_tab[s + 1]) / ((dist * dist) * 0.03f);
+            return sdiv3(xyz(s_tab[s + 1]), (dist * dist) * 0.03f);
          }
          const int s = hdr(H_LSLOT + k) + 3 * index; // madarch-lights-spot_lights.adb:5-24
          float4 a = s_tab[s];
          dir = xyz(a) - pos;
          dist = length(dir);
          dir = dir / dist;
-         float attenuation = 1.0f / ((dist * dist) * 0.03f);
+         float attenuation = sdiv(1.0f, (dist * dist) * 0.03f);
          float theta = acos_(max_(dot(-dir, xyz(s_tab[s + 1])), 0.0f));
-         float ratio = clamp_(theta / a.w, 0.0f, 1.0f);
+         float ratio = clamp_(sdiv(theta, a.w), 0.0f, 1.0f);
          float visible = 1.0f - pow8_(ratio);
          return (xyz(s_tab[s + 2]) * min_(attenuation, 1.5f)) * visible;
       }
@@ -1207,7 +1240,8 @@ MDH_DEV Material get_material(const KScene &sc, int id) // glsl/materials.glsl:1
 // glsl/cook_torrance_brdf.glsl:1-52
 MDH_DEV void cook_torrance(f3 N, f3 V, f3 L, float NdotL, f3 albedo, float metallic, float roughness, f3 &kD, f3 &kS)
 {
-   f3 H = normalize(V + L);
+   MDH_SHADING_FP
+   f3 H = snormalize(V + L);
    float NdotV = max_(dot(N, V), 0.0f);
    f3 F0 = F3(mix_(0.04f, albedo.x, metallic), mix_(0.04f, albedo.y, metallic), mix_(0.04f, albedo.z, metallic));
    float a = roughness * roughness;
@@ -1216,11 +1250,11 @@ MDH_DEV void cook_torrance(f3 N, f3 V, f3 L, float NdotL, f3 albedo, float metal
    float NdotH2 = NdotH * NdotH;
    float denom = NdotH2 * (a2 - 1.0f) + 1.0f;
    denom = MDH_PI * denom * denom;
-   float NDF = a2 / denom;
+   float NDF = sdiv(a2, denom);
    float rr = roughness + 1.0f;
-   float kk = (rr * rr) / 8.0f;
-   float ggx2 = NdotV / (NdotV * (1.0f - kk) + kk);
-   float ggx1 = NdotL / (NdotL * (1.0f - kk) + kk);
+   float kk = (rr * rr) / 8.0f; // (a division by a power of two: exact either way)
+   float ggx2 = sdiv(NdotV, NdotV * (1.0f - kk) + kk);
+   float ggx1 = sdiv(NdotL, NdotL * (1.0f - kk) + kk);
    float G = ggx1 * ggx2;
    float p5 = pow5_(1.001f - max_(dot(H, V), 0.0f));
    f3 F = F3(F0.x + (1.0f - F0.x) * p5, F0.y + (1.0f - F0.y) * p5, F0.z + (1.0f - F0.z) * p5);
@@ -1228,7 +1262,7 @@ MDH_DEV void cook_torrance(f3 N, f3 V, f3 L, float NdotL, f3 albedo, float metal
    float denominator = 4.0f * NdotV * NdotL;
    float dm = max_(denominator, 0.001f);
    kD = F3(1.0f - F.x, 1.0f - F.y, 1.0f - F.z) * (1.0f - metallic);
-   kS = min3s(numerator / dm, 1.0f);
+   kS = min3s(sdiv3(numerator, dm), 1.0f);
 }
 // glsl/lighting.glsl:42-49
 MDH_DEV f3 compute_indirect_lighting(f3 irradiance, f3 radiance, f3 V, f3 N, f3 L, f3 albedo, float metallic, float roughness)
@@ -1236,7 +1270,7 @@ MDH_DEV f3 compute_indirect_lighting(f3 irradiance, f3 radiance, f3 V, f3 N, f3 
    f3 kD, kS;
    float NdotL = max_(dot(N, L), 0.0f);
    cook_torrance(N, V, L, NdotL, albedo, metallic, roughness, kD, kS);
-   return (kD * irradiance) / MDH_PI + (kS * radiance) * NdotL;
+   return sdiv3(kD * irradiance, MDH_PI) + (kS * radiance) * NdotL;
 }
 // ------------------------------------------------------------------------- probe utils
 // glsl/probe_utils.glsl:19-56
@@ -1276,7 +1310,7 @@ template <bool P2 = false> MDH_DEV f2 probe_id_to_coord(const KProbes &pr, int i
 MDH_DEV float sign_not_zero(float v) { return v >= 0.0f ? 1.0f : -1.0f; }
 MDH_DEV f2 float32x3_to_oct(f3 v)
 {
-   float s = 1.0f / ((__builtin_fabsf(v.x) + __builtin_fabsf(v.y)) + __builtin_fabsf(v.z));
+   float s = sdiv(1.0f, (__builtin_fabsf(v.x) + __builtin_fabsf(v.y)) + __builtin_fabsf(v.z));
    f2 p = F2(v.x * s, v.y * s);
    if (v.z <= 0.0f) return F2((1.0f - __builtin_fabsf(p.y)) * sign_not_zero(p.x), (1.0f - __builtin_fabsf(p.x)) * sign_not_zero(p.y));
    return p;
@@ -1489,7 +1523,8 @@ MDH_DEV float henvey_greenstein_phase(f3 in_dir, f3 out_dir)
    float cos_angle = dot(in_dir, out_dir);
    float t2 = MDH_TAU * MDH_TAU;
    float result = 1.0f - t2;
-   result /= 4.0f * MDH_PI * pow1_5_(1.0f + t2 - 2.0f * MDH_TAU * cos_angle);
+   const float base = 1.0f + t2 - 2.0f * MDH_TAU * cos_angle;
+   result = sdiv(result, 4.0f * MDH_PI * (MDH_HYBRID_NUMERICS ? base * ssqrt(base) : pow1_5_(base)));
    return result;
 }
 // bilinear tap of a plain row-major texture with C floats per texel
@@ -1523,7 +1558,7 @@ MDH_DEV f3 render_volumetrics(const KScene &sc, const KVolumetrics &vol, f3 L, f
          float dist = __builtin_fabsf(d[3] - len);
          if (dist < closest) { closest = dist; fog = F3(d[0], d[1], d[2]); }
       }
-   return L * exp_(-len * MDH_TAU) + fog;
+   return L * sexp(-len * MDH_TAU) + fog;
 }
 
 struct PrimaryHit { int index; float t; int steps; };

@@ -205,7 +205,7 @@ __global__ __launch_bounds__(MDH_BLOCK, MDH_OCC(PART, MODE)) void k_screen(KScen
       c = render_volumetrics(sc, vol, c, origin, pos, hit, F2(u, v));
    }
    if (MODE != 1) // draw_screen.glsl:29
-      c = F3(pow_(c.x / (c.x + 1.0f), 0.4545f), pow_(c.y / (c.y + 1.0f), 0.4545f), pow_(c.z / (c.z + 1.0f), 0.4545f));
+      c = F3(spow(sdiv(c.x, c.x + 1.0f), 0.4545f), spow(sdiv(c.y, c.y + 1.0f), 0.4545f), spow(sdiv(c.z, c.z + 1.0f), 0.4545f));
    const size_t px = (size_t)j * a.W + i;
    a.fb[px] = make_float4(c.x, c.y, c.z, 1.0f);
    if (a.window) a.window[px] = pack_rgba8(make_float4(c.x, c.y, c.z, 1.0f));
@@ -983,7 +983,7 @@ template <int PART> __global__ __launch_bounds__(MDH_BLOCK) void k_visibility(KS
       if (mm == 0ull || __popcll(wm) >= MDH_VIS_REFILL) {
          if (waiting) {
             if (lin >= 0) { // sample_lights :8-19: the ended ray's term, in light order
-               const f3 L_in = radiance * (exp_(-L_dist * MDH_TAU) * vis);
+               const f3 L_in = radiance * (sexp(-L_dist * MDH_TAU) * vis);
                result = result + (L_in * MDH_TAU) * henvey_greenstein_phase(L, dir);
                ++light;
             }
@@ -1047,7 +1047,7 @@ template <int PART> __global__ __launch_bounds__(MDH_BLOCK) void k_visibility(KS
       float L_dist;
       f3 radiance = sample_light<(PART & MDH_PF_CUSTOM) != 0>(sc, l, pos, F3(1.0f, 0.0f, 0.0f), L, L_dist); // compute_frustrum_visibility.glsl:12
       float visibility = raycast_visibility<PART>(sc, pos, L, L_dist);
-      f3 L_in = radiance * (exp_(-L_dist * MDH_TAU) * visibility);
+      f3 L_in = radiance * (sexp(-L_dist * MDH_TAU) * visibility);
       result = result + (L_in * MDH_TAU) * henvey_greenstein_phase(L, dir);
    }
    float *o = vol.vis + ((size_t)j * W + i) * 3;
@@ -1114,7 +1114,7 @@ __global__ __launch_bounds__(MDH_SCAT_BLOCK) void k_scat_fold(KVolumetrics vol)
          for (int q = 0; q < c0 + tid; ++q) f += vol.sstep;
          s_f[tid] = f;
          s_rel[tid] = __builtin_floorf(f / vol.vstep); // sample_visibility :9-15
-         s_e[tid] = exp_(-f * MDH_TAU);
+         s_e[tid] = sexp(-f * MDH_TAU);
       }
       __syncthreads();
       if (!(s_f[0] < max_depth)) break; // (len <= max_depth: no texel has a step here; uniform)

@@ -334,7 +334,7 @@ MDH_DEV int queued_visibility(const KScene &sc, const KProbes &pr, float *pk, f3
                const f3 oN = F3(pk[3 * MDH_BLOCK + owner], pk[4 * MDH_BLOCK + owner], pk[5 * MDH_BLOCK + owner]);
                const f3 hvec = grid_to_world(pr, cage_probe(pr, world_to_grid(pr, oP), corner)) - oP;
                const float dist = length(hvec);
-               d = hvec / dist;
+               d = sdiv3(hvec, dist);
                vmax = dist - MDH_MIN_STEP * 5.0f;
                o = oP + (oN * MDH_MIN_STEP) * 5.0f;
                total = pk[16 * MDH_BLOCK + owner];
@@ -504,7 +504,7 @@ MDH_DEV int queued_visibility_shared(const KScene &sc, const KProbes &pr, float 
                   const f3 oN = F3(pk[3 * MDH_BLOCK + owner], pk[4 * MDH_BLOCK + owner], pk[5 * MDH_BLOCK + owner]);
                   const f3 hvec = grid_to_world(pr, cage_probe(pr, world_to_grid(pr, oP), corner)) - oP;
                   const float dist = length(hvec);
-                  d = hvec / dist;
+                  d = sdiv3(hvec, dist);
                   vmax = dist - MDH_MIN_STEP * 5.0f;
                   o = oP + (oN * MDH_MIN_STEP) * 5.0f;
                   total = pk[16 * MDH_BLOCK + owner];
@@ -795,7 +795,7 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
                      f3 kD, kS;
                      cook_torrance(N, -rd, L, NdotL, m.albedo, m.metallic, m.roughness, kD, kS);
                      if (ctx == 0 && !cfg.direct_specular) kS = F3(0.0f, 0.0f, 0.0f);
-                     const f3 contrib = (((kD * m.albedo) / MDH_PI + kS) * radiance) * NdotL;
+                     const f3 contrib = ((sdiv3(kD * m.albedo, MDH_PI) + kS) * radiance) * NdotL;
                      float shadows = 0.0f;
                      PH_ADD(pt, 2);
                      // a light that contributes exactly nothing here (outside a spot's cone, black BRDF)
@@ -914,7 +914,7 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
                      const f3 pw = grid_to_world(pq, q);
                      const f3 hvec = irrp ? (pw - P) : (P - pw);
                      const float dist = length(hvec);
-                     f3 vd = hvec / dist; // irrp: dir_to_probe, else: probe_to_spec
+                     f3 vd = sdiv3(hvec, dist); // irrp: dir_to_probe, else: probe_to_spec
                      if (!irrp) vd = -vd; // the visibility ray always runs from the point to the probe
                      // the irradiance tap of this corner (render_probes.glsl:44-58) depends on the probe and
                      // N only: its texel loads go out now and land while the visibility ray is marched
@@ -985,10 +985,10 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
                         // two factors from {0} and [2^-24, 1] (fx = px - floor (px) with px = cx W - 0.5 a multiple of 2^-24 below 1 --
                         // the subtraction is exact there -- and of ulp (px) above; 1 - fx likewise), its terms are not negative.  No
                         // rescaling can apply: the square root's nine-instruction core, 7 instructions less x 3 channels x 8 corners.
-                        if (pq.fmt == 0) s_term = F3(sqrt_unscaled_(tx.x), sqrt_unscaled_(tx.y), sqrt_unscaled_(tx.z));
+                        if (pq.fmt == 0 && !MDH_HYBRID_NUMERICS) s_term = F3(sqrt_unscaled_(tx.x), sqrt_unscaled_(tx.y), sqrt_unscaled_(tx.z));
                         else
 #endif
-                        s_term = sqrt3(tx);
+                        s_term = ssqrt3(tx);
                      } else { // render_probes.glsl:170-183; probe_to_spec = -vd
                         float weight = dot(-vd, -N);
                         weight *= vis;
@@ -1009,7 +1009,7 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
                   }
                   if (SPEC == 2 && ctx == 1 && full2) { // render_probes.glsl:233-243: indirect (no specular of its own) + direct
                      f3 irr = F3(0.0f, 0.0f, 0.0f);
-                     if (accw != 0.0f) { irr = acc / accw; irr = irr * irr; }
+                     if (accw != 0.0f) { irr = sdiv3(acc, accw); irr = irr * irr; }
                      const Material m = get_material(sc, pm);
                      specular_col = compute_indirect_lighting(irr, F3(0.0f, 0.0f, 0.0f), -rd, N, reflect(rd, N), m.albedo, m.metallic, m.roughness) + specular_col;
                      park_store3<MDH_PARK_SPEC>(pk, wb, specular_col);
@@ -1017,7 +1017,7 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
                   if (ctx == 0) {
                      // render_probes.glsl:65-66 (0/0 fixed as 0)
                      f3 irr = F3(0.0f, 0.0f, 0.0f);
-                     if (accw != 0.0f) { irr = acc / accw; irr = irr * irr; }
+                     if (accw != 0.0f) { irr = sdiv3(acc, accw); irr = irr * irr; }
 #if MDH_QVIS_SHARED
                      if (QVIS && !REFLECT) irr_keep = irr; // (rows 12-15 are the workgroup's job list until the kernel ends)
                      else
@@ -1090,7 +1090,7 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
                max_ao_sum += factor * (float)(i + 1) * 0.1f;
                factor = factor * 0.5f;
             }
-            ao = 0.6f + 0.4f * ao_sum / max_ao_sum;
+            ao = 0.6f + sdiv(0.4f * ao_sum, max_ao_sum);
          }
          result = direct * ao;
       }

@@ -18,7 +18,7 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-OUT = os.path.join(ROOT, "gpurun_out")
+OUT = os.environ.get("TMPDIR", "/tmp")  # (three 1080p frames with their buffers: too large for gpurun_out)
 
 
 def render(which, atlas, frames, out):
@@ -38,7 +38,7 @@ def render(which, atlas, frames, out):
     for _ in range(frames):
         R.Render()
     idx, t, steps = R.Read_Gbuffer()
-    np.savez(out, image=R.Read_Framebuffer(), gb_index=idx, gb_steps=steps, radiance=R.Read_Texture(B.TEX_RADIANCE), irradiance=R.Read_Texture(B.TEX_IRRADIANCE))
+    np.savez(out, image=R.Read_Framebuffer(), gb_index=idx, gb_steps=steps, gb_t=t, radiance=R.Read_Texture(B.TEX_RADIANCE), irradiance=R.Read_Texture(B.TEX_IRRADIANCE))
     info = {"which": which, "version": (binding.version() or b"").decode() if which != "oracle" else "oracle", "numerics": R.Get_Option(B.OPT_NUMERICS)}
     if which != "oracle":
         R.Set_Option(B.OPT_GBUFFER, 0)
@@ -69,9 +69,11 @@ def main():
     import numpy as np
     atlas = sys.argv[1] if len(sys.argv) > 1 else "rgb8"
     frames = int(sys.argv[2]) if len(sys.argv) > 2 else 8
-    libs = {"exact": os.path.join(ROOT, "madarch_amd", "csrc", "libmadarch_hip.so"), "fast": os.path.join(ROOT, "madarch_amd", "csrc", "libmadarch_hip_fast.so")}
+    libs = {"exact": os.path.join(ROOT, "madarch_amd", "csrc", "libmadarch_hip.so"), "fast": os.path.join(ROOT, "madarch_amd", "csrc", "libmadarch_hip_fast.so"),
+            "hybrid": os.path.join(ROOT, "madarch_amd", "csrc", "libmadarch_hip_hybrid.so")}
+    libs = {k: v for k, v in libs.items() if os.path.exists(v)}
     infos = {}
-    for which in ("oracle", "exact", "fast"):
+    for which in ("oracle",) + tuple(libs):
         env = dict(os.environ)
         if which in libs:
             env["MADARCH_HIP_LIBRARY"] = libs[which]
@@ -81,20 +83,26 @@ def main():
         infos[which] = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     want = np.load(os.path.join(OUT, "numerics_oracle.npz"))
     print("BASELINE config 3, 1920x1080, DDGI 8x8x8, %s atlases, frame %d of the probe feedback; the gate: every channel within 1e-4 relative (floor 1e-5) of the EXACT oracle" % (atlas, frames))
-    for which in ("exact", "fast"):
+    for which in libs:
         got, info = np.load(os.path.join(OUT, "numerics_%s.npz" % which)), infos[which]
         img_ok = np.isclose(got["image"], want["image"], rtol=1e-4, atol=1e-5, equal_nan=True).all(axis=2)
         rel = np.abs(got["image"] - want["image"]) / np.maximum(np.abs(want["image"]), 1e-5)
         print("%-5s  %s" % (which, info["version"]))
         print("       pixels inside the gate %.4f %% (%d of %d outside), bit-equal %.4f %%, largest relative error %.3g, 99.9th percentile %.3g" % (
             100.0 * img_ok.mean(), (~img_ok).sum(), img_ok.size, 100.0 * (got["image"] == want["image"]).all(axis=2).mean(), float(np.nanmax(rel)), float(np.nanpercentile(rel, 99.9))))
-        print("       geometry buffer: %d pixels with another primitive index, %d with another step count; atlas texels that differ: radiance %d of %d, irradiance %d of %d" % (
-            (got["gb_index"] != want["gb_index"]).sum(), (got["gb_steps"] != want["gb_steps"]).sum(),
+        bad = np.argwhere(~img_ok)
+        if 0 < len(bad) <= 12:
+            print("       outside the gate (row, column): " + ", ".join("(%d, %d)" % (y, x) for y, x in bad))
+        print("       geometry buffer: %d pixels with another primitive index, %d with another step count or march length; atlas texels that differ: radiance %d of %d, irradiance %d of %d" % (
+            (got["gb_index"] != want["gb_index"]).sum(), ((got["gb_steps"] != want["gb_steps"]) | (got["gb_t"] != want["gb_t"])).sum(),
             (got["radiance"] != want["radiance"]).any(axis=2).sum(), want["radiance"].shape[0] * want["radiance"].shape[1],
             (got["irradiance"] != want["irradiance"]).any(axis=2).sum(), want["irradiance"].shape[0] * want["irradiance"].shape[1]))
         print("       %.1f Mpixels/s with frames in flight, %.1f one synchronised frame at a time; passes (serial, ms) %s" % (info["mpix_in_flight"], info["mpix_serial"], info["passes_serial_ms"]))
-    e, f = infos["exact"], infos["fast"]
-    print("fast / exact: %.3f in flight, %.3f serial" % (f["mpix_in_flight"] / e["mpix_in_flight"], f["mpix_serial"] / e["mpix_serial"]))
+    e = infos["exact"]
+    for which in libs:
+        if which != "exact":
+            f = infos[which]
+            print("%s / exact: %.3f in flight, %.3f serial" % (which, f["mpix_in_flight"] / e["mpix_in_flight"], f["mpix_serial"] / e["mpix_serial"]))
 
 
 if __name__ == "__main__":
