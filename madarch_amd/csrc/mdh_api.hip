@@ -686,6 +686,9 @@ static int commit_scene(mdh_renderer *r, hipStream_t up)
       s.part_inv_sp[a] = pow2 ? 1.0f / r->pg_spacing[a] : 0.0f;
       if (!pow2) s.part_sp_pow2 = 0;
    }
+   // the grid's dimensions as the fp32 values the cell index is computed with (uniform conversions the kernels would repeat at every march step)
+   for (int a = 0; a < 3; ++a) s.part_fdims[a] = (float)r->part.grid_dimensions[a];
+   s.part_fyz = (float)(r->part.grid_dimensions[1] * r->part.grid_dimensions[2]);
    s.part_table = r->d_part_ring[r->part_slot];
    s.part_mask_off = (int)part_table_ints(r);
    s.part_mask_words = part_mask_words(r);
@@ -697,6 +700,7 @@ static int commit_scene(mdh_renderer *r, hipStream_t up)
       for (int k = 0; k < r->npk; ++k) {
          const Kind &kd = r->pk[k];
          if (kd.type == PK_CUSTOM || kd.max_count > 32) small = false;
+         else if (kd.max_count > 0 && s.part_tmask[kd.type]) small = false; // (two kinds of one built-in type: one shift and mask cannot name both)
          else if (kd.max_count > 0) { s.part_tbit[kd.type] = (unsigned)r->prim_base[k]; s.part_tmask[kd.type] = kd.max_count == 32 ? 0xffffffffu : ((1u << kd.max_count) - 1u); }
          declared += kd.max_count;
       }

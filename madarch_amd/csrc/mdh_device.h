@@ -70,6 +70,7 @@ struct KScene {
    // so the lookup is straight-line code without the table's kind headers (partitioning_closest_bits).
    int part_small;
    unsigned part_tbit[4], part_tmask[4];
+   float part_fdims[3], part_fyz; // (float)part_dims[a] and (float)(part_dims[1] * part_dims[2]): the same conversions, once on the host
 };
 // int block at table[0..]: per-kind data in SCENE order (the order the flat primitive index
 // and the arg-min tie-break follow, scenes.adb:656-666) and the light kinds
@@ -906,8 +907,18 @@ MDH_DEV int partition_cell_clamped(const KScene &sc, f3 x)
 {
    const f3 rel = x - F3(sc.part_off[0], sc.part_off[1], sc.part_off[2]);
    const f3 fx = floor3(sc.part_sp_pow2 ? rel * F3(sc.part_inv_sp[0], sc.part_inv_sp[1], sc.part_inv_sp[2]) : rel / F3(sc.part_sp[0], sc.part_sp[1], sc.part_sp[2]));
-   const f3 cfx = F3(clamp_(fx.x, 0.0f, (float)sc.part_dims[0]), clamp_(fx.y, 0.0f, (float)sc.part_dims[1]), clamp_(fx.z, 0.0f, (float)sc.part_dims[2]));
-   const float yz = (float)(sc.part_dims[1] * sc.part_dims[2]), zz = (float)sc.part_dims[2];
+#if MDH_PART_CELL_TRIM
+   // clamp (v, 0, d) = min (max (v, 0), d) as ONE instruction: v_med3_f32 is the median of its operands and, with a NaN among
+   // them, their minNum -- 0 for v = NaN, as the two-instruction form gives (max (NaN, 0) = 0; d >= 0)
+   const f3 cfx = F3(__builtin_amdgcn_fmed3f(fx.x, 0.0f, sc.part_fdims[0]), __builtin_amdgcn_fmed3f(fx.y, 0.0f, sc.part_fdims[1]), __builtin_amdgcn_fmed3f(fx.z, 0.0f, sc.part_fdims[2]));
+   const float yz = sc.part_fyz, zz = sc.part_fdims[2];
+   // (every term and every partial sum is an integer below 2^24 for tables of fewer than 2^24 cells: the two fused forms round
+   //  nothing that the four separate operations would not -- the same value with two instructions instead of four)
+   if (sc.part_cells < (1 << 24)) return (int)__builtin_fmaf(cfx.x, yz, __builtin_fmaf(cfx.y, zz, cfx.z));
+#else
+   const f3 cfx = F3(clamp_(fx.x, 0.0f, sc.part_fdims[0]), clamp_(fx.y, 0.0f, sc.part_fdims[1]), clamp_(fx.z, 0.0f, sc.part_fdims[2]));
+   const float yz = sc.part_fyz, zz = sc.part_fdims[2];
+#endif
    return (int)((cfx.x * yz + cfx.y * zz) + cfx.z);
 }
 // partitioning_closest[_info] (scenes.adb:839-1118): per-lane cell record from HBM/L2,
@@ -990,6 +1001,42 @@ template <bool INFO, bool CUSTOM, bool FALLBACK = true> MDH_DEV float partitioni
 #ifndef MDH_PART_MERGE_ROOTS
 #define MDH_PART_MERGE_ROOTS 1
 #endif
+#ifndef MDH_PART_SQRT_WAVE
+#define MDH_PART_SQRT_WAVE 1
+#endif
+#ifndef MDH_PART_PLANE_SINGLE
+#define MDH_PART_PLANE_SINGLE 1
+#endif
+#ifndef MDH_PART_ALIGNBIT
+#define MDH_PART_ALIGNBIT 0 // (measured: the scalar branch of the funnel-shift form costs more than the 64-bit shift it replaces, -4 % on simple_scene)
+#endif
+#ifndef MDH_PART_CELL_TRIM
+#define MDH_PART_CELL_TRIM 1
+#endif
+// the correctly rounded root of a wavefront's operands through the nine-instruction core when none of them is a positive
+// number below 2^-96 (the only inputs hipcc's expansion rescales: sqrt_unscaled_ above), through the full expansion otherwise
+MDH_DEV float sqrt_wave_(float x)
+{
+#if MDH_FAST_NUMERICS
+   return __builtin_amdgcn_sqrtf(x);
+#endif
+#if MDH_PART_SQRT_WAVE
+   if (__ballot(x < 0x1p-96f && x > 0.0f) != 0ull) return sqrt_(x);
+   return sqrt_unscaled_(x);
+#else
+   return sqrt_(x);
+#endif
+}
+MDH_DEV float walk_planes_single(unsigned w, const float4 *t, f3 x, float closest)
+{
+   while (w) { // (a cell of the reference's scenes names one or two planes: pairs evaluated most of them twice)
+      MDH_DIAG_STEP(6);
+      const int p = __builtin_ctz(w);
+      w &= w - 1u;
+      closest = min_raw(closest, sd_plane(t[p], x));
+   }
+   return closest;
+}
 MDH_DEV float walk_spheres_merged(unsigned w, const float4 *t, f3 x, float closest)
 {
    float S = __builtin_inff(), r_cur = 0.0f;
@@ -1001,14 +1048,14 @@ MDH_DEV float walk_spheres_merged(unsigned w, const float4 *t, f3 x, float close
       const float d2 = dot2(xyz(a) - x);
       const bool other = __float_as_int(a.w) != __float_as_int(r_cur);
       if ((__ballot(other) & __ballot(S < __builtin_inff())) != 0ull) { // (wave-uniform) some lane changes its radius: its minimum so far goes through the root
-         if (other) closest = min_raw(closest, sqrt_(S) - r_cur); // (S = inf: sqrt = inf, no change)
+         if (other) closest = min_raw(closest, sqrt_wave_(S) - r_cur); // (S = inf: sqrt = inf, no change)
       }
       S = min_raw(other ? __builtin_inff() : S, d2);
       r_cur = a.w; // (unchanged when !other)
    }
    const float tsum = closest + r_cur;
    const bool need = !(tsum < 0.0f) && !(S > (tsum * tsum) * 1.000001f); // (closest_primitive's cull; S = inf: no candidate, never needed)
-   if (!MDH_CULL || __ballot(need) != 0ull) closest = min_raw(closest, sqrt_(S) - r_cur);
+   if (!MDH_CULL || __ballot(need) != 0ull) closest = min_raw(closest, sqrt_wave_(S) - r_cur);
    return closest;
 }
 MDH_DEV float walk_boxes_merged(unsigned w, const float4 *t, f3 x, float closest)
@@ -1026,7 +1073,7 @@ MDH_DEV float walk_boxes_merged(unsigned w, const float4 *t, f3 x, float closest
    // sqrt (S) + U: U < 0 means S = 0 and the value is U itself; otherwise it is sqrt (S) >= 0, which cannot lower a negative
    // `closest` and cannot lower a positive one when S > closest^2 (1 + 1e-6)
    const bool need = !(U < 0.0f) && !(closest < 0.0f) && !(S > (closest * closest) * 1.000001f);
-   if (!MDH_CULL || __ballot(need) != 0ull) closest = min_raw(closest, sqrt_(S) + U);
+   if (!MDH_CULL || __ballot(need) != 0ull) closest = min_raw(closest, sqrt_wave_(S) + U);
    else closest = min_raw(closest, U < 0.0f ? U : closest);
    return closest;
 }
@@ -1035,6 +1082,7 @@ template <int TYPE> MDH_DEV float walk_bits(unsigned w, const float4 *t, f3 x, f
 #if MDH_PART_MERGE_ROOTS
    if (TYPE == PK_SPHERE) return walk_spheres_merged(w, t, x, closest);
    if (TYPE == PK_BOX) return walk_boxes_merged(w, t, x, closest);
+   if (TYPE == PK_PLANE && MDH_PART_PLANE_SINGLE) return walk_planes_single(w, t, x, closest);
 #endif
    if (TYPE == PK_TRIANGLE) {
       while (w) { const int pi = __builtin_ctz(w); w &= w - 1u; closest = min_raw(closest, sd_triangle<false>(xyz(t[3 * pi]), xyz(t[3 * pi + 1]), xyz(t[3 * pi + 2]), x)); }
@@ -1073,7 +1121,14 @@ template <bool CUSTOM, bool FALLBACK> MDH_DEV float partitioning_closest_bits(co
    if (!CUSTOM && MDH_PART_SMALL && sc.part_small) { // (wave-uniform) straight-line code: one load, a shift and a mask per type
       typedef const unsigned long long __attribute__((address_space(1))) *GlobalPairs;
       const unsigned long long mm = ((GlobalPairs)(sc.part_table + sc.part_mask_off))[cell];
-#define MDH_TYPE_BITS(T) ((unsigned)(mm >> sc.part_tbit[T]) & sc.part_tmask[T]) /* (one 64-bit shift by a scalar) */
+      // a type's candidates: 32 bits of the cell's 64 from bit part_tbit on -- one funnel shift (v_alignbit_b32) while the
+      // type starts in the low dword, a plain shift of the high one otherwise (part_tbit is uniform: a scalar branch)
+      const unsigned mlo = (unsigned)mm, mhi = (unsigned)(mm >> 32);
+#if MDH_PART_ALIGNBIT
+#define MDH_TYPE_BITS(T) ((sc.part_tbit[T] < 32u ? __builtin_amdgcn_alignbit(mhi, mlo, sc.part_tbit[T]) : (mhi >> (sc.part_tbit[T] - 32u))) & sc.part_tmask[T])
+#else
+#define MDH_TYPE_BITS(T) ((unsigned)(mm >> sc.part_tbit[T]) & sc.part_tmask[T])
+#endif
       if (sc.part_tmask[PK_PLANE]) closest = walk_bits<PK_PLANE>(MDH_TYPE_BITS(PK_PLANE), s_tab + sc.tslot[PK_PLANE], x, closest);
       if (sc.part_tmask[PK_SPHERE]) closest = walk_bits<PK_SPHERE>(MDH_TYPE_BITS(PK_SPHERE), s_tab + sc.tslot[PK_SPHERE], x, closest);
       if (sc.part_tmask[PK_BOX]) closest = walk_bits<PK_BOX>(MDH_TYPE_BITS(PK_BOX), s_tab + sc.tslot[PK_BOX], x, closest);
