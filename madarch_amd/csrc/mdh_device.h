@@ -251,16 +251,40 @@ MDH_DEV float sqrt_unscaled_(float x)
    s = (vs > 0.0f) ? su : s;
    return s;
 }
+#ifndef MDH_SQRT_WAVE_ALL
+#define MDH_SQRT_WAVE_ALL 1 // every correctly rounded root through the nine-instruction core behind a wave-wide guard (sqrt_wave_ below): the same bits; config 3 serial +1.7 %, in flight +-0
+#endif
 MDH_DEV float sqrt_(float x)
 {
 #if MDH_FAST_NUMERICS
    return __builtin_amdgcn_sqrtf(x);
+#endif
+#if MDH_SQRT_WAVE_ALL
+   if (__ballot(x < 0x1p-96f && x > 0.0f) != 0ull) return __builtin_sqrtf(x);
+   return sqrt_unscaled_(x);
 #endif
 #if MDH_FAST_EXACT_SQRT
    if (__builtin_expect(x < 0x1p-96f && x > 0.0f, 0)) return __builtin_sqrtf(x);
    return sqrt_unscaled_(x);
 #else
    return __builtin_sqrtf(x);
+#endif
+}
+#ifndef MDH_PART_SQRT_WAVE
+#define MDH_PART_SQRT_WAVE 1
+#endif
+// the correctly rounded root of a wavefront's operands through the nine-instruction core when none of them is a positive
+// number below 2^-96 (the only inputs hipcc's expansion rescales: sqrt_unscaled_ above), through the full expansion otherwise
+MDH_DEV float sqrt_wave_(float x)
+{
+#if MDH_FAST_NUMERICS
+   return __builtin_amdgcn_sqrtf(x);
+#endif
+#if MDH_PART_SQRT_WAVE
+   if (__ballot(x < 0x1p-96f && x > 0.0f) != 0ull) return sqrt_(x);
+   return sqrt_unscaled_(x);
+#else
+   return sqrt_(x);
 #endif
 }
 // MDH_HYBRID_NUMERICS: the second LABELLED EXPERIMENT (`make -C madarch_amd/csrc hybrid`; never the shipped
@@ -704,6 +728,9 @@ MDH_DEV float prim_dist(int type, int slot, f3 x)
 #ifndef MDH_SDF_PREFETCH
 #define MDH_SDF_PREFETCH 1
 #endif
+#ifndef MDH_SDF_SQRT_WAVE
+#define MDH_SDF_SQRT_WAVE 0 // the brute-force scan's sphere and box roots through sqrt_wave_ (below)
+#endif
 // The first sphere and the first box of the table in registers: a march loop that evaluates the SDF many times
 // reads them from LDS once (MDH_SDF_REGS) instead of once per evaluation.  (With a count of 0 the words
 // belong to the next kind and are not used.)
@@ -743,7 +770,7 @@ template <bool CUSTOM> MDH_DEV float closest_primitive(const KScene &sc, f3 x, c
          const float d2 = dot2(xyz(a) - x); /* sd_sphere = sqrt(d2) - a.w (spheres.ads:13-14) */ \
          const float tsum = closest + a.w;                                                   \
          const bool need = !(tsum < 0.0f) && !(d2 > (tsum * tsum) * 1.000001f);              \
-         if (!MDH_CULL || __ballot(need) != 0ull) closest = min_raw(closest, sqrt_(d2) - a.w); \
+         if (!MDH_CULL || __ballot(need) != 0ull) closest = min_raw(closest, (MDH_SDF_SQRT_WAVE ? sqrt_wave_(d2) : sqrt_(d2)) - a.w); \
       } while (0)
 #if MDH_SDF_PREFETCH
       if (n > 0) MDH_SPHERE_STEP(pf_s);
@@ -763,7 +790,7 @@ template <bool CUSTOM> MDH_DEV float closest_primitive(const KScene &sc, f3 x, c
          const float m = max_(q.x, max_(q.y, q.z));                                          \
          const float thr = closest > 0.0f ? closest * 1.000001f : closest;                   \
          if (!MDH_CULL || __ballot(!(m > thr)) != 0ull)                                      \
-            closest = min_raw(closest, length(F3(max0_raw(q.x), max0_raw(q.y), max0_raw(q.z))) + min0_raw(m)); \
+            closest = min_raw(closest, (MDH_SDF_SQRT_WAVE ? sqrt_wave_(dot2(F3(max0_raw(q.x), max0_raw(q.y), max0_raw(q.z)))) : length(F3(max0_raw(q.x), max0_raw(q.y), max0_raw(q.z)))) + min0_raw(m)); \
       } while (0)
 #if MDH_SDF_PREFETCH
       if (n > 0) MDH_BOX_STEP(pf_b0, pf_b1);
@@ -1001,9 +1028,6 @@ template <bool INFO, bool CUSTOM, bool FALLBACK = true> MDH_DEV float partitioni
 #ifndef MDH_PART_MERGE_ROOTS
 #define MDH_PART_MERGE_ROOTS 1
 #endif
-#ifndef MDH_PART_SQRT_WAVE
-#define MDH_PART_SQRT_WAVE 1
-#endif
 #ifndef MDH_PART_PLANE_SINGLE
 #define MDH_PART_PLANE_SINGLE 1
 #endif
@@ -1013,20 +1037,6 @@ template <bool INFO, bool CUSTOM, bool FALLBACK = true> MDH_DEV float partitioni
 #ifndef MDH_PART_CELL_TRIM
 #define MDH_PART_CELL_TRIM 1
 #endif
-// the correctly rounded root of a wavefront's operands through the nine-instruction core when none of them is a positive
-// number below 2^-96 (the only inputs hipcc's expansion rescales: sqrt_unscaled_ above), through the full expansion otherwise
-MDH_DEV float sqrt_wave_(float x)
-{
-#if MDH_FAST_NUMERICS
-   return __builtin_amdgcn_sqrtf(x);
-#endif
-#if MDH_PART_SQRT_WAVE
-   if (__ballot(x < 0x1p-96f && x > 0.0f) != 0ull) return sqrt_(x);
-   return sqrt_unscaled_(x);
-#else
-   return sqrt_(x);
-#endif
-}
 MDH_DEV float walk_planes_single(unsigned w, const float4 *t, f3 x, float closest)
 {
    while (w) { // (a cell of the reference's scenes names one or two planes: pairs evaluated most of them twice)
