@@ -282,6 +282,7 @@ struct mdh_renderer {
    // an open frame (mdh_frame_begin .. mdh_frame_end)
    bool in_frame = false, frame_pipelined = false;
    bool in_frame_passes = false; // run_pass is called for the passes that end an open frame (frame_end_passes)
+   void *d_rad_rec = nullptr; size_t rad_rec_bytes = 0; // MADARCH_HIP_RAD_SPLIT: the per-ray records between the radiance pass's two kernels
    bool fuse_scat_march = false; // the frame's visibility launch also marches the scattering texels' camera rays (k_visibility)
    int frame_cur = 0;
    int scr_parity = 0; // which screen stream / framebuffer the last pipelined frame drew on
@@ -821,6 +822,7 @@ extern "C" int32_t mdh_destroy(mdh_renderer *r)
    if (r->vol_stream) (void)hipStreamSynchronize(r->vol_stream);
    if (r->comm) { ncclComm_t c = r->comm; r->comm = nullptr; (void)rccl_api_destroy(c); }
    if (r->d_comm_scratch) (void)hipFree(r->d_comm_scratch);
+   if (r->d_rad_rec) (void)hipFree(r->d_rad_rec);
    peer_drop(r);
    void *ptrs[] = {r->d_table_ring[0], r->d_table_ring[1], r->d_table_ring[2], r->d_table_ring[3], r->d_part_ring[0], r->d_part_ring[1], r->d_part_ring[2], r->d_part_ring[3], r->d_warn, r->d_query, r->d_rad_steps, r->d_rad_order, r->d_rad_hist, r->d_scr_cost, r->d_scr_order[0], r->d_scr_order[1], r->d_scr_hist, r->d_fb2[0], r->d_fb2[1], r->d_gb2[0][0], r->d_gb2[0][1], r->d_gb2[0][2], r->d_gb2[1][0], r->d_gb2[1][1], r->d_gb2[1][2]};
    for (void *p : ptrs)
@@ -1688,7 +1690,7 @@ static int run_pass(mdh_renderer *r, int pass, hipStream_t st, int src, int dst,
       if (n > 0) {
          // the rays in the order of the previous pass's primary-march lengths (RadOrder, mdh_kernels.h)
          const long rays = (long)(pr.probe_end - pr.probe_begin) * pr.rres * pr.rres;
-         RadOrder ro = {nullptr, nullptr, (int)rays, 64};
+         RadOrder ro = {nullptr, nullptr, (int)rays, 64, nullptr};
          // (chunks of whole workgroup strides, at most MDH_RO_MAX_CHUNKS of them)
          const long ro_chunk = std::max(2048l, ((rays + MDH_RO_MAX_CHUNKS - 1) / MDH_RO_MAX_CHUNKS + 1023) / 1024 * 1024);
          const int ro_chunks = (int)((rays + ro_chunk - 1) / ro_chunk);
@@ -1736,6 +1738,28 @@ static int run_pass(mdh_renderer *r, int pass, hipStream_t st, int src, int dst,
          } else {
 #define MDH_LAUNCH_RAD_(...) hipLaunchKernelGGL((__VA_ARGS__), dim3(blocks), dim3(MDH_BLOCK), lds, st, r->ks, pr, rad_first_round(r, (const void *)(__VA_ARGS__), nullptr, lds, blocks), ro)
 #define MDH_LAUNCH_RAD(P) do { if (rad_small_launch(r)) MDH_LAUNCH_RAD_(k_radiance<P, true>); else MDH_LAUNCH_RAD_(k_radiance<P, false>); } while (0)
+            // MADARCH_HIP_RAD_SPLIT=1 (an experiment; the brute-force power-of-two variant only): the pass as two
+            // kernels -- marches and direct light into per-ray records, then the probe code from the records
+            static const bool rad_split = [] { const char *e = getenv("MADARCH_HIP_RAD_SPLIT"); return e && atoi(e) == 1; }();
+            if (rad_split && pow2 && !has_custom && !(pf & MDH_PF_PART)) {
+               const size_t need = (size_t)blocks * MDH_BLOCK * sizeof(RadRecord);
+               if (need > r->rad_rec_bytes) {
+                  if (r->probe_stream) HIP_TRY(hipStreamSynchronize(r->probe_stream));
+                  HIP_TRY(hipStreamSynchronize(r->stream));
+                  if (r->d_rad_rec) HIP_TRY(hipFree(r->d_rad_rec));
+                  r->d_rad_rec = nullptr; r->rad_rec_bytes = 0;
+                  HIP_TRY(hipMalloc(&r->d_rad_rec, need));
+                  r->rad_rec_bytes = need;
+               }
+               ro.rec = (RadRecord *)r->d_rad_rec;
+               if (rad_small_launch(r)) {
+                  hipLaunchKernelGGL((k_radiance<MDH_PF_POW2, true, 1>), dim3(blocks), dim3(MDH_BLOCK), lds, st, r->ks, pr, 0, ro);
+                  hipLaunchKernelGGL((k_radiance<MDH_PF_POW2, true, 2>), dim3(blocks), dim3(MDH_BLOCK), lds, st, r->ks, pr, 0, ro);
+               } else {
+                  hipLaunchKernelGGL((k_radiance<MDH_PF_POW2, false, 1>), dim3(blocks), dim3(MDH_BLOCK), lds, st, r->ks, pr, rad_first_round(r, (const void *)(k_radiance<MDH_PF_POW2, false, 1>), nullptr, lds, blocks), ro);
+                  hipLaunchKernelGGL((k_radiance<MDH_PF_POW2, false, 2>), dim3(blocks), dim3(MDH_BLOCK), lds, st, r->ks, pr, rad_first_round(r, (const void *)(k_radiance<MDH_PF_POW2, false, 2>), nullptr, lds, blocks), ro);
+               }
+            } else
             if (pow2 && !has_custom) {
                if (pf & MDH_PF_FALLBACK) MDH_LAUNCH_RAD(MDH_PF_PART | MDH_PF_POW2 | MDH_PF_FALLBACK);
                else if (pf & MDH_PF_PART) MDH_LAUNCH_RAD(MDH_PF_PART | MDH_PF_POW2);

@@ -245,6 +245,7 @@ struct RadOrder {
    // paying every latency of its dependency chain in full).  Spread over four times as many wavefronts the same rays
    // hide each other's latencies, and a wavefront's marches end with the longest of 16 rays instead of 64.
    int fill;
+   RadRecord *rec; // [launch lanes] MADARCH_HIP_RAD_SPLIT: what the first kernel leaves for the second (null: one kernel)
 };
 // `first_round`: the workgroups the chip holds at once (0: not told).  The pass is ONE round of wavefronts and a
 // remainder -- 8 192 wavefronts on 7 168 slots at the headline size -- and ends with its slowest wavefront.  A SIMD
@@ -294,7 +295,13 @@ MDH_DEV void radiance_texel(const KProbes &pr, const RadOrder &ro, long lin, int
       x = rem - y * pr.rres;
    }
 }
-template <int PART, bool SMALL = false> __global__ __launch_bounds__(MDH_BLOCK, MDH_OCC_RAD(PART, SMALL)) void k_radiance(KScene sc, KProbes pr, int first_round, RadOrder ro)
+// PHASE 1 / 2: the pass as two kernels (an experiment, MADARCH_HIP_RAD_SPLIT): 1 = every ray's primary and
+// shadow marches, its hit point and direct light into ro.rec[launch lane] (no probe code: eight wavefronts per SIMD); 2 = the
+// probe visibility queue, the irradiance taps and the store, from the records.  The same arithmetic per ray: the same texels.
+#ifndef MDH_RAD_A_WAVES_PER_SIMD
+#define MDH_RAD_A_WAVES_PER_SIMD 8
+#endif
+template <int PART, bool SMALL = false, int PHASE = 0> __global__ __launch_bounds__(MDH_BLOCK, PHASE == 1 ? MDH_RAD_A_WAVES_PER_SIMD : MDH_OCC_RAD(PART, SMALL)) void k_radiance(KScene sc, KProbes pr, int first_round, RadOrder ro)
 {
    if (first_round > 0 && (int)blockIdx.x >= first_round) __builtin_amdgcn_s_setprio(3);
 #if MDH_QVIS_SHARED && MDH_RAD_QVIS
@@ -324,7 +331,7 @@ template <int PART, bool SMALL = false> __global__ __launch_bounds__(MDH_BLOCK, 
       cfg.ao_steps = 0;
       bool hit;
       f3 pos;
-      c = MDH_SHADE<PART, 0, 0, MDH_RAD_QVIS != 0>(sc, pr, cfg, valid, world, ray_dir, ph, hit, pos);
+      c = MDH_SHADE<PART, 0, 0, MDH_RAD_QVIS != 0, PHASE>(sc, pr, cfg, valid, world, ray_dir, ph, hit, pos, PHASE ? ro.rec + lin : nullptr);
 #if !MDH_RAD_REDERIVE
       if (valid) atlas_store(pr.rad, pr.fmt, atlas_index(pr.pcx, pr.rres, pr.rshift, i, j), c);
       if (valid && ro.steps) // the ray's sort key: the levels of its primary-march and soft-shadow step counts
@@ -338,7 +345,7 @@ template <int PART, bool SMALL = false> __global__ __launch_bounds__(MDH_BLOCK, 
    // cannot trace: the same integer operations on the same inputs.
    {
       struct KArgs { KScene sc; KProbes pr; int first_round; RadOrder ro; };
-      static_assert(alignof(RadOrder) == 8 && __builtin_offsetof(KArgs, pr) == sizeof(KScene) && __builtin_offsetof(KArgs, first_round) == sizeof(KScene) + sizeof(KProbes) &&
+      static_assert(alignof(RadOrder) == 8 && sizeof(RadOrder) % 8 == 0 && __builtin_offsetof(KArgs, pr) == sizeof(KScene) && __builtin_offsetof(KArgs, first_round) == sizeof(KScene) + sizeof(KProbes) &&
                     __builtin_offsetof(KArgs, ro) == sizeof(KScene) + sizeof(KProbes) + 8, "KArgs is the kernel argument segment of k_radiance");
       typedef const KArgs __attribute__((address_space(4))) *KArgsPtr;
       KArgsPtr ka = (KArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
@@ -362,8 +369,8 @@ template <int PART, bool SMALL = false> __global__ __launch_bounds__(MDH_BLOCK, 
       if (probe_raw < pr2.probe_end) {
          const int ty = probe_raw / pr2.pcx, tx = probe_raw - ty * pr2.pcx;
          const int i = tx * pr2.rres + x, j = ty * pr2.rres + y;
-         atlas_store(pr2.rad, pr2.fmt, atlas_index(pr2.pcx, pr2.rres, pr2.rshift, i, j), c);
-         if (ro2.steps) // the ray's sort key: the levels of its primary-march and soft-shadow step counts
+         if (PHASE != 1) atlas_store(pr2.rad, pr2.fmt, atlas_index(pr2.pcx, pr2.rres, pr2.rshift, i, j), c);
+         if (ro2.steps && PHASE != 2) // the ray's sort key: the levels of its primary-march and soft-shadow step counts
             ro2.steps[(size_t)(probe_raw - pr2.probe_begin) * (pr2.rres * pr2.rres) + y * pr2.rres + x] = (unsigned char)((rad_level(ph.steps & 0xffff) << 4) | rad_level(ph.steps >> 16));
       }
    }

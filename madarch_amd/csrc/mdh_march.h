@@ -701,9 +701,12 @@ MDH_DEV KProbes probes_fresh(const KProbes &pr)
 // SPEC: 0 = no second point (the radiance pass), 1 = the reflection as the reference's renderer fixes it
 // (M_COMPUTE_INDIRECT_SPECULAR = 2, or none), 2 = the kernel variant that holds the two other bodies of
 // render_probes.glsl:264-272 (cfg.spec_mode 1 or 3; MDH_OPT_INDIRECT_SPECULAR)
-template <int PART, int MODE, int SPEC, bool QVIS>
+// PHASE (the radiance pass as two kernels, an experiment: MDH_OPT... MADARCH_HIP_RAD_SPLIT): 0 = the whole program; 1 = up to the
+// direct light of the hit point, which goes to `rec` (RadRecord) instead of being shaded further; 2 = from such a record on
+struct RadRecord { float4 p_pm, n_sd0, lo; }; // {P, material id or -1: no hit}, {N, first-step distance}, {direct light, -}
+template <int PART, int MODE, int SPEC, bool QVIS, int PHASE = 0>
 MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCfg cfg, bool lane_valid, f3 from, f3 dir_in,
-                            PrimaryHit &ph, bool &hit, f3 &pos_out)
+                            PrimaryHit &ph, bool &hit, f3 &pos_out, RadRecord *rec = nullptr)
 {
    constexpr bool P2 = (PART & MDH_PF_POW2) != 0;
    constexpr bool REFLECT = SPEC != 0 && MODE == 0; // (modes 1 and 2 never shade a second point: no loop, and nothing kept for one)
@@ -740,10 +743,13 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
          float t;
          int steps;
          PH_T0(pt);
-         const bool h = march_plain<PART>(sc, ro, rd, sc.max_dist, t, steps);
+         RadRecord rr; // (PHASE 2: what phase 1 left of this ray)
+         if (PHASE == 2) { rr = *rec; t = 0.0f; steps = 0; }
+         const bool h = PHASE == 2 ? __float_as_int(rr.p_pm.w) >= 0 : march_plain<PART>(sc, ro, rd, sc.max_dist, t, steps);
          PH_ADD(pt, 0);
          if (ctx == 0) { hit = h; ph.steps = steps; }
          active = false; // a miss ends the chain (ctx 1: specular_col stays 0, render_probes.glsl:142-144)
+         if (PHASE == 1 && !h) { rec->p_pm = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(-1)); return F3(0.0f, 0.0f, 0.0f); }
          if (SPEC == 2 && ctx == 1 && full2 && !h) { // ... or is the sky seen along the reflection, render_probes.glsl:216-218
             const float s = rd.y * 0.7f;
             park_store3<MDH_PARK_SPEC>(pk, wb, F3(0.30f - s, 0.36f - s, 0.60f - s));
@@ -754,11 +760,14 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
          if (h) {
             f3 P = ro + rd * t;
             int index = -1;
-            MDH_WORK(3);
-            (void)sdf_info<PART>(sc, P, index);
             f3 N;
             int pm;
+            if (PHASE == 2) { P = xyz(rr.p_pm); N = xyz(rr.n_sd0); pm = __float_as_int(rr.p_pm.w); }
+            else {
+            MDH_WORK(3);
+            (void)sdf_info<PART>(sc, P, index);
             primitive_info<(PART & MDH_PF_CUSTOM) != 0>(sc, index, P, N, pm);
+            }
             if (ctx == 0) {
                park_store1<PARK_MAT>(pk, wb, __int_as_float(pm));
                ph.index = index; ph.t = t;
@@ -771,10 +780,10 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
                // Every shadow and probe-visibility ray of this point starts AT from_off with t = 0, so
                // their first SDF evaluation is at the same position (from_off + dir * 0): it is done
                // once here and each ray replays its first iteration with this value.
-               const float sd0 = MDH_SHARE_FIRST_STEP ? sdf<PART>(sc, from_off) : 0.0f;
+               const float sd0 = PHASE == 2 ? rr.n_sd0.w : (MDH_SHARE_FIRST_STEP ? sdf<PART>(sc, from_off) : 0.0f);
                // ---- compute_direct_lighting (lighting.glsl:1-40) at P, seen along rd
-               f3 Lo = F3(0.0f, 0.0f, 0.0f);
-               {
+               f3 Lo = PHASE == 2 ? xyz(rr.lo) : F3(0.0f, 0.0f, 0.0f);
+               if (PHASE != 2) {
 #pragma unroll 1
                   for (int li = 0; li < sc.total_lights; ++li) {
                      // (the material is read again for every light, through an id the compiler cannot look through: read
@@ -828,6 +837,12 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
                      Lo = Lo + contrib * shadows;
                      PH_ADD(pt, 3);
                   }
+               }
+               if (PHASE == 1) { // the record: the point, its normal and material, its first step and its direct light
+                  rec->p_pm = make_float4(P.x, P.y, P.z, __int_as_float(pm));
+                  rec->n_sd0 = make_float4(N.x, N.y, N.z, sd0);
+                  rec->lo = make_float4(Lo.x, Lo.y, Lo.z, 0.0f);
+                  return Lo;
                }
                if (ctx == 0) park_store3<9>(pk, wb, Lo); // = direct
                f3 specular_col = Lo;                      // ctx 1: + the radiance tap below (render_probes.glsl:197-206)
