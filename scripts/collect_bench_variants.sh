@@ -12,7 +12,6 @@ $B --steps 200 --warmup 20 --atlas f32 2>/dev/null | tail -1 > $OUT/bench_f32_at
 $B --steps 200 --warmup 20 --animate-light 2>/dev/null | tail -1 > $OUT/bench_animated_light.json &&
 $B --steps 200 --warmup 20 --swap-buffers 2>/dev/null | tail -1 > $OUT/bench_swap_buffers.json &&
 $B --steps 200 --warmup 20 --rehearse-rccl 2>/dev/null | tail -1 > $OUT/bench_rehearse_rccl.json &&
-timeout -k 10 200 python scripts/ball_game_bench.py > $OUT/ball_game.log 2>&1 &&
 timeout -k 10 300 python scripts/emulate_shards.py 4096 4096 $OUT/shards_4096.json > $OUT/shards_4096.log 2>&1 &&
 timeout -k 10 300 python scripts/emulate_shards.py 1920 1080 $OUT/shards_1080p.json > $OUT/shards_1080p.log 2>&1
 for f in driver_20steps f32_atlases animated_light swap_buffers rehearse_rccl; do
@@ -21,4 +20,4 @@ import json
 d=json.loads(open('$OUT/bench_$f.json').read())
 print('%-16s %8.1f Mpix/s %.4f ms | serial %8.1f' % ('$f', d['value'], d['ms_per_step'], d.get('value_serial', 0)))"
 done
-tail -3 $OUT/ball_game.log; cat $OUT/shards_4096.log $OUT/shards_1080p.log
+cat $OUT/shards_4096.log $OUT/shards_1080p.log
