@@ -1174,7 +1174,12 @@ static size_t lds_bytes(const mdh_renderer *r) { return (size_t)(r->ks.table_f4 
 static size_t lds_bytes_march(const mdh_renderer *r) { return lds_bytes(r) + (size_t)MDH_PARK_DWORDS * MDH_BLOCK * sizeof(float); }
 // the screen pass runs without the visibility queue, whose entries, first steps and result words are the park
 // slots from 15 up: 3 KiB less per workgroup, room for one more workgroup of a neighbouring pass on the CU
-static size_t lds_bytes_screen(const mdh_renderer *r) { return lds_bytes(r) + (size_t)(r->opt_mode == 2 ? MDH_DIRECT_PARK_ROWS : MDH_SCR_PARK_ROWS) * MDH_BLOCK * sizeof(float); }
+static size_t lds_bytes_screen(const mdh_renderer *r)
+{
+   // (scenes with a space partition: three more rows, the second shaded point's normal across its visibility marches, MDH_PARK_VD_ROW)
+   const int rows = r->opt_mode == 2 ? MDH_DIRECT_PARK_ROWS : (r->part.enable && MDH_PART_PARK_VD ? std::max(MDH_SCR_PARK_ROWS, MDH_PARK_VD_ROW + 3) : MDH_SCR_PARK_ROWS);
+   return lds_bytes(r) + (size_t)rows * MDH_BLOCK * sizeof(float);
+}
 
 // ------------------------------------------------------------------ hiprtc build of user-defined kinds
 // MDH_OPT_JIT: instead of interpreting the MDH_X programs, compile them.  Every program becomes a

@@ -24,6 +24,10 @@
 #ifndef MDH_TAP_EARLY_PART
 #define MDH_TAP_EARLY_PART 0
 #endif
+#ifndef MDH_PART_PARK_VD
+#define MDH_PART_PARK_VD 1
+#endif
+#define MDH_PARK_VD_ROW 19 // (rows 19-21: allocated by the host for scenes with a space partition, lds_bytes_screen; six wavefronts per SIMD need 22 rows or fewer)
 #ifndef MDH_SKIP_NULL_RAYS
 #define MDH_SKIP_NULL_RAYS 1
 #endif
@@ -718,6 +722,11 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
    // the irradiance tap of a cage corner issued before its visibility march (its loads land during the march) -- not in the
    // space-partition variants, whose march needs the registers (MDH_TAP_EARLY_PART)
    constexpr bool TAP_EARLY = MDH_TAP_EARLY != 0 && (MDH_TAP_EARLY_PART != 0 || !(PART & MDH_PF_PART));
+   // the space-partition variants of the screen pass: the shaded point and its normal come back from park rows behind every
+   // corner's visibility march (the second point's wait in the rows of its colour and in three rows of their own) and the probe's grid position is derived again there:
+   // the lookups of that march need the registers -- kept live across it, these values went to scratch memory eight times per
+   // shaded point (300 MB of spill stores per 1080p launch at six wavefronts per SIMD)
+   constexpr bool PARK_VD = MDH_PART_PARK_VD != 0 && (PART & MDH_PF_PART) != 0 && SPEC == 1 && MODE == 0 && CORNER_UNROLL == 1;
    // the second point goes through the whole of pixel_color_probes' lighting (compute_indirect_specular) ...
    const bool full2 = SPEC == 2 && cfg.spec_mode == 3;
    // ... or is only a position that the cage probes of the FIRST point light (sample_radiance_with_specular)
@@ -773,6 +782,9 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
                ph.index = index; ph.t = t;
                park_store3<0>(pk, wb, P);
                park_store3<3>(pk, wb, N);
+            } else if (PARK_VD) { // (the second point's P in the rows of its colour -- written behind its corner loop -- and its N in rows of their own)
+               park_store3<MDH_PARK_SPEC>(pk, wb, P);
+               park_store3<MDH_PARK_VD_ROW>(pk, wb, N);
             }
             PH_ADD(pt, 1);
             if (MODE != 1) {
@@ -976,6 +988,12 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
                      }
                      vis_bits |= (vis != 0.0f ? 1 : 0) << i;
                      pq = probes_fresh(pr);
+                     i3 q2 = q;
+                     if (PARK_VD) { // the point again, from its park rows (nothing in the march reads P or N: they need not live through it)
+                        if (ctx == 0) { P = park_load3<0>(pk, wb); N = park_load3<3>(pk, wb); }
+                        else { P = park_load3<MDH_PARK_SPEC>(pk, wb); N = park_load3<MDH_PARK_VD_ROW>(pk, wb); }
+                        q2 = cage_probe(pq, gp, i); // (the same clamps of the same cell: the same probe)
+                     }
                      PH_ADD(pt, 5);
                      if (irrp) { // render_probes.glsl:26-62
                         float angle = (dot(vd, N) + 1.0f) * 0.5f;
@@ -991,7 +1009,7 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
                         if (TAP_EARLY) tx = atlas_tap_resolve(pq.irr, pq.fmt, tap, u8_tab);
                         else { // (the space-partition variants: the tap's eight registers do not live across the visibility march)
                            const f2 rid = parked ? park_load2<MDH_PARK_RIDN>(pk, wb) : rid_n;
-                           const f2 base = probe_id_to_coord<P2>(pq, grid_to_probe_id<P2>(pq, q));
+                           const f2 base = probe_id_to_coord<P2>(pq, grid_to_probe_id<P2>(pq, q2));
                            tx = atlas_sample<P2>(pq.irr, pq.fmt, pq.pcx, pq.pcy, pq.ires, pq.ishift, pq.irr_w, pq.irr_h, base.x + div_pcx<P2>(pq, rid.x), base.y + div_pcy<P2>(pq, rid.y), u8_tab, pq.m_ires);
                         }
 #endif
@@ -1007,7 +1025,7 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
                      } else { // render_probes.glsl:170-183; probe_to_spec = -vd
                         float weight = dot(-vd, -N);
                         weight *= vis;
-                        if (weight > accw) { accw = weight; best_q = q.x | (q.y << 10) | (q.z << 20); acc = -vd; }
+                        if (weight > accw) { accw = weight; best_q = q2.x | (q2.y << 10) | (q2.z << 20); acc = -vd; }
                      }
                      }
                      if (irrp) { // render_probes.glsl:34-62: the trilinear factor and the sum
