@@ -170,6 +170,30 @@ package Madarch_HIP is
    function Comm_Reduce_Framebuffer (R : Handle; Root : int) return Status
      with Import, Convention => C, External_Name => "mdh_comm_reduce_framebuffer";
 
+   function Comm_Available return Status
+     with Import, Convention => C, External_Name => "mdh_comm_available";
+
+   function Comm_Abort (R : Handle) return Status
+     with Import, Convention => C, External_Name => "mdh_comm_abort";
+
+   --  The same sharded frame without a collective library (madarch_hip.h, mdh_peer_*): every
+   --  rank exports 512 bytes of interprocess handles, the host hands all ranks' blobs to every
+   --  rank, Peer_Init opens them, and Render's exchange is device-to-device copies ordered on
+   --  the device.  One process per rank, one node; the form several ranks can run on ONE GPU.
+   Peer_Blob_Bytes : constant := 512;
+   type Peer_Blob is array (0 .. Peer_Blob_Bytes - 1) of Interfaces.C.unsigned_char
+     with Convention => C;
+   type Peer_Blobs is array (Natural range <>) of Peer_Blob
+     with Convention => C;
+
+   function Peer_Export (R : Handle; Blob_Out : access Peer_Blob) return Status
+     with Import, Convention => C, External_Name => "mdh_peer_export";
+
+   --  Blobs: the address of World blobs in rank order
+   function Peer_Init
+     (R : Handle; Blobs : System.Address; Rank, World : int) return Status
+     with Import, Convention => C, External_Name => "mdh_peer_init";
+
    function Last_Error return Strings.chars_ptr
      with Import, Convention => C, External_Name => "mdh_last_error";
 end Madarch_HIP;
