@@ -21,6 +21,9 @@
 #ifndef MDH_TAP_EARLY
 #define MDH_TAP_EARLY 1
 #endif
+#ifndef MDH_TWIN_PREV_PART
+#define MDH_TWIN_PREV_PART 0
+#endif
 #ifndef MDH_TAP_EARLY_PART
 #define MDH_TAP_EARLY_PART 0
 #endif
@@ -722,6 +725,9 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
    // the irradiance tap of a cage corner issued before its visibility march (its loads land during the march) -- not in the
    // space-partition variants, whose march needs the registers (MDH_TAP_EARLY_PART)
    constexpr bool TAP_EARLY = MDH_TAP_EARLY != 0 && (MDH_TAP_EARLY_PART != 0 || !(PART & MDH_PF_PART));
+   // the x-twin's probe term kept for the corner behind it (item 6 of "Exact work elimination") -- not in the space-partition
+   // variants, where its four registers across the visibility march are scratch memory (MDH_TWIN_PREV_PART)
+   constexpr bool TWIN_PREV = MDH_TWIN_PREV != 0 && (MDH_TWIN_PREV_PART != 0 || !(PART & MDH_PF_PART));
    // the space-partition variants of the screen pass: the shaded point and its normal come back from park rows behind every
    // corner's visibility march (the second point's wait in the rows of its colour and in three rows of their own) and the probe's grid position is derived again there:
    // the lookups of that march need the registers -- kept live across it, these values went to scratch memory eight times per
@@ -932,7 +938,7 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
                      f3 s_term = F3(0.0f, 0.0f, 0.0f); // sqrt(irradiance tap) of this corner's probe
                      float wpre = 0.0f;                // its weight before the trilinear factor
                      const i3 q = cage_probe(pq, gp, i);
-                     const bool twin_prev = MDH_TWIN_PREV && irrp && (i & 1) && (folded & 1);
+                     const bool twin_prev = TWIN_PREV && irrp && (i & 1) && (folded & 1);
                      if (twin_prev) {
                         s_term = s_keep;
                         wpre = w_keep;
@@ -1036,7 +1042,7 @@ MDH_DEV f3 shade_structured(const KScene &sc, const KProbes &pr, const MachineCf
                         weight *= tri.x * tri.y * tri.z;
                         acc = acc + s_term * weight;
                         accw += weight;
-                        if (MDH_TWIN_PREV) { s_keep = s_term; w_keep = wpre; }
+                        if (TWIN_PREV) { s_keep = s_term; w_keep = wpre; }
                      }
                      PH_ADD(pt, 6);
                   }
