@@ -1828,12 +1828,13 @@ static int run_pass(mdh_renderer *r, int pass, hipStream_t st, int src, int dst,
          // inside a frame the launch also marches the scattering texels' camera rays (k_visibility's second part, mdh_kernels.h)
          const int vis_blocks = blocks;
          if (MDH_SCAT_SPLIT && r->fuse_scat_march) blocks += (int)(((long)vol.sw * vol.sh + MDH_BLOCK - 1) / MDH_BLOCK);
+         const size_t vis_lds = lds_bytes(r) + (MDH_VIS_QUEUE == 2 ? (size_t)(MDH_BLOCK / 64) * MDH_VIS_Q_FLOATS * sizeof(float) : 0); // (the second form of the ray queue keeps its rays in LDS)
          if (jit) {
             struct { KScene sc; KVolumetrics vol; KCamera cam; int vis_blocks; } args = {r->ks, vol, cam, vis_blocks};
-            int rc = jit_launch(jm->fn[kname], blocks, MDH_BLOCK, lds_bytes(r), st, args);
+            int rc = jit_launch(jm->fn[kname], blocks, MDH_BLOCK, vis_lds, st, args);
             if (rc != MDH_OK) return rc;
          } else
-            MDH_LAUNCH_PF(k_visibility, dim3(blocks), dim3(MDH_BLOCK), lds_bytes(r), r->ks, vol, cam, vis_blocks);
+            MDH_LAUNCH_PF(k_visibility, dim3(blocks), dim3(MDH_BLOCK), vis_lds, r->ks, vol, cam, vis_blocks);
       }
       break;
    }

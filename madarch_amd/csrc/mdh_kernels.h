@@ -912,6 +912,8 @@ __global__ __launch_bounds__(MDH_IRR_BLOCK) void k_irradiance(KProbes pr, const 
 #ifndef MDH_VIS_ROUNDS
 #define MDH_VIS_ROUNDS 4
 #endif
+// LDS of the second form of the queue, per wavefront, in floats: seven per ray, the list (u16) and the reached bytes
+#define MDH_VIS_Q_FLOATS (7 * 64 * MDH_VIS_ROUNDS + 64 * MDH_VIS_ROUNDS / 2 + 64 * MDH_VIS_ROUNDS / 4)
 #ifndef MDH_VIS_REFILL
 #define MDH_VIS_REFILL 16
 #endif
@@ -970,7 +972,104 @@ template <int PART> __global__ __launch_bounds__(MDH_BLOCK) void k_visibility(KS
    }
    const int W = vol.vw, H = vol.vh * vol.vz;
    const long n = (long)W * H;
-#if MDH_VIS_QUEUE
+#if MDH_VIS_QUEUE == 2
+   // The second form of the queue (round 4): the set-up and the finish of a froxel stay DENSE -- a wavefront owns MDH_VIS_ROUNDS x 64
+   // froxels and walks them round by round at full lanes -- and only the MARCH goes through a list with replacement, as
+   // queued_visibility does for the probe rays: the rays that need marching are listed (ballot ranks), their origin, direction and
+   // length wait in LDS, a lane whose ray has ended takes the next entry (seven LDS reads), a ray that reaches its light sets its byte.
+   {
+      constexpr int R = MDH_VIS_ROUNDS, NJ = 64 * R;
+      const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+      const long wave_global = (long)blockIdx.x * (MDH_BLOCK / 64) + wv;
+      const long begin = wave_global * NJ;
+      if (begin >= n) return; // (wave-uniform)
+      float *wbase = (float *)(s_tab + sc.table_f4 + sc.part_bits_f4) + (size_t)wv * MDH_VIS_Q_FLOATS;
+      float *jp = wbase;                                             // [7][NJ]: pos.xyz, L.xyz, L_dist of every froxel's ray
+      unsigned short *list = (unsigned short *)(wbase + 7 * NJ);     // [NJ] the rays to march
+      unsigned char *reached = (unsigned char *)(list + NJ);         // [NJ] 1: the ray reached its light (or never had to be marched)
+      f3 result[R], dirs[R], Ls[R], rads[R];
+      float Ld[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) result[r] = F3(0.0f, 0.0f, 0.0f);
+      for (int l = 0; l < sc.total_lights; ++l) { // sample_lights :8-19, light by light for all the wavefront's froxels
+         int njobs = 0;
+#pragma unroll
+         for (int r = 0; r < R; ++r) { // set-up, dense
+            const long lin = begin + r * 64 + lane;
+            int i, j;
+            froxel_texel(W, H, lin < n ? lin : n - 1, i, j);
+            f3 pos;
+            froxel_point(vol, cam, W, H, i, j, pos, dirs[r]);
+            rads[r] = sample_light<(PART & MDH_PF_CUSTOM) != 0>(sc, l, pos, F3(1.0f, 0.0f, 0.0f), Ls[r], Ld[r]); // compute_frustrum_visibility.glsl:12
+            MDH_WORK(0);
+            const int e = r * 64 + lane;
+            jp[0 * NJ + e] = pos.x; jp[1 * NJ + e] = pos.y; jp[2 * NJ + e] = pos.z;
+            jp[3 * NJ + e] = Ls[r].x; jp[4 * NJ + e] = Ls[r].y; jp[5 * NJ + e] = Ls[r].z; jp[6 * NJ + e] = Ld[r];
+            const bool need = lin < n && 0.0f < Ld[r]; // raycast_visibility's first test: a loop that is never entered leaves the light visible
+            reached[e] = need ? 0 : 1;
+            const unsigned long long m = __ballot(need);
+            if (need) list[njobs + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = (unsigned short)e;
+            njobs += (int)__popcll(m);
+         }
+         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+         __builtin_amdgcn_wave_barrier();
+         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+         { // the march, through the list with replacement (raymarching.glsl:39-56 from its second test on)
+            int head = 0, job = -1;
+            float total = 0.0f, vmax = 0.0f;
+            f3 o = F3(0.0f, 0.0f, 0.0f), d = o;
+            for (;;) {
+               const unsigned long long idle = __ballot(job < 0);
+               const int n_idle = (int)__popcll(idle);
+               if (head < njobs && n_idle >= MDH_VIS_REFILL) {
+                  if (job < 0) {
+                     const int my = head + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(idle >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)idle, 0u));
+                     if (my < njobs) {
+                        const int e = list[my];
+                        o = F3(jp[0 * NJ + e], jp[1 * NJ + e], jp[2 * NJ + e]);
+                        d = F3(jp[3 * NJ + e], jp[4 * NJ + e], jp[5 * NJ + e]);
+                        vmax = jp[6 * NJ + e];
+                        total = 0.0f;
+                        job = e;
+                     }
+                  }
+                  head += n_idle;
+               }
+               if (__ballot(job >= 0) == 0ull) break;
+               if (job >= 0) {
+                  MDH_WORK(1);
+                  const float dist = sdf<PART>(sc, o + d * total);
+                  if (dist < MDH_EPS) job = -1; // blocked: the byte stays 0
+                  else {
+                     total += dist;
+                     if (!(total < vmax)) { reached[job] = 1; job = -1; }
+                  }
+               }
+            }
+         }
+         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+         __builtin_amdgcn_wave_barrier();
+         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+         for (int r = 0; r < R; ++r) { // the light's term, dense
+            const float visibility = reached[r * 64 + lane] ? 1.0f : 0.0f;
+            const f3 L_in = rads[r] * (sexp(-Ld[r] * MDH_TAU) * visibility);
+            result[r] = result[r] + (L_in * MDH_TAU) * henvey_greenstein_phase(Ls[r], dirs[r]);
+         }
+         __builtin_amdgcn_wave_barrier(); // (the next light's set-up overwrites what this finish read)
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+         const long lin = begin + r * 64 + lane;
+         if (lin < n) {
+            int i, j;
+            froxel_texel(W, H, lin, i, j);
+            float *o = vol.vis + ((size_t)j * W + i) * 3;
+            o[0] = result[r].x; o[1] = result[r].y; o[2] = result[r].z;
+         }
+      }
+   }
+#elif MDH_VIS_QUEUE
    const long wave_global = (long)blockIdx.x * (MDH_BLOCK / 64) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
    const long begin = wave_global * (64 * MDH_VIS_ROUNDS);
    if (begin >= n) return; // (wave-uniform)
