@@ -421,6 +421,57 @@ class Renderer {
       if (Rank == 0) std::remove(Id_File.c_str()); // (every rank holds the id: the collective join has returned)
       if (state == 2) throw Program_Error(error);
    }
+   // ---- the same sharded frame without a collective library: the peer exchange (include/madarch_hip.h, mdh_peer_*).  Every rank
+   // publishes its 512 bytes of interprocess handles as a file of `Dir` and reads the others'; Render is then the sharded frame,
+   // its exchange being device-to-device copies between the ranks' processes (one process per rank, one node; several ranks
+   // may share ONE GPU).  `Dir` must be this run's own (files of an earlier run are refused by their age, as in Join_Node).
+   static void Publish_File(const std::string &Path, const void *Data, size_t N)
+   {
+      const std::string tmp = Path + ".tmp";
+      FILE *f = fopen(tmp.c_str(), "wb");
+      if (!f || fwrite(Data, 1, N, f) != N) throw Program_Error("cannot write " + tmp);
+      fclose(f);
+      if (rename(tmp.c_str(), Path.c_str()) != 0) throw Program_Error("cannot publish " + Path);
+   }
+   static std::vector<uint8_t> Await_File(const std::string &Path, size_t N, std::chrono::system_clock::time_point Since, double Timeout_S)
+   {
+      const auto t0 = std::chrono::steady_clock::now();
+      for (;;) {
+         struct stat sb;
+         if (stat(Path.c_str(), &sb) == 0 && std::chrono::duration<double>(Since - std::chrono::system_clock::from_time_t(sb.st_mtime)).count() <= Timeout_S) {
+            std::vector<uint8_t> buf(N + 1);
+            FILE *f = fopen(Path.c_str(), "rb");
+            const size_t n = f ? fread(buf.data(), 1, buf.size(), f) : 0;
+            if (f) fclose(f);
+            if (n == N) { buf.resize(N); return buf; }
+         }
+         if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > Timeout_S) throw Program_Error("a rank never published " + Path);
+         std::this_thread::sleep_for(std::chrono::milliseconds(10));
+      }
+   }
+   void Join_Peers(int Rank, int World, const std::string &Dir, double Timeout_S = 120.0) const
+   {
+      const auto wall0 = std::chrono::system_clock::now();
+      uint8_t blob[MDH_PEER_BLOB_BYTES];
+      Check(mdh_peer_export(h_.get(), blob));
+      Publish_File(Dir + "/peer_" + std::to_string(Rank) + ".blob", blob, sizeof blob);
+      std::vector<uint8_t> all((size_t)World * MDH_PEER_BLOB_BYTES);
+      for (int q = 0; q < World; ++q) {
+         const auto b = Await_File(Dir + "/peer_" + std::to_string(q) + ".blob", MDH_PEER_BLOB_BYTES, wall0, Timeout_S);
+         std::copy(b.begin(), b.end(), all.begin() + (size_t)q * MDH_PEER_BLOB_BYTES);
+      }
+      Check(mdh_peer_init(h_.get(), all.data(), Rank, World));
+   }
+   // every rank has reached this point of the run (a file per rank and tag): e.g. before anybody leaves the exchange --
+   // a rank's atlases must outlive the peers' last copies out of them
+   static void Peers_Barrier(int Rank, int World, const std::string &Dir, const std::string &Tag, double Timeout_S = 120.0)
+   {
+      const auto wall0 = std::chrono::system_clock::now();
+      const uint8_t one = 1;
+      Publish_File(Dir + "/" + Tag + "_" + std::to_string(Rank), &one, 1);
+      for (int q = 0; q < World; ++q) (void)Await_File(Dir + "/" + Tag + "_" + std::to_string(q), 1, wall0, Timeout_S);
+   }
+   void Finish() const { Check(mdh_finish(h_.get())); }
    void Leave_Node() const { Check(mdh_comm_destroy(h_.get())); }
    void Barrier() const { Check(mdh_comm_barrier(h_.get())); }
    double Max_Over_Ranks(double V) const { Check(mdh_comm_max_f64(h_.get(), &V)); return V; }

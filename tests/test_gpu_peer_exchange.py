@@ -90,3 +90,26 @@ def test_peer_exchange_between_processes_on_one_gpu(hip, world, probes_name, ove
         assert helpers.same_bits(o["irradiance"], want["irradiance"]), "irradiance atlas of rank %d" % rank
         assert o["exchanges"] == frames and o["exchange_ms"] >= 0.0
     print("peer exchange, %d ranks on one GPU: %s ms per frame" % (world, ", ".join("%.4f" % o["exchange_ms"] for o in outs)))
+
+
+def test_cpp_example_renders_with_the_peer_exchange(tmp_path):
+    """examples/global_illumination.cpp --rank R --world 2 --peer-dir D --device 0: two C++ processes on the C ABI alone (no Python, no
+    torch, no RCCL) render the example as a sharded frame on the ONE GPU; their tiles add up to the frame the plain program renders."""
+    import subprocess
+    exe = os.path.join(ROOT, "examples", "bin", "global_illumination")
+    assert os.path.exists(exe), "build first (python -c 'import __graft_entry__ as g; g.build()')"
+    W, H, frames = 96, 64, 5
+    plain = str(tmp_path / "plain.f32")
+    r = subprocess.run([exe, str(W), str(H), str(frames), plain], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    d = tmp_path / "peers"
+    d.mkdir()
+    out = str(tmp_path / "node.f32")
+    procs = [subprocess.Popen([exe, str(W), str(H), str(frames), out, "--rank", str(q), "--world", "2", "--peer-dir", str(d), "--device", "0"],
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for q in range(2)]
+    for p in procs:
+        so, se = p.communicate(timeout=300)
+        assert p.returncode == 0, so + se
+    want = np.fromfile(plain, dtype=np.float32)
+    got = sum(np.fromfile(out + ".rank%d" % q, dtype=np.float32) for q in range(2))
+    assert np.array_equal(got, want, equal_nan=True)
