@@ -696,3 +696,64 @@ def test_screen_tile_order_changes_no_pixel(hip, scene, mode, world, overlap):
         if world == 1:  # (the geometry buffer of other ranks' tiles is never written, nor cleared)
             assert all(same_bits(x, y) for x, y in zip(gb_a, gb_b))
         assert (px_a == px_b).all()
+
+
+@pytest.mark.parametrize("sres,sstep,vres,vstep", [((23, 21), 0.0125, (20, 20, 24), 0.1),   # 192 steps: two chunks of the fold's 128; texel count no multiple of 16
+                                                   ((17, 5), 0.3, (24, 16, 12), 0.25),         # ten coarse steps, a ragged froxel volume (no 8x8 tiles)
+                                                   ((40, 40), 0.007, (16, 16, 30), 0.1)])      # 429 steps: four chunks
+def test_scattering_steps_beyond_one_chunk(hip, orc, sres, sstep, vres, vstep):
+    """The scattering pass's two kernels (k_scat_march inside the visibility launch, k_scat_fold: a texel's steps spread over lanes
+    in chunks of 128, folded in step order) for step counts and texture sizes the default settings never reach; froxel and
+    scattering textures whole, bit for bit, serial frames and frames in flight, and a scattering pass outside a frame."""
+    vol = renderers.Volumetrics_Settings(Visibility_Resolution=vres, Visibility_Step_Size=vstep, Scattering_Resolution=sres, Scattering_Step_Size=sstep)
+    outs = []
+    for b in (hip, orc):
+        R = make("light_shafts", 72, 40, b, probes=SMALL_PROBES, Volumetrics=vol)
+        out = snapshot(R, 3)
+        # single passes outside a frame after a camera move: the scattering pass marches its own camera rays then
+        R.Set_Camera_Position((2.5, 2.5, -0.5))
+        R.Render_Pass(B.PASS_VISIBILITY)
+        R.Render_Pass(B.PASS_SCATTERING)
+        out["visibility2"], out["scattering2"] = R.Read_Texture(B.TEX_VISIBILITY), R.Read_Texture(B.TEX_SCATTERING)
+        outs.append(out)
+    assert_parity(*outs)
+    for k in ("visibility2", "scattering2"):
+        assert same_bits(outs[0][k], outs[1][k]), k
+    assert outs[1]["scattering"][..., :3].max() > 0
+
+
+@pytest.mark.parametrize("method", [0, 1, 2])
+def test_partition_build_with_more_instances_than_a_wavefront(hip, orc, method):
+    """k_partition_build (one wavefront per cell; lanes = the instances of a kind, 64 at a time) for kinds with more instances than
+    lanes and cells whose pre-candidates run into hundreds: 150 spheres and 70 boxes in a coarse grid, all three builders, the tables
+    and warning counts bit for bit, and frames through the general (not the small-scene) bit lookup."""
+    from madarch_amd import materials, scenes, windows
+    from madarch_amd.lights import point_lights
+    from madarch_amd.primitives import boxes, planes, spheres
+    rng = np.random.RandomState(7)
+    cs = (rng.rand(150, 3) * np.array([7.0, 7.0, 12.0]) + np.array([-0.5, -0.5, -5.5])).astype(np.float32)
+    cb = (rng.rand(70, 3) * np.array([7.0, 7.0, 12.0]) + np.array([-0.5, -0.5, -5.5])).astype(np.float32)
+    outs = []
+    for b in (hip, orc):
+        part = scenes.Partitioning_Settings(Enable=True, Index_Count=12, Grid_Dimensions=(3, 3, 4), Grid_Spacing=(3.0, 3.0, 3.5), Grid_Offset=(-1.0, -1.0, -6.0))
+        scene = scenes.Compile([(spheres.Sphere, 160), (planes.Plane, 8), (boxes.Box, 70)], [(point_lights.Point_Light, 2)], Partitioning=part)
+        R = renderers.Create(windows.Open(48, 32), scene, Probes=SMALL_PROBES, Volumetrics=renderers.No_Volumetrics, Binding=b)
+        for m, alb in enumerate(((0.8, 0.8, 0.8), (0.9, 0.1, 0.1), (0.1, 0.1, 0.9))):
+            R.Set_Material(m, materials.Create(alb, 0.0, 0.6))
+        for n, o in (((0, 1, 0), 1.0), ((0, -1, 0), 7.0), ((1, 0, 0), 1.0), ((-1, 0, 0), 7.0), ((0, 0, 1), 6.0), ((0, 0, -1), 7.0)):
+            R.Add_Primitive(planes.Plane, planes.Create(n, o, 0))
+        for i, c in enumerate(cs):
+            R.Add_Primitive(spheres.Sphere, spheres.Create(tuple(float(v) for v in c), 0.12 + 0.02 * (i % 5), 1 + i % 2))
+        for i, c in enumerate(cb):
+            R.Add_Primitive(boxes.Box, boxes.Create(tuple(float(v) for v in c), (0.1 + 0.03 * (i % 4), 0.15, 0.1), 1 + i % 2))
+        R.Set_Light(1, point_lights.Point_Light, point_lights.Create((3.0, 6.0, 0.0), (0.9, 0.9, 0.9)))
+        R.Set_Camera_Position((3.0, 3.0, -4.0))
+        R.Set_Option(B.OPT_GBUFFER, 1)
+        R.Update_Partitioning(method)
+        out = snapshot(R, 2)
+        out["partition"], out["warnings"] = R.Read_Partitioning(), np.array([R.Partition_Warnings()])
+        outs.append(out)
+    assert same_bits(outs[0]["partition"], outs[1]["partition"]) and same_bits(outs[0]["warnings"], outs[1]["warnings"])
+    if method != 0:
+        assert outs[1]["warnings"][0] > 0  # Index_Count = 12 is too small for what the fast builders collect in cells of this grid
+    assert_parity(*outs)
