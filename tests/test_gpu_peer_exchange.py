@@ -113,3 +113,48 @@ def test_cpp_example_renders_with_the_peer_exchange(tmp_path):
     want = np.fromfile(plain, dtype=np.float32)
     got = sum(np.fromfile(out + ".rank%d" % q, dtype=np.float32) for q in range(2))
     assert np.array_equal(got, want, equal_nan=True)
+
+
+def test_peer_exchange_refusals(hip):
+    """what mdh_peer_* must refuse: joining before exporting, blobs that are none, a blob of this very process at another rank's place
+    (a process cannot open its own interprocess handles), an atlas format change while peers hold the handles, the collectives of
+    a communicator; and that leaving returns the renderer to rank 0 of 1."""
+    import helpers
+    from madarch_amd import _binding as B
+    R = helpers.make("global_illumination", 32, 24, hip, probes=helpers.SMALL_PROBES)
+    with pytest.raises(B.MadarchError) as e:
+        R.Peer_Init(bytes(2 * B.PEER_BLOB_BYTES), 0, 2)
+    assert e.value.status == B.MDH_E_STATE  # no export yet
+    blob = R.Peer_Export()
+    assert len(blob) == B.PEER_BLOB_BYTES and any(blob)
+    with pytest.raises(B.MadarchError) as e:
+        R.Peer_Init(blob + bytes(B.PEER_BLOB_BYTES), 0, 2)
+    assert e.value.status == B.MDH_E_INVALID  # rank 1's blob is no blob
+    R2 = helpers.make("global_illumination", 32, 24, hip, probes=helpers.SMALL_PROBES)
+    blob2 = R2.Peer_Export()
+    with pytest.raises(B.MadarchError) as e:
+        R.Peer_Init(blob + blob2, 0, 2)
+    assert e.value.status == B.MDH_E_INVALID and "one process" in str(e.value)
+    with pytest.raises(B.MadarchError) as e:
+        R.Peer_Init(blob2 + blob, 0, 2)
+    assert e.value.status == B.MDH_E_INVALID  # the blob at this rank's place is another renderer's
+    with pytest.raises(B.MadarchError) as e:
+        R.Set_Option(B.OPT_ATLAS_FORMAT, 1)
+    assert e.value.status == B.MDH_E_STATE  # the handles name the atlases as they are
+    # a world of one: every rank's blob is its own, nothing to open -- Render is a whole frame, the exchange a no-op that is timed
+    want = helpers.snapshot(helpers.make("global_illumination", 32, 24, hip, probes=helpers.SMALL_PROBES), 2)
+    R.Peer_Init(R.Peer_Export(), 0, 1)
+    assert (R.Get_Option(B.OPT_RANK), R.Get_Option(B.OPT_WORLD)) == (0, 1)
+    for call in (R.Comm_Barrier, lambda: R.Comm_Max(1.0), R.Comm_Reduce_Framebuffer):
+        with pytest.raises(B.MadarchError) as e:
+            call()
+        assert e.value.status == B.MDH_E_STATE
+    with pytest.raises(B.MadarchError):
+        R.Set_Option(B.OPT_IRRADIANCE_ALL, 0)
+    got = helpers.snapshot(R, 2)
+    for k in want:
+        assert helpers.same_bits(got[k], want[k]), k
+    R.Comm_Destroy()
+    R.Set_Option(B.OPT_WORLD, 1)  # the caller's again
+    R.Render(); R.Finish()
+    R.Destroy(); R2.Destroy()
