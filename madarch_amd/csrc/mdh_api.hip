@@ -247,6 +247,8 @@ struct mdh_renderer {
    int opt_mips = 0;
    int n_cus = 0;                          // compute units of the device
    // RadOrder (mdh_kernels.h): every ray's primary-march steps, the rays sorted by them, the sort's histograms
+   float *d_irr_taps = nullptr;  // k_irradiance's scratch: the taps of the pass's probes (mdh_kernels.h)
+   size_t irr_taps_cap = 0;      // in floats
    unsigned char *d_rad_steps = nullptr;
    unsigned *d_rad_order = nullptr, *d_rad_hist = nullptr;
    long rad_rays_cap = 0;                  // rays the three buffers are sized for
@@ -824,7 +826,7 @@ extern "C" int32_t mdh_destroy(mdh_renderer *r)
    if (r->d_comm_scratch) (void)hipFree(r->d_comm_scratch);
    if (r->d_rad_rec) (void)hipFree(r->d_rad_rec);
    peer_drop(r);
-   void *ptrs[] = {r->d_table_ring[0], r->d_table_ring[1], r->d_table_ring[2], r->d_table_ring[3], r->d_part_ring[0], r->d_part_ring[1], r->d_part_ring[2], r->d_part_ring[3], r->d_warn, r->d_query, r->d_rad_steps, r->d_rad_order, r->d_rad_hist, r->d_scr_cost, r->d_scr_order[0], r->d_scr_order[1], r->d_scr_hist, r->d_fb2[0], r->d_fb2[1], r->d_gb2[0][0], r->d_gb2[0][1], r->d_gb2[0][2], r->d_gb2[1][0], r->d_gb2[1][1], r->d_gb2[1][2]};
+   void *ptrs[] = {r->d_table_ring[0], r->d_table_ring[1], r->d_table_ring[2], r->d_table_ring[3], r->d_part_ring[0], r->d_part_ring[1], r->d_part_ring[2], r->d_part_ring[3], r->d_warn, r->d_query, r->d_irr_taps, r->d_rad_steps, r->d_rad_order, r->d_rad_hist, r->d_scr_cost, r->d_scr_order[0], r->d_scr_order[1], r->d_scr_hist, r->d_fb2[0], r->d_fb2[1], r->d_gb2[0][0], r->d_gb2[0][1], r->d_gb2[0][2], r->d_gb2[1][0], r->d_gb2[1][1], r->d_gb2[1][2]};
    for (void *p : ptrs)
       if (p) (void)hipFree(p);
    for (int q = 0; q < mdh_renderer::NSETS; ++q)
@@ -1801,9 +1803,26 @@ static int run_pass(mdh_renderer *r, int pass, hipStream_t st, int src, int dst,
       if (pr.ires * pr.ires <= 64) lds += (size_t)4 * 64 * sizeof(float4); // (the experiment's fold: all taps staged, four partial sums per texel)
       else
 #endif
+      float *tap_planes = nullptr;
+      if (MDH_IRR_CHANNELS && pr.ires * pr.ires <= 64 && MDH_IRR_BLOCK == 256 && n > 0) { // (k_irradiance: a channel per wavefront, the taps through device memory)
+         const size_t need = (size_t)n * 6 * MDH_IRR_CHANNELS_PLANE(pr.rres * pr.rres);
+         if (need > r->irr_taps_cap) { // (the scratch of irradiance passes only, which follow one another on their stream)
+            if (r->probe_stream) HIP_TRY(hipStreamSynchronize(r->probe_stream));
+            HIP_TRY(hipStreamSynchronize(r->stream));
+            r->irr_taps_cap = 0;
+            { void *q = r->d_irr_taps; r->d_irr_taps = nullptr; if (q) HIP_TRY(hipFree(q)); }
+            HIP_TRY(hipMalloc(&r->d_irr_taps, need * sizeof(float)));
+            r->irr_taps_cap = need;
+         }
+         tap_planes = r->d_irr_taps;
+         lds = MDH_IRR_CHANNELS_LDS;
+      } else
       if (MDH_IRR_WPRE && pr.ires * pr.ires <= 64 && MDH_IRR_BLOCK == 256) lds = MDH_IRR_WPRE_LDS; // (k_irradiance: the weights' pipeline)
       else
       if (MDH_IRR_CHUNK && pr.ires * pr.ires <= 64 && lds > (size_t)4 * MDH_IRR_CHUNK * sizeof(float4)) lds = (size_t)4 * MDH_IRR_CHUNK * sizeof(float4); // two chunk buffers
+#ifdef MDH_IRR_LDS_PAD
+      lds += MDH_IRR_LDS_PAD; // (experiment: what the pass's LDS footprint costs it beside the march kernels of frames in flight)
+#endif
       if (lds > 64 * 1024) { // radiance tiles beyond 45 x 45 texels: up to the whole 160 KiB of a CU (70 x 70)
          if (lds > 160 * 1024) return seterr(MDH_E_INVALID, "radiance resolution too large for the irradiance pass (160 KiB of LDS: at most 70)");
          if (!r->irr_lds_granted) { // (the attribute belongs to the function on THIS device: kept per renderer, not per process)
@@ -1812,7 +1831,7 @@ static int run_pass(mdh_renderer *r, int pass, hipStream_t st, int src, int dst,
          }
       }
       // (hysteresis: the previous frame's irradiance is set `src` -- the same set when the pass runs in place)
-      if (n > 0) hipLaunchKernelGGL(k_irradiance, dim3(n), dim3(MDH_IRR_BLOCK), lds, st, pr, (const void *)r->d_irr2[src], (float)r->opt_hyst / 1000.0f);
+      if (n > 0) hipLaunchKernelGGL(k_irradiance, dim3(n), dim3(MDH_IRR_BLOCK), lds, st, pr, (const void *)r->d_irr2[src], (float)r->opt_hyst / 1000.0f, tap_planes);
       break;
    }
    case MDH_PASS_VISIBILITY: {

@@ -1133,8 +1133,8 @@ template <bool CUSTOM, bool FALLBACK> MDH_DEV float partitioning_closest_bits(co
       const unsigned long long mm = ((GlobalPairs)(sc.part_table + sc.part_mask_off))[cell];
       // a type's candidates: 32 bits of the cell's 64 from bit part_tbit on -- one funnel shift (v_alignbit_b32) while the
       // type starts in the low dword, a plain shift of the high one otherwise (part_tbit is uniform: a scalar branch)
-      const unsigned mlo = (unsigned)mm, mhi = (unsigned)(mm >> 32);
 #if MDH_PART_ALIGNBIT
+      const unsigned mlo = (unsigned)mm, mhi = (unsigned)(mm >> 32);
 #define MDH_TYPE_BITS(T) ((sc.part_tbit[T] < 32u ? __builtin_amdgcn_alignbit(mhi, mlo, sc.part_tbit[T]) : (mhi >> (sc.part_tbit[T] - 32u))) & sc.part_tmask[T])
 #else
 #define MDH_TYPE_BITS(T) ((unsigned)(mm >> sc.part_tbit[T]) & sc.part_tmask[T])

@@ -555,6 +555,18 @@ __global__ __launch_bounds__(256) void k_order_floor(unsigned char *keys, int n,
 // thirteen operations; a lone workgroup takes 30 us whatever its instruction count.  Off.
 #define MDH_IRR_WPRE 0
 #endif
+#ifndef MDH_IRR_CHANNELS
+#define MDH_IRR_CHANNELS 1 // one channel of the fold per wavefront, the weights shared through LDS (k_irradiance)
+#endif
+#ifndef MDH_IRR_PRIO
+#define MDH_IRR_PRIO 3 // s_setprio of that form's wavefronts (0 = none)
+#endif
+#ifndef MDH_IRR_CCHUNK
+#define MDH_IRR_CCHUNK 64 // taps per weight buffer of that form
+#endif
+// LDS of that form: two weight buffers of 64 rows; its scratch in device memory: six planes of the taps (rounded up to whole chunks) per probe
+#define MDH_IRR_CHANNELS_LDS ((size_t)2 * 64 * (MDH_IRR_CCHUNK + 4) * sizeof(float))
+#define MDH_IRR_CHANNELS_PLANE(n) ((size_t)(((n) + MDH_IRR_CCHUNK - 1) / MDH_IRR_CCHUNK * MDH_IRR_CCHUNK))
 #ifndef MDH_IRR_ABL
 #define MDH_IRR_ABL 0 // (timing experiments only: 1 no fold, 2 no tap evaluation, 3 no weights -- wrong results)
 #endif
@@ -572,11 +584,58 @@ MDH_DEV f3 irradiance_blend(const KProbes &pr, const void *prev, float hyst, uns
    const f3 old = atlas_texel(prev, pr.fmt, idx, -1);
    return F3(mix_(fresh.x, old.x, hyst), mix_(fresh.y, old.y, hyst), mix_(fresh.z, old.z, hyst));
 }
-__global__ __launch_bounds__(MDH_IRR_BLOCK) void k_irradiance(KProbes pr, const void *prev, float hyst)
+// k_irradiance's channel form, one whole chunk of 64 taps on one wavefront: this wavefront's sixteen taps of the NEXT chunk's
+// weights (NEXT) and the chunk folded into the wavefront's channel (RAD: the channel has a radiance plane; the weight's own
+// chain adds w).
+//   A tap's radiance and direction are the same for all 64 texels.  Read as LDS broadcasts they cost an LDS instruction and
+//   four LDS cycles per four taps each, and with two probes on a CU the LDS array, not instruction issue, bounded the pass.
+//   Here sixteen taps sit in ONE register, lane l holding tap l mod 16 (one 4-byte read per sixteen taps and plane), and
+//   every multiplication takes its tap from that register through the DPP row broadcast (v_mul_f32_dpp row_newbcast:n -- lane
+//   n of each row of sixteen to the whole row: the operand's route changes, the IEEE operation does not).
+//   The LDS reads run ahead of their use -- a wavefront alone on its SIMD has nothing else to hide their latency behind:
+//   everything the chunk reads is asked for before anything is computed (reads return in order: counted waits).
+template <int N> MDH_DEV float irr_row_bcast(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + N, 0xf, 0xf, true)); }
+template <int K> MDH_DEV float irr_comp(const float4 &v) { return K == 0 ? v.x : K == 1 ? v.y : K == 2 ? v.z : v.w; }
+#define MDH_IRR_X16(X_) X_(0) X_(1) X_(2) X_(3) X_(4) X_(5) X_(6) X_(7) X_(8) X_(9) X_(10) X_(11) X_(12) X_(13) X_(14) X_(15)
+// sixteen taps' weights for this lane's texel (the taps' directions in dxv, dyv, dzv: lane l holds tap l mod 16) into the texel's row
+MDH_DEV void irr_produce16(float dxv, float dyv, float dzv, float *wrow, f3 irr_dir)
+{
+   float wn[16];
+#define MDH_IRR_W1(n_) wn[n_] = max_((irr_dir.x * irr_row_bcast<n_>(dxv) + irr_dir.y * irr_row_bcast<n_>(dyv)) + irr_dir.z * irr_row_bcast<n_>(dzv), 0.0f);
+   MDH_IRR_X16(MDH_IRR_W1)
+#undef MDH_IRR_W1
+#pragma unroll
+   for (int g = 0; g < 4; ++g) *(float4 *)(wrow + 4 * g) = make_float4(wn[4 * g], wn[4 * g + 1], wn[4 * g + 2], wn[4 * g + 3]);
+}
+// 64 taps folded into one channel: their weights w (this lane's texel), their radiance rv (lane l holds taps l mod 16 of each sixteen)
+template <bool RAD> MDH_DEV float irr_fold64(const float (&rv)[4], const float4 (&w)[16], float acc)
+{
+   // (four products, then their four additions: a DPP instruction that follows the one before it at a distance of two reuses
+   //  its destination and waits a slot for it)
+#define MDH_IRR_F4(q_)                                                                                                    \
+   {                                                                                                                     \
+      const float4 wq = w[4 * b + (q_)];                                                                                 \
+      if (RAD) {                                                                                                         \
+         const float p0 = irr_row_bcast<4 * (q_)>(rvb) * wq.x, p1 = irr_row_bcast<4 * (q_) + 1>(rvb) * wq.y, p2 = irr_row_bcast<4 * (q_) + 2>(rvb) * wq.z, p3 = irr_row_bcast<4 * (q_) + 3>(rvb) * wq.w; \
+         acc = acc + p0; acc = acc + p1; acc = acc + p2; acc = acc + p3;                                                 \
+      } else { acc = acc + wq.x; acc = acc + wq.y; acc = acc + wq.z; acc = acc + wq.w; }                                 \
+   }
+#pragma unroll
+   for (int b = 0; b < 4; ++b) {
+      const float rvb = rv[b];
+      MDH_IRR_F4(0) MDH_IRR_F4(1) MDH_IRR_F4(2) MDH_IRR_F4(3)
+   }
+#undef MDH_IRR_F4
+   return acc;
+}
+__global__ __launch_bounds__(MDH_IRR_BLOCK) void k_irradiance(KProbes pr, const void *prev, float hyst, float *tap_planes)
 {
    extern __shared__ float4 s_taps[]; // [2 * rres * rres]: {rad.xyz, 1} {dir.xyz, -}
    const int probe = pr.probe_begin + blockIdx.x;
    if (probe >= pr.probe_end) return;
+#if MDH_IRR_ABL == 9
+   return; // (timing experiments only: what the pass's launch and its two events cost by themselves)
+#endif
    const int ntaps = pr.rres * pr.rres;
    const int ty = probe / pr.pcx, tx = probe - ty * pr.pcx;
    const float pcx = (float)pr.pcx, pcy = (float)pr.pcy;
@@ -619,6 +678,145 @@ __global__ __launch_bounds__(MDH_IRR_BLOCK) void k_irradiance(KProbes pr, const 
          const float4 a = part[lane], b = part[64 + lane], c = part[128 + lane], d = part[192 + lane];
          const f3 sum = F3((a.x + b.x) + (c.x + d.x), (a.y + b.y) + (c.y + d.y), (a.z + b.z) + (c.z + d.z));
          const f3 irradiance = sum / ((a.w + b.w) + (c.w + d.w));
+         const unsigned idx = atlas_index(pr.pcx, pr.ires, pr.ishift, i, j);
+         atlas_store(pr.irr, pr.fmt, idx, irradiance_blend(pr, prev, hyst, idx, irradiance));
+      }
+      return;
+   }
+#endif
+#if MDH_IRR_CHANNELS
+   if (pr.ires * pr.ires <= 64 && MDH_IRR_BLOCK == 256 && tap_planes) { // (the host's test: mdh_api.hip, MDH_PASS_IRRADIANCE)
+      // Round 4 (second session): ONE CHANNEL PER WAVEFRONT.  A wavefront that is alone on its SIMD issues one instruction every
+      // four cycles whatever the instruction (vector, LDS or scalar), so the lone folding wavefront of the forms below pays
+      // ~17 issue slots per tap -- 74 cycles, 30 us for 1 024 taps -- while three wavefronts beside it idle.  The four sums of a
+      // texel (x, y, z, weight) are four independent chains of additions: wavefront k carries channel k of all 64 texels, two
+      // instructions per tap (one for the weight's chain), with a quarter of the taps' weights w = max (dot (irr_dir, rad_dir), 0)
+      // computed by each wavefront one chunk ahead and shared through LDS ([texel][tap]: 16-byte reads and writes, rows 4 * odd
+      // dwords apart).  The same multiplications and additions in the reference's order on every chain; the issue slots of a
+      // probe's fold spread over four SIMDs instead of one.
+#if MDH_IRR_PRIO
+      // all four wavefronts are the pass's critical path and meet at a barrier every 64 taps; beside the march kernels of the
+      // neighbouring frames (five or seven wavefronts per SIMD, all of them older) the youngest wavefront of a SIMD gets the
+      // issue slots the others leave: raised priority for the pass that heads the next frame's dependency chain
+      __builtin_amdgcn_s_setprio(MDH_IRR_PRIO);
+#endif
+      constexpr int CH = MDH_IRR_CCHUNK, S = CH + 4, CHQ = CH / 4;
+      static_assert(CH == 64 && ((S / 4) & 1) == 1, "a wavefront's quarter of a chunk is one register of sixteen taps; weight rows 16-byte aligned, an odd number of quads apart");
+      const int ntp = (ntaps + CH - 1) / CH * CH, nchunks = ntp / CH;
+      // The taps themselves (radiance and direction: the same for all 64 texels) go through a scratch buffer in device memory,
+      // six planes of ntp floats per probe of the pass -- written by this workgroup, read back by it behind a barrier, sixteen
+      // taps to a register, a chunk ahead of their use: the LDS holds the weights only (34 KiB; with the taps beside them the
+      // pass needed 59 KiB and, with frames in flight, waited for a CU that had them free: -8 % frame rate, measured).
+      float *g_dpl = tap_planes + (size_t)blockIdx.x * 6 * ntp; // [3][ntp] the taps' directions, a plane per component
+      float *g_rch = g_dpl + 3 * ntp;                            // [3][ntp] their radiance, a plane per channel
+      float *s_w = (float *)s_taps;                              // [2][64][S] weights of two chunks, a row per texel
+      const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, l16 = lane & 15;
+      const int ntex = pr.ires * pr.ires;
+      const int x = lane % pr.ires, y = lane / pr.ires;
+      const int i = tx * pr.ires + x, j = ty * pr.ires + y;
+      const f2 nc = F2((centre(i, pr.pcx * pr.ires) + 1.0f) * 0.5f, (centre(j, pr.pcy * pr.ires) + 1.0f) * 0.5f);
+      const f3 irr_dir = ray_id_to_ray_dir(F2(fract_(nc.x * pcx), fract_(nc.y * pcy)));
+#ifdef MDH_PHASES
+      const unsigned long long ph_k0 = __builtin_amdgcn_s_memtime();
+#endif
+      // a thread's taps four at a time: the texels of all four asked for before the first direction is decoded (one round trip
+      // to the atlas instead of four)
+      for (int t0 = threadIdx.x; t0 < ntaps; t0 += 4 * MDH_IRR_BLOCK) {
+         AtlasTap tap[4];
+         f2 cc[4];
+#pragma unroll
+         for (int k = 0; k < 4; ++k) {
+            const int t = min(t0 + k * MDH_IRR_BLOCK, ntaps - 1); // (a tap beyond the last: the last one again, not stored)
+            const int yy = t / pr.rres, xx = t - yy * pr.rres;
+            cc[k] = F2(clamp_(rad_coord.x + (float)xx * step.x, step.x, 1.0f - step.x), clamp_(rad_coord.y + (float)yy * step.y, step.y, 1.0f - step.y));
+            tap[k] = atlas_tap_issue(pr.rad, pr.fmt, pr.pcx, pr.pcy, pr.rres, pr.rshift, pr.rad_w, pr.rad_h, cc[k].x, cc[k].y);
+         }
+#pragma unroll
+         for (int k = 0; k < 4; ++k) {
+            const int t = t0 + k * MDH_IRR_BLOCK;
+            const f3 rad_dir = ray_id_to_ray_dir(F2(fract_(cc[k].x * pcx), fract_(cc[k].y * pcy)));
+            const f3 rad = atlas_tap_resolve(pr.rad, pr.fmt, tap[k], -1);
+            if (t < ntaps) {
+               g_dpl[t] = rad_dir.x; g_dpl[ntp + t] = rad_dir.y; g_dpl[2 * ntp + t] = rad_dir.z;
+               g_rch[t] = rad.x; g_rch[ntp + t] = rad.y; g_rch[2 * ntp + t] = rad.z;
+            }
+         }
+      }
+      __syncthreads(); // (the workgroup's stores are in L2 behind it; none of these lines was read before: nothing stale in this CU's L1)
+#ifdef MDH_PHASES
+      const unsigned long long ph_k1 = __builtin_amdgcn_s_memtime();
+      unsigned long long ph_work = 0ull, ph_wait = 0ull;
+      if (lane == 0) atomicAdd(&g_phase[8 + wv], ph_k1 - ph_k0); // (staging, its barrier included)
+#endif
+      float acc = 0.0f;
+      const float *g_rc = g_rch + (wv < 3 ? wv : 0) * ntp; // this wavefront's channel
+      if (ntaps % CH == 0) {
+         // chunk c: this wavefront's sixteen taps of chunk c + 1's weights, then the chunk folded; the registers of taps for the
+         // next turn (directions of chunk c + 2's sixteen, radiance of chunk c + 1) asked for at the top of this one
+         const float *g_d = g_dpl + wv * CHQ + l16;
+         float dx = g_d[0], dy = g_d[ntp], dz = g_d[2 * ntp], rv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+         irr_produce16(dx, dy, dz, s_w + lane * S + wv * CHQ, irr_dir);
+         if (nchunks > 1) { dx = g_d[CH]; dy = g_d[ntp + CH]; dz = g_d[2 * ntp + CH]; }
+         if (wv < 3) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) rv[b] = g_rc[16 * b + l16];
+         }
+         // (vmcnt (0): with loads pending on entry the compiler's wait-count pass makes every turn of the loop wait for the loads
+         //  that turn has just issued)
+         __builtin_amdgcn_s_waitcnt(0x0f70);
+         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll 1
+         for (int c = 0; c < nchunks; ++c) {
+#ifdef MDH_PHASES
+            const unsigned long long ph_t0 = __builtin_amdgcn_s_memtime();
+#endif
+            float dxn = 0.0f, dyn = 0.0f, dzn = 0.0f, rvn[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (c + 2 < nchunks) { dxn = g_d[(c + 2) * CH]; dyn = g_d[ntp + (c + 2) * CH]; dzn = g_d[2 * ntp + (c + 2) * CH]; }
+            if (c + 1 < nchunks && wv < 3) {
+#pragma unroll
+               for (int b = 0; b < 4; ++b) rvn[b] = g_rc[(c + 1) * CH + 16 * b + l16];
+            }
+            const float *wr = s_w + (c & 1) * 64 * S + lane * S;
+            float4 w[16];
+#pragma unroll
+            for (int g = 0; g < 16; ++g) w[g] = *(const float4 *)(wr + 4 * g);
+            if (c + 1 < nchunks) irr_produce16(dx, dy, dz, s_w + ((c + 1) & 1) * 64 * S + lane * S + wv * CHQ, irr_dir);
+            acc = wv < 3 ? irr_fold64<true>(rv, w, acc) : irr_fold64<false>(rv, w, acc);
+#ifdef MDH_PHASES
+            const unsigned long long ph_t1 = __builtin_amdgcn_s_memtime();
+#endif
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#ifdef MDH_PHASES
+            ph_work += ph_t1 - ph_t0; ph_wait += __builtin_amdgcn_s_memtime() - ph_t1;
+#endif
+            dx = dxn; dy = dyn; dz = dzn;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) rv[b] = rvn[b];
+         }
+      } else {
+         // radiance tiles whose texels are no multiple of 64 (not the reference's: 32 x 32): the same four chains tap by tap
+         for (int c = 0; c <= nchunks; ++c) { // (turn c: the weights of chunk c, the fold of chunk c - 1)
+            if (c < nchunks) {
+               const int t0 = c * CH + wv * CHQ, t1 = min(t0 + CHQ, ntaps);
+               float *wb = s_w + (c & 1) * 64 * S + lane * S - c * CH;
+               for (int t = t0; t < t1; ++t) wb[t] = max_((irr_dir.x * g_dpl[t] + irr_dir.y * g_dpl[ntp + t]) + irr_dir.z * g_dpl[2 * ntp + t], 0.0f);
+            }
+            if (c > 0) {
+               const int nh = min(CH, ntaps - (c - 1) * CH);
+               const float *wr = s_w + ((c - 1) & 1) * 64 * S + lane * S, *rc = g_rc + (c - 1) * CH;
+               for (int t = 0; t < nh; ++t) acc = wv < 3 ? acc + rc[t] * wr[t] : acc + wr[t];
+            }
+            __syncthreads();
+         }
+      }
+#ifdef MDH_PHASES
+      if (lane == 0) { atomicAdd(&g_phase[2 * wv], ph_work); atomicAdd(&g_phase[2 * wv + 1], ph_wait); }
+#endif
+      // the four sums of a texel back to one lane (through the weight rows: the loop's last barrier is behind every read of them)
+      if (wv > 0) s_w[(wv - 1) * 64 + lane] = acc;
+      __syncthreads();
+      if (wv == 0 && lane < ntex) {
+         const f3 irradiance = F3(acc, s_w[lane], s_w[64 + lane]) / s_w[128 + lane];
          const unsigned idx = atlas_index(pr.pcx, pr.ires, pr.ishift, i, j);
          atlas_store(pr.irr, pr.fmt, idx, irradiance_blend(pr, prev, hyst, idx, irradiance));
       }

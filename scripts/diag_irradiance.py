@@ -11,5 +11,5 @@ buf = (C.c_ulonglong * 16)()
 for _ in range(3): R.Render()
 R.Finish(); hb.lib.mdh_diag_phases(buf)
 R.Render_Pass(B.PASS_IRRADIANCE); R.Finish(); hb.lib.mdh_diag_phases(buf)
-for w, name in enumerate(("fold", "tap evaluation", "weights (a)", "weights (b)")):
-    print("wavefront %d %-16s work %8.0f cycles per probe, barrier wait %8.0f" % (w, name, buf[2 * w] / 512, buf[2 * w + 1] / 512))
+for w in range(4):
+    print("wavefront %d: loop work %8.0f cycles per probe, barrier wait %8.0f, staging before the loop %8.0f" % (w, buf[2 * w] / 512, buf[2 * w + 1] / 512, buf[8 + w] / 512))
