@@ -562,11 +562,11 @@ __global__ __launch_bounds__(256) void k_order_floor(unsigned char *keys, int n,
 #define MDH_IRR_PRIO 3 // s_setprio of that form's wavefronts (0 = none)
 #endif
 #ifndef MDH_IRR_CCHUNK
-#define MDH_IRR_CCHUNK 64 // taps per weight buffer of that form
+#define MDH_IRR_CCHUNK 32 // taps per weight buffer of that form (32: 18 KiB of LDS, 64: 34 KiB -- the same speed alone, 32 starts sooner beside the march kernels of frames in flight)
 #endif
 // LDS of that form: two weight buffers of 64 rows; its scratch in device memory: six planes of the taps (rounded up to whole chunks) per probe
 #define MDH_IRR_CHANNELS_LDS ((size_t)2 * 64 * (MDH_IRR_CCHUNK + 4) * sizeof(float))
-#define MDH_IRR_CHANNELS_PLANE(n) ((size_t)(((n) + MDH_IRR_CCHUNK - 1) / MDH_IRR_CCHUNK * MDH_IRR_CCHUNK))
+#define MDH_IRR_CHANNELS_PLANE(n) ((size_t)(((n) + 63) / 64 * 64))
 #ifndef MDH_IRR_ABL
 #define MDH_IRR_ABL 0 // (timing experiments only: 1 no fold, 2 no tap evaluation, 3 no weights -- wrong results)
 #endif
@@ -597,18 +597,19 @@ MDH_DEV f3 irradiance_blend(const KProbes &pr, const void *prev, float hyst, uns
 template <int N> MDH_DEV float irr_row_bcast(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + N, 0xf, 0xf, true)); }
 template <int K> MDH_DEV float irr_comp(const float4 &v) { return K == 0 ? v.x : K == 1 ? v.y : K == 2 ? v.z : v.w; }
 #define MDH_IRR_X16(X_) X_(0) X_(1) X_(2) X_(3) X_(4) X_(5) X_(6) X_(7) X_(8) X_(9) X_(10) X_(11) X_(12) X_(13) X_(14) X_(15)
-// sixteen taps' weights for this lane's texel (the taps' directions in dxv, dyv, dzv: lane l holds tap l mod 16) into the texel's row
-MDH_DEV void irr_produce16(float dxv, float dyv, float dzv, float *wrow, f3 irr_dir)
+// PT taps' weights for this lane's texel into the texel's row: the taps' directions in dxv, dyv, dzv (lane l holds tap l mod 16 of
+// the register's sixteen), taps OFF .. OFF + PT - 1 of them
+template <int OFF, int PT> MDH_DEV void irr_produce(float dxv, float dyv, float dzv, float *wrow, f3 irr_dir)
 {
    float wn[16];
-#define MDH_IRR_W1(n_) wn[n_] = max_((irr_dir.x * irr_row_bcast<n_>(dxv) + irr_dir.y * irr_row_bcast<n_>(dyv)) + irr_dir.z * irr_row_bcast<n_>(dzv), 0.0f);
+#define MDH_IRR_W1(n_) if ((n_) < PT) wn[n_] = max_((irr_dir.x * irr_row_bcast<(OFF + (n_)) & 15>(dxv) + irr_dir.y * irr_row_bcast<(OFF + (n_)) & 15>(dyv)) + irr_dir.z * irr_row_bcast<(OFF + (n_)) & 15>(dzv), 0.0f);
    MDH_IRR_X16(MDH_IRR_W1)
 #undef MDH_IRR_W1
 #pragma unroll
-   for (int g = 0; g < 4; ++g) *(float4 *)(wrow + 4 * g) = make_float4(wn[4 * g], wn[4 * g + 1], wn[4 * g + 2], wn[4 * g + 3]);
+   for (int g = 0; g < PT / 4; ++g) *(float4 *)(wrow + 4 * g) = make_float4(wn[4 * g], wn[4 * g + 1], wn[4 * g + 2], wn[4 * g + 3]);
 }
-// 64 taps folded into one channel: their weights w (this lane's texel), their radiance rv (lane l holds taps l mod 16 of each sixteen)
-template <bool RAD> MDH_DEV float irr_fold64(const float (&rv)[4], const float4 (&w)[16], float acc)
+// 16 * NB taps folded into one channel: their weights w (this lane's texel), their radiance rv (lane l holds tap l mod 16 of each sixteen)
+template <bool RAD, int NB> MDH_DEV float irr_fold(const float *rv, const float4 *w, float acc)
 {
    // (four products, then their four additions: a DPP instruction that follows the one before it at a distance of two reuses
    //  its destination and waits a slot for it)
@@ -621,7 +622,7 @@ template <bool RAD> MDH_DEV float irr_fold64(const float (&rv)[4], const float4 
       } else { acc = acc + wq.x; acc = acc + wq.y; acc = acc + wq.z; acc = acc + wq.w; }                                 \
    }
 #pragma unroll
-   for (int b = 0; b < 4; ++b) {
+   for (int b = 0; b < NB; ++b) {
       const float rvb = rv[b];
       MDH_IRR_F4(0) MDH_IRR_F4(1) MDH_IRR_F4(2) MDH_IRR_F4(3)
    }
@@ -701,8 +702,8 @@ __global__ __launch_bounds__(MDH_IRR_BLOCK) void k_irradiance(KProbes pr, const 
       __builtin_amdgcn_s_setprio(MDH_IRR_PRIO);
 #endif
       constexpr int CH = MDH_IRR_CCHUNK, S = CH + 4, CHQ = CH / 4;
-      static_assert(CH == 64 && ((S / 4) & 1) == 1, "a wavefront's quarter of a chunk is one register of sixteen taps; weight rows 16-byte aligned, an odd number of quads apart");
-      const int ntp = (ntaps + CH - 1) / CH * CH, nchunks = ntp / CH;
+      static_assert((CH == 64 || CH == 32) && ((S / 4) & 1) == 1, "a wavefront's quarter of a chunk is a register of sixteen taps or half of one; weight rows 16-byte aligned, an odd number of quads apart");
+      const int ntp = (ntaps + 63) / 64 * 64, nchunks = (ntaps + CH - 1) / CH;
       // The taps themselves (radiance and direction: the same for all 64 texels) go through a scratch buffer in device memory,
       // six planes of ntp floats per probe of the pass -- written by this workgroup, read back by it behind a barrier, sixteen
       // taps to a register, a chunk ahead of their use: the LDS holds the weights only (34 KiB; with the taps beside them the
@@ -750,13 +751,19 @@ __global__ __launch_bounds__(MDH_IRR_BLOCK) void k_irradiance(KProbes pr, const 
 #endif
       float acc = 0.0f;
       const float *g_rc = g_rch + (wv < 3 ? wv : 0) * ntp; // this wavefront's channel
-      if (ntaps % CH == 0) {
-         // chunk c: this wavefront's sixteen taps of chunk c + 1's weights, then the chunk folded; the registers of taps for the
-         // next turn (directions of chunk c + 2's sixteen, radiance of chunk c + 1) asked for at the top of this one
-         const float *g_d = g_dpl + wv * CHQ + l16;
-         float dx = g_d[0], dy = g_d[ntp], dz = g_d[2 * ntp], rv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-         irr_produce16(dx, dy, dz, s_w + lane * S + wv * CHQ, irr_dir);
-         if (nchunks > 1) { dx = g_d[CH]; dy = g_d[ntp + CH]; dz = g_d[2 * ntp + CH]; }
+      if (ntaps % 64 == 0) {
+         // Turns of 64 taps in 64 / CH chunks.  Chunk c: the weights' rows of the chunk asked for, this wavefront's quarter of
+         // chunk c + 1's weights computed and stored, the chunk folded, barrier.  The registers of taps of the NEXT turn (radiance
+         // of its 64 taps; directions of the sixteen taps whose weights this wavefront computes during it) are asked for at the
+         // top of this one.  A direction register of turn s holds, for chunk 2 s + 1 + h (CH = 32; chunk s + 1 for CH = 64),
+         // the wavefront's taps in lanes 8 h .. 8 h + 7.
+         constexpr int HALVES = 64 / CH, PT = CH / 4, NB = CH / 16, NW = CH / 4;
+         const int h16 = HALVES == 2 ? l16 >> 3 : 0, n16 = HALVES == 2 ? l16 & 7 : l16;
+         auto dir_tap = [&](int turn) { return min(((turn * HALVES + 1 + h16) * CH + wv * PT + n16), ntp - 1); }; // (beyond the last chunk: never used)
+         float dx, dy, dz, rv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+         { const int t = wv * PT + n16; dx = g_dpl[t]; dy = g_dpl[ntp + t]; dz = g_dpl[2 * ntp + t]; }
+         irr_produce<0, PT>(dx, dy, dz, s_w + lane * S + wv * PT, irr_dir);
+         { const int t = dir_tap(0); dx = g_dpl[t]; dy = g_dpl[ntp + t]; dz = g_dpl[2 * ntp + t]; }
          if (wv < 3) {
 #pragma unroll
             for (int b = 0; b < 4; ++b) rv[b] = g_rc[16 * b + l16];
@@ -765,29 +772,45 @@ __global__ __launch_bounds__(MDH_IRR_BLOCK) void k_irradiance(KProbes pr, const 
          //  that turn has just issued)
          __builtin_amdgcn_s_waitcnt(0x0f70);
          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+         const int nturns = ntaps / 64;
 #pragma unroll 1
-         for (int c = 0; c < nchunks; ++c) {
+         for (int turn = 0; turn < nturns; ++turn) {
 #ifdef MDH_PHASES
             const unsigned long long ph_t0 = __builtin_amdgcn_s_memtime();
+            unsigned long long ph_b = 0ull;
 #endif
             float dxn = 0.0f, dyn = 0.0f, dzn = 0.0f, rvn[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-            if (c + 2 < nchunks) { dxn = g_d[(c + 2) * CH]; dyn = g_d[ntp + (c + 2) * CH]; dzn = g_d[2 * ntp + (c + 2) * CH]; }
-            if (c + 1 < nchunks && wv < 3) {
+            if (turn + 1 < nturns) {
+               const int t = dir_tap(turn + 1);
+               dxn = g_dpl[t]; dyn = g_dpl[ntp + t]; dzn = g_dpl[2 * ntp + t];
+               if (wv < 3) {
 #pragma unroll
-               for (int b = 0; b < 4; ++b) rvn[b] = g_rc[(c + 1) * CH + 16 * b + l16];
+                  for (int b = 0; b < 4; ++b) rvn[b] = g_rc[(turn + 1) * 64 + 16 * b + l16];
+               }
             }
-            const float *wr = s_w + (c & 1) * 64 * S + lane * S;
-            float4 w[16];
 #pragma unroll
-            for (int g = 0; g < 16; ++g) w[g] = *(const float4 *)(wr + 4 * g);
-            if (c + 1 < nchunks) irr_produce16(dx, dy, dz, s_w + ((c + 1) & 1) * 64 * S + lane * S + wv * CHQ, irr_dir);
-            acc = wv < 3 ? irr_fold64<true>(rv, w, acc) : irr_fold64<false>(rv, w, acc);
+            for (int hf = 0; hf < HALVES; ++hf) {
+               const int c = turn * HALVES + hf;
+               const float *wr = s_w + (c & 1) * 64 * S + lane * S;
+               float4 w[NW];
+#pragma unroll
+               for (int g = 0; g < NW; ++g) w[g] = *(const float4 *)(wr + 4 * g);
+               if (c + 1 < nchunks) {
+                  float *wn = s_w + ((c + 1) & 1) * 64 * S + lane * S + wv * PT;
+                  if (hf == 0) irr_produce<0, PT>(dx, dy, dz, wn, irr_dir);
+                  else irr_produce<8, PT>(dx, dy, dz, wn, irr_dir);
+               }
+               acc = wv < 3 ? irr_fold<true, NB>(rv + hf * NB, w, acc) : irr_fold<false, NB>(rv + hf * NB, w, acc);
 #ifdef MDH_PHASES
-            const unsigned long long ph_t1 = __builtin_amdgcn_s_memtime();
+               const unsigned long long ph_t1 = __builtin_amdgcn_s_memtime();
 #endif
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+               asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #ifdef MDH_PHASES
-            ph_work += ph_t1 - ph_t0; ph_wait += __builtin_amdgcn_s_memtime() - ph_t1;
+               ph_b += __builtin_amdgcn_s_memtime() - ph_t1;
+#endif
+            }
+#ifdef MDH_PHASES
+            ph_wait += ph_b; ph_work += __builtin_amdgcn_s_memtime() - ph_t0 - ph_b;
 #endif
             dx = dxn; dy = dyn; dz = dzn;
 #pragma unroll
@@ -1115,10 +1138,24 @@ __global__ __launch_bounds__(MDH_IRR_BLOCK) void k_irradiance(KProbes pr, const 
 #ifndef MDH_VIS_REFILL
 #define MDH_VIS_REFILL 16
 #endif
-// the froxel texel (i, j) at place `lin` of the launch: 8x8 tiles when the sizes allow it, so a wave's rays are neighbours on the image plane
-MDH_DEV void froxel_texel(int W, int H, long lin, int &i, int &j)
+// the froxel texel (i, j) at place `lin` of the launch.  Which froxels share a wavefront decides how many of its lanes march
+// together: the texture is vw x (vh * vz) texels, row j = slice * vh + y, and in launch order a wavefront of the reference's
+// 100^3 froxels was a strip of 64 froxels along x (100 is no multiple of 8: no 8x8 tiles either).  MDH_VIS_BLOCK3: blocks of
+// 4 x 4 froxels x 4 depth slices -- neighbours in space, whose rays to a light pass the same geometry.
+#ifndef MDH_VIS_BLOCK3
+#define MDH_VIS_BLOCK3 1
+#endif
+MDH_DEV void froxel_texel(const KVolumetrics &vol, int W, int H, long lin, int &i, int &j)
 {
-   if ((W & 7) == 0 && (H & 7) == 0) {
+   if (MDH_VIS_BLOCK3 && ((vol.vw | vol.vh | vol.vz) & 3) == 0) {
+      const long blk = lin >> 6;
+      const int l = (int)(lin & 63), bxn = vol.vw >> 2, byn = vol.vh >> 2;
+      const int bx = (int)(blk % bxn);
+      const long rest = blk / bxn;
+      const int by = (int)(rest % byn), bz = (int)(rest / byn);
+      i = bx * 4 + (l & 3);
+      j = (bz * 4 + (l >> 4)) * vol.vh + by * 4 + ((l >> 2) & 3);
+   } else if ((W & 7) == 0 && (H & 7) == 0) {
       const long tile = lin >> 6;
       const int l = (int)(lin & 63), tpr = W >> 3;
       i = (int)(tile % tpr) * 8 + (l & 7);
@@ -1195,7 +1232,7 @@ template <int PART> __global__ __launch_bounds__(MDH_BLOCK) void k_visibility(KS
          for (int r = 0; r < R; ++r) { // set-up, dense
             const long lin = begin + r * 64 + lane;
             int i, j;
-            froxel_texel(W, H, lin < n ? lin : n - 1, i, j);
+            froxel_texel(vol, W, H, lin < n ? lin : n - 1, i, j);
             f3 pos;
             froxel_point(vol, cam, W, H, i, j, pos, dirs[r]);
             rads[r] = sample_light<(PART & MDH_PF_CUSTOM) != 0>(sc, l, pos, F3(1.0f, 0.0f, 0.0f), Ls[r], Ld[r]); // compute_frustrum_visibility.glsl:12
@@ -1261,7 +1298,7 @@ template <int PART> __global__ __launch_bounds__(MDH_BLOCK) void k_visibility(KS
          const long lin = begin + r * 64 + lane;
          if (lin < n) {
             int i, j;
-            froxel_texel(W, H, lin, i, j);
+            froxel_texel(vol, W, H, lin, i, j);
             float *o = vol.vis + ((size_t)j * W + i) * 3;
             o[0] = result[r].x; o[1] = result[r].y; o[2] = result[r].z;
          }
@@ -1293,7 +1330,7 @@ template <int PART> __global__ __launch_bounds__(MDH_BLOCK) void k_visibility(KS
             }
             if (lin >= 0 && light >= sc.total_lights) {
                int i, j;
-               froxel_texel(W, H, lin, i, j);
+               froxel_texel(vol, W, H, lin, i, j);
                float *o = vol.vis + ((size_t)j * W + i) * 3;
                o[0] = result.x; o[1] = result.y; o[2] = result.z;
                lin = -1;
@@ -1307,7 +1344,7 @@ template <int PART> __global__ __launch_bounds__(MDH_BLOCK) void k_visibility(KS
                if (mine < end) {
                   lin = mine;
                   int i, j;
-                  froxel_texel(W, H, lin, i, j);
+                  froxel_texel(vol, W, H, lin, i, j);
                   froxel_point(vol, cam, W, H, i, j, pos, dir);
                   result = F3(0.0f, 0.0f, 0.0f);
                   light = 0;
@@ -1342,7 +1379,7 @@ template <int PART> __global__ __launch_bounds__(MDH_BLOCK) void k_visibility(KS
    const long lin = (long)blockIdx.x * MDH_BLOCK + threadIdx.x;
    if (lin >= n) return;
    int i, j;
-   froxel_texel(W, H, lin, i, j);
+   froxel_texel(vol, W, H, lin, i, j);
    f3 pos, dir;
    froxel_point(vol, cam, W, H, i, j, pos, dir);
    f3 result = F3(0.0f, 0.0f, 0.0f);
