@@ -256,7 +256,14 @@ enum {
       ((a + b) + (c + d)) / 4 per channel in fp32, stored in the atlas's format) and the two taps read
       them as GL_LINEAR_MIPMAP_LINEAR would.  Needs a power-of-two radiance resolution
       (MDH_E_INVALID otherwise).  Levels can be read back: mdh_read_texture (MDH_TEX_RADIANCE_MIP0 + l). */
-   MDH_OPT_RADIANCE_MIPS = 17
+   MDH_OPT_RADIANCE_MIPS = 17,
+   /* Scheduling only, no effect on any pixel: a screen launch whose tiles, as two or four wavefronts each (8x4 or 4x4
+    * pixels: 32 or 16 of a wavefront's 64 lanes), stay within `value` wavefronts is launched that way -- a launch that
+    * leaves the chip's wavefront slots empty (a rank's tiles of a sharded frame, a small window) lasts as long as its slowest
+    * wavefront, which then marches for a quarter of the tile only, and the tile's work runs on four SIMDs.  Default 2560
+    * (half the slots of an MI355X at five wavefronts per SIMD); 0 = every tile one wavefront.  Launches of 2 048 tiles and
+    * more (MDH_OPT_SCREEN_ORDER's) are never split. */
+   MDH_OPT_SCREEN_SPLIT = 18
 };
 
 /* passes of Renderers.Render (madarch-renderers.adb:302-321) */

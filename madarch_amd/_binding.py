@@ -21,7 +21,7 @@ MDH_VEC3, MDH_FLOAT, MDH_INT = 0, 1, 2
 
 OPT_ATLAS_FORMAT, OPT_SCREEN_MODE, OPT_AO_STEPS, OPT_GBUFFER = 0, 1, 2, 3
 OPT_RANK, OPT_WORLD, OPT_TIMING, OPT_ADA_EVAL_DIV, OPT_FRAME_OVERLAP, OPT_JIT, OPT_IRRADIANCE_ALL, OPT_WINDOW = 4, 5, 6, 7, 8, 9, 10, 11
-OPT_INDIRECT_SPECULAR, OPT_HYSTERESIS_PERMILLE, OPT_RADIANCE_ORDER, OPT_SCREEN_ORDER, OPT_NUMERICS, OPT_RADIANCE_MIPS = 12, 13, 14, 15, 16, 17
+OPT_INDIRECT_SPECULAR, OPT_HYSTERESIS_PERMILLE, OPT_RADIANCE_ORDER, OPT_SCREEN_ORDER, OPT_NUMERICS, OPT_RADIANCE_MIPS, OPT_SCREEN_SPLIT = 12, 13, 14, 15, 16, 17, 18
 
 PASS_RADIANCE, PASS_IRRADIANCE, PASS_VISIBILITY, PASS_SCATTERING, PASS_SCREEN, PASS_EXCHANGE = range(6)
 PASS_NAMES = ("radiance", "irradiance", "visibility", "scattering", "screen", "exchange")

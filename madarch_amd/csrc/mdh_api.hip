@@ -269,6 +269,7 @@ struct mdh_renderer {
    hipEvent_t ev_scr_sort = nullptr, ev_scr_other = nullptr;
    unsigned long long scr_sort_version = 0, scr_sort_seen[NSTREAMS] = {0, 0, 0, 0, 0};
    int opt_scr_order = 1;
+   int opt_scr_split = MDH_SCREEN_SPLIT_DEFAULT; // MDH_OPT_SCREEN_SPLIT: the wavefronts a split screen launch may have (0: never split)
    std::map<std::pair<const void *, size_t>, int> resident; // workgroups per CU of (kernel, LDS bytes): rad_first_round
    int last = 0;
    int opt_overlap = 2;
@@ -1041,6 +1042,7 @@ extern "C" int32_t mdh_set_option(mdh_renderer *r, int32_t option, int32_t value
    case MDH_OPT_HYSTERESIS_PERMILLE: if (value < 0 || value > 999) return seterr(MDH_E_INVALID, "hysteresis is 0 .. 999 per mille"); r->opt_hyst = value; break;
    case MDH_OPT_RADIANCE_ORDER: r->opt_rad_order = value ? 1 : 0; r->rad_order_rays = 0; break;
    case MDH_OPT_SCREEN_ORDER: r->opt_scr_order = value ? 1 : 0; r->scr_order_cur = -1; break;
+   case MDH_OPT_SCREEN_SPLIT: if (value < 0) return seterr(MDH_E_INVALID, "MDH_OPT_SCREEN_SPLIT: a number of wavefronts"); r->opt_scr_split = value; break;
    case MDH_OPT_NUMERICS: if (value != (MDH_FAST_NUMERICS ? 1 : (MDH_HYBRID_NUMERICS ? 2 : 0))) return seterr(MDH_E_STATE, "the numerics are a property of the library build (make fast builds the experiment)"); break;
    case MDH_OPT_RADIANCE_MIPS: {
       const int res = r->probes.radiance_resolution;
@@ -1078,6 +1080,7 @@ extern "C" int32_t mdh_get_option(mdh_renderer *r, int32_t option, int32_t *valu
    case MDH_OPT_HYSTERESIS_PERMILLE: *value = r->opt_hyst; break;
    case MDH_OPT_RADIANCE_ORDER: *value = r->opt_rad_order; break;
    case MDH_OPT_SCREEN_ORDER: *value = r->opt_scr_order; break;
+   case MDH_OPT_SCREEN_SPLIT: *value = r->opt_scr_split; break;
    case MDH_OPT_NUMERICS: *value = MDH_FAST_NUMERICS ? 1 : (MDH_HYBRID_NUMERICS ? 2 : 0); break; // 0 exact (shipped), 1 / 2 the labelled experiments
    case MDH_OPT_RADIANCE_MIPS: *value = r->opt_mips; break;
    default: return seterr(MDH_E_INVALID, "unknown option");
@@ -1942,8 +1945,16 @@ static int run_pass(mdh_renderer *r, int pass, hipStream_t st, int src, int dst,
          }
       } else
          r->scr_order_cur = -1;
+      // MDH_OPT_SCREEN_SPLIT (ScreenArgs::split): launches that leave most of the chip's wavefront slots empty give a tile to
+      // two or four wavefronts; never with a tile order (launches of 2 048 tiles and more)
+      a.split = 0;
+      if (!a.order && !a.cost && r->opt_scr_split > 0) {
+         if ((long)own_tiles * 4 <= r->opt_scr_split) a.split = 2;
+         else if ((long)own_tiles * 2 <= r->opt_scr_split) a.split = 1;
+      }
       if (own_tiles > 0) {
-         int blocks = (own_tiles + (MDH_BLOCK / 64) - 1) / (MDH_BLOCK / 64);
+         const long waves = (long)own_tiles << a.split;
+         int blocks = (int)((waves + (MDH_BLOCK / 64) - 1) / (MDH_BLOCK / 64));
          if (jit) {
             struct { KScene sc; KProbes pr; KVolumetrics vol; KCamera cam; ScreenArgs a; } args = {r->ks, pr, vol, cam, a};
             int rc = jit_launch(jm->fn[kname], blocks, MDH_BLOCK, lds_bytes_screen(r), st, args);

@@ -101,7 +101,16 @@ struct ScreenArgs {
    int n_own;             // tiles this launch draws: own index 0 .. n_own - 1, tile = rank + own * world
    const unsigned *order; // [n_own] the own index at every place of the launch, or null: image order
    unsigned char *cost;   // [n_own] written by the pass when not null: the tile's wavefront duration as a sort key
+   // A launch too small to fill the chip (a rank's share of a sharded frame, a small window) is the latency of its slowest
+   // wavefront, and a wavefront alone on its SIMD issues one instruction every four cycles whatever its lanes do: `split` = 1, 2
+   // gives a tile to two wavefronts of 8x4 pixels or four of 4x4 (32 / 16 lanes each, the others idle from the start) -- every
+   // wavefront marches only as long as ITS pixels need and the tile's work runs on several SIMDs.  A pixel's operations do not
+   // depend on which lanes march beside it: the same bits (tests/test_gpu_parity.py::test_split_tiles_change_no_pixel).
+   int split;
 };
+#ifndef MDH_SCREEN_SPLIT_DEFAULT
+#define MDH_SCREEN_SPLIT_DEFAULT 2560 // MDH_OPT_SCREEN_SPLIT's initial value
+#endif
 // a wavefront's duration in ticks of s_memtime (which need not be the shader clock) as a key of the counting sort (k_rad_hist ...)
 #ifndef MDH_TILE_COST_SHIFT
 #define MDH_TILE_COST_SHIFT 12
@@ -116,10 +125,20 @@ MDH_DEV unsigned char tile_cost_key(unsigned cycles) { return (unsigned char)min
 // argument segment read through a pointer the compiler cannot trace back and from a lane index taken from the hardware
 // (tile_pixel).  Kept live they cost ~10 VGPRs and ~20 SGPRs which the compiler spilled to scratch (80 bytes per
 // lane written and read back through HBM: 172 MB per launch at 1080p against a 33 MB framebuffer).
-MDH_DEV void tile_pixel(const ScreenArgs &a, int tile, int lane, int &i, int &j, float &u, float &v)
+MDH_DEV void tile_pixel(const ScreenArgs &a, int tile, int sub, int lane, int &i, int &j, float &u, float &v)
 {
-   i = (tile % a.tiles_x) * 8 + (lane & 7);
-   j = (tile / a.tiles_x) * 8 + (lane >> 3);
+   if (a.split == 0) { // (wave-uniform)
+      i = (tile % a.tiles_x) * 8 + (lane & 7);
+      j = (tile / a.tiles_x) * 8 + (lane >> 3);
+   } else if (a.split == 1) { // the tile's upper or lower 8x4 pixels
+      i = (tile % a.tiles_x) * 8 + (lane & 7);
+      j = (tile / a.tiles_x) * 8 + sub * 4 + ((lane >> 3) & 3);
+      if (lane >= 32) i = a.W; // (no pixel: not valid)
+   } else { // one of its four 4x4 quadrants
+      i = (tile % a.tiles_x) * 8 + (sub & 1) * 4 + (lane & 3);
+      j = (tile / a.tiles_x) * 8 + (sub >> 1) * 4 + ((lane >> 2) & 3);
+      if (lane >= 16) i = a.W;
+   }
    u = centre(i, a.W);
    v = -centre(j, a.H); // row 0 = top
 }
@@ -130,9 +149,9 @@ __global__ __launch_bounds__(MDH_BLOCK, MDH_OCC(PART, MODE)) void k_screen(KScen
    stage_table(sc);
    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
    const int place = blockIdx.x * (MDH_BLOCK / 64) + wave;
-   if (place >= a.n_own) return; // wave-uniform
+   if ((place >> a.split) >= a.n_own) return; // wave-uniform
    const unsigned t_begin = (unsigned)__builtin_amdgcn_s_memtime();
-   const int own = a.order ? (int)a.order[place] : place;
+   const int own = a.order ? (int)a.order[place >> a.split] : place >> a.split;
    const int tile = a.rank + own * a.world;
    PH_KERNEL_BEGIN();
    MDH_DIAG_WAVE(own);
@@ -143,7 +162,7 @@ __global__ __launch_bounds__(MDH_BLOCK, MDH_OCC(PART, MODE)) void k_screen(KScen
    {
       int i, j;
       float u, v;
-      tile_pixel(a, tile, lane, i, j, u, v);
+      tile_pixel(a, tile, place & ((1 << a.split) - 1), lane, i, j, u, v);
       const bool valid = i < a.W && j < a.H;
       f3 origin, dir;
       camera_ray(cam, u, v, origin, dir);
@@ -188,9 +207,9 @@ __global__ __launch_bounds__(MDH_BLOCK, MDH_OCC(PART, MODE)) void k_screen(KScen
       int wave2 = wave;
       asm volatile("" : "+s"(wave2));
       const int place2 = (int)blockIdx.x * (MDH_BLOCK / 64) + wave2;
-      const int own2 = a.order ? (int)a.order[place2] : place2;
+      const int own2 = a.order ? (int)a.order[place2 >> a.split] : place2 >> a.split;
       const int tile2 = a.rank + own2 * a.world;
-      tile_pixel(a, tile2, lane_index_fresh(), i, j, u, v);
+      tile_pixel(a, tile2, place2 & ((1 << a.split) - 1), lane_index_fresh(), i, j, u, v);
       // (everything but the tone map and the stores is behind the wavefront: what it took decides its place in later passes)
       if (a.cost && lane_index_fresh() == 0) a.cost[own2] = tile_cost_key((unsigned)__builtin_amdgcn_s_memtime() - t_begin);
    }

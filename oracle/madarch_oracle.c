@@ -1503,6 +1503,7 @@ int32_t orc_set_option(orc_renderer *r, int32_t option, int32_t value)
       break;
    case MDH_OPT_RADIANCE_ORDER: break; /* which lane computes a texel, not what it holds: nothing to restate */
    case MDH_OPT_SCREEN_ORDER: break;   /* the order the tiles are started in: nothing to restate */
+   case MDH_OPT_SCREEN_SPLIT: break;   /* how many wavefronts draw a tile: nothing to restate */
    case MDH_OPT_NUMERICS: if (value != 0) return seterr(MDH_E_STATE, "the oracle's numerics are the contract"); break;
    case MDH_OPT_RADIANCE_MIPS:
       if (value && (r->probes.radiance_resolution & (r->probes.radiance_resolution - 1)) != 0)
@@ -1536,6 +1537,7 @@ int32_t orc_get_option(orc_renderer *r, int32_t option, int32_t *value)
    case MDH_OPT_RADIANCE_MIPS: *value = r->opt_mips; break;
    case MDH_OPT_RADIANCE_ORDER: *value = 0; break;
    case MDH_OPT_SCREEN_ORDER: *value = 0; break;
+   case MDH_OPT_SCREEN_SPLIT: *value = 0; break;
    case MDH_OPT_NUMERICS: *value = 0; break;
    case ORC_OPT_SDF_MODE: *value = r->opt_sdf_mode; break;
    case ORC_OPT_THREADS: *value = nthreads(r); break;

@@ -10,6 +10,8 @@ from madarch_amd import examples, sharding, _binding as B
 W, H = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (1920, 1080)
 hb = B.hip_binding()
 R = examples.global_illumination(W, H, Probes=examples.GI_8X8X8_PROBES, Binding=hb)
+if os.environ.get("MADARCH_SPLIT") is not None:  # (experiments: MDH_OPT_SCREEN_SPLIT's limit)
+    R.Set_Option(B.OPT_SCREEN_SPLIT, int(os.environ["MADARCH_SPLIT"]))
 rows = []
 for world in (1, 2, 4, 8):
     frame = sharding.ShardedFrame(R, 0, world, None)

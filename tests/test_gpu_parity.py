@@ -757,3 +757,38 @@ def test_partition_build_with_more_instances_than_a_wavefront(hip, orc, method):
     if method != 0:
         assert outs[1]["warnings"][0] > 0  # Index_Count = 12 is too small for what the fast builders collect in cells of this grid
     assert_parity(*outs)
+
+
+@pytest.mark.parametrize("scene,mode,world", [("global_illumination", 0, 1), ("simple_scene", 0, 1), ("simple_scene", 2, 1), ("light_shafts", 0, 1),
+                                              ("global_illumination", 0, 3), ("simple_scene", 1, 1)])
+def test_split_tiles_change_no_pixel(hip, scene, mode, world):
+    """MDH_OPT_SCREEN_SPLIT: a screen launch that leaves the chip's wavefront slots empty gives every 8x8 tile to two
+    wavefronts of 8x4 pixels or four of 4x4 (the other lanes idle).  HOW MANY wavefronts draw a tile, never what it holds:
+    framebuffer, geometry buffer and window pixels are those of one wavefront per tile -- both split factors, partial
+    tiles at the right and lower edge, a rank's tiles, frames in flight."""
+    outs = []
+    # 27 x 18 = 486 tiles, the last column and row partial: 4 x 486 <= 2560 (quadrants), 2 x 486 <= 1000 (halves), 0 (whole tiles)
+    for limit in (0, 2560, 1000):
+        R = make(scene, 212, 140, hip, mode=mode, probes=SMALL_PROBES)
+        assert R.Get_Option(B.OPT_SCREEN_SPLIT) == 2560
+        R.Set_Option(B.OPT_SCREEN_SPLIT, limit)
+        if world > 1:
+            R.Set_Option(B.OPT_WORLD, world)
+            R.Set_Option(B.OPT_RANK, 1)
+        frames = []
+        for f in range(4):
+            if f == 2:
+                R.Set_Camera_Position((2.2, 2.0, 0.0))
+            R.Render()
+            R.Swap_Buffers()
+            frames.append((R.Read_Framebuffer(), R.Read_Gbuffer(), R.Front_Buffer()))
+        outs.append(frames)
+        R.Destroy()
+    for other in outs[1:]:
+        for (img_a, gb_a, px_a), (img_b, gb_b, px_b) in zip(outs[0], other):
+            assert same_bits(img_a, img_b)
+            if world == 1:  # (the geometry buffer of other ranks' tiles is never written, nor cleared)
+                assert all(same_bits(x, y) for x, y in zip(gb_a, gb_b))
+            assert (px_a == px_b).all()
+    with pytest.raises(B.MadarchError):
+        make(scene, 16, 16, hip, mode=mode, probes=SMALL_PROBES).Set_Option(B.OPT_SCREEN_SPLIT, -1)
