@@ -652,6 +652,12 @@ static int commit_scene(mdh_renderer *r, hipStream_t up)
    for (int k = 0; k < r->npk; ++k) { H[H_KQUAD + 4 * k] = H[H_KTYPE + k]; H[H_KQUAD + 4 * k + 1] = H[H_KSLOT + k]; H[H_KQUAD + 4 * k + 2] = H[H_KBASE + k]; H[H_KQUAD + 4 * k + 3] = H[H_KMAX + k]; }
    memcpy(t.data(), H, sizeof H);
    s.table_f4 = (int)t.size();
+   { // (MDH_SDF_SGPR: the words closest_primitive would read from the table; with a count of 0 they belong to the next kind and are not used)
+      const size_t ss = (size_t)s.tslot[PK_SPHERE], sb = (size_t)s.tslot[PK_BOX];
+      const float4 z = mk4(0, 0, 0, 0), a = ss < t.size() ? t[ss] : z, b0 = sb < t.size() ? t[sb] : z, b1 = sb + 1 < t.size() ? t[sb + 1] : z;
+      const float fs[4] = {a.x, a.y, a.z, a.w}, fb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+      memcpy(s.first_sphere, fs, sizeof fs); memcpy(s.first_box, fb, sizeof fb);
+   }
    // (the march kernels park MDH_PARK_DWORDS floats per thread behind the table, lds_bytes_march)
    if ((size_t)(s.table_f4 + part_bits_f4(r)) * 16 + (size_t)MDH_SCR_PARK_ROWS * MDH_BLOCK * sizeof(float) > 64 * 1024)
       return seterr(MDH_E_INVALID, "scene tables exceed the 64 KiB LDS budget of a workgroup");
@@ -1802,11 +1808,11 @@ static int run_pass(mdh_renderer *r, int pass, hipStream_t st, int src, int dst,
       if (r->opt_world > 1 && r->opt_irr_all) { pr.probe_begin = 0; pr.probe_end = probe_total(r); } // every rank, every probe
       int n = pr.probe_end - pr.probe_begin; // one workgroup per probe, its taps staged in LDS
       size_t lds = (size_t)2 * pr.rres * pr.rres * sizeof(float4);
+      float *tap_planes = nullptr;
 #if MDH_FAST_NUMERICS
       if (pr.ires * pr.ires <= 64) lds += (size_t)4 * 64 * sizeof(float4); // (the experiment's fold: all taps staged, four partial sums per texel)
       else
 #endif
-      float *tap_planes = nullptr;
       if (MDH_IRR_CHANNELS && pr.ires * pr.ires <= 64 && MDH_IRR_BLOCK == 256 && n > 0) { // (k_irradiance: a channel per wavefront, the taps through device memory)
          const size_t need = (size_t)n * 6 * MDH_IRR_CHANNELS_PLANE(pr.rres * pr.rres);
          if (need > r->irr_taps_cap) { // (the scratch of irradiance passes only, which follow one another on their stream)
@@ -1845,7 +1851,8 @@ static int run_pass(mdh_renderer *r, int pass, hipStream_t st, int src, int dst,
          const long per_block = (long)MDH_BLOCK * MDH_VIS_ROUNDS; // every wavefront owns MDH_VIS_ROUNDS x 64 froxels (k_visibility)
          int blocks = (int)((n + per_block - 1) / per_block);
 #else
-         int blocks = (int)((n + MDH_BLOCK - 1) / MDH_BLOCK);
+         const long per_block = (long)MDH_BLOCK * MDH_VIS_LOOP;
+         int blocks = (int)((n + per_block - 1) / per_block);
 #endif
          // inside a frame the launch also marches the scattering texels' camera rays (k_visibility's second part, mdh_kernels.h)
          const int vis_blocks = blocks;

@@ -71,6 +71,9 @@ struct KScene {
    int part_small;
    unsigned part_tbit[4], part_tmask[4];
    float part_fdims[3], part_fyz; // (float)part_dims[a] and (float)(part_dims[1] * part_dims[2]): the same conversions, once on the host
+   // MDH_SDF_SGPR: the first sphere and the first box of the table once more, as kernel arguments -- scalar operands of the
+   // brute-force scan (closest_primitive) instead of three LDS broadcast reads into twelve vector registers per evaluation
+   float first_sphere[4], first_box[8];
 };
 // int block at table[0..]: per-kind data in SCENE order (the order the flat primitive index
 // and the arg-min tie-break follow, scenes.adb:656-666) and the light kinds
@@ -728,6 +731,9 @@ MDH_DEV float prim_dist(int type, int slot, f3 x)
 #ifndef MDH_SDF_PREFETCH
 #define MDH_SDF_PREFETCH 1
 #endif
+#ifndef MDH_SDF_SGPR
+#define MDH_SDF_SGPR 0
+#endif
 #ifndef MDH_SDF_SQRT_WAVE
 #define MDH_SDF_SQRT_WAVE 0 // the brute-force scan's sphere and box roots through sqrt_wave_ (below)
 #endif
@@ -738,6 +744,10 @@ struct SdfRegs { float4 s, b0, b1; };
 MDH_DEV SdfRegs sdf_regs(const KScene &sc)
 {
    SdfRegs r;
+#if MDH_SDF_SGPR
+   r.s = r.b0 = r.b1 = make_float4(0.0f, 0.0f, 0.0f, 0.0f); // (unused: closest_primitive takes the kernel arguments)
+   return r;
+#endif
    r.s = s_tab[sc.tslot[PK_SPHERE]];
    r.b0 = s_tab[sc.tslot[PK_BOX]]; r.b1 = s_tab[sc.tslot[PK_BOX] + 1];
    return r;
@@ -745,7 +755,10 @@ MDH_DEV SdfRegs sdf_regs(const KScene &sc)
 template <bool CUSTOM> MDH_DEV float closest_primitive(const KScene &sc, f3 x, const SdfRegs *regs = nullptr)
 {
    float closest = sc.max_dist;
-#if MDH_SDF_PREFETCH
+#if MDH_SDF_SGPR
+   const float4 pf_s = make_float4(sc.first_sphere[0], sc.first_sphere[1], sc.first_sphere[2], sc.first_sphere[3]);
+   const float4 pf_b0 = make_float4(sc.first_box[0], sc.first_box[1], sc.first_box[2], sc.first_box[3]), pf_b1 = make_float4(sc.first_box[4], sc.first_box[5], sc.first_box[6], sc.first_box[7]);
+#elif MDH_SDF_PREFETCH
    // the first sphere and the first box are on their way from LDS while the planes are evaluated: a wavefront that
    // has a SIMD to itself (the tail of every pass, and whole passes of a sharded frame) has nothing else to
    // hide that latency behind.

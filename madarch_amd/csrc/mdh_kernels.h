@@ -1149,6 +1149,9 @@ __global__ __launch_bounds__(MDH_IRR_BLOCK) void k_irradiance(KProbes pr, const 
 #define MDH_VIS_QUEUE 0 // (measured on MI355X, light_shafts 1080p: the pass 0.067 -> 0.109 ms on its own and -1.5 % in flight --
                         //  serving a lane is ~250 instructions under a sparse mask, as much as its march saves: DESIGN.md, dropped)
 #endif
+#ifndef MDH_VIS_LOOP
+#define MDH_VIS_LOOP 1 // froxels per lane of the lock-step form, one after the other (measured 2 and 4: the pass 0.074 -> 0.100 / 0.153 ms alone, +-0 in flight -- it is the length of a wavefront's chain, not the staging of the table)
+#endif
 #ifndef MDH_VIS_ROUNDS
 #define MDH_VIS_ROUNDS 4
 #endif
@@ -1395,23 +1398,27 @@ template <int PART> __global__ __launch_bounds__(MDH_BLOCK) void k_visibility(KS
       }
    }
 #else
-   const long lin = (long)blockIdx.x * MDH_BLOCK + threadIdx.x;
-   if (lin >= n) return;
-   int i, j;
-   froxel_texel(vol, W, H, lin, i, j);
-   f3 pos, dir;
-   froxel_point(vol, cam, W, H, i, j, pos, dir);
-   f3 result = F3(0.0f, 0.0f, 0.0f);
-   for (int l = 0; l < sc.total_lights; ++l) { // sample_lights :8-19
-      f3 L;
-      float L_dist;
-      f3 radiance = sample_light<(PART & MDH_PF_CUSTOM) != 0>(sc, l, pos, F3(1.0f, 0.0f, 0.0f), L, L_dist); // compute_frustrum_visibility.glsl:12
-      float visibility = raycast_visibility<PART>(sc, pos, L, L_dist);
-      f3 L_in = radiance * (sexp(-L_dist * MDH_TAU) * visibility);
-      result = result + (L_in * MDH_TAU) * henvey_greenstein_phase(L, dir);
+   // (MDH_VIS_LOOP froxels per lane, one after the other: a workgroup stages the scene table once for all of them)
+#pragma unroll 1
+   for (int turn = 0; turn < MDH_VIS_LOOP; ++turn) {
+      const long lin = ((long)blockIdx.x * MDH_VIS_LOOP + turn) * MDH_BLOCK + threadIdx.x;
+      if (lin >= n) return;
+      int i, j;
+      froxel_texel(vol, W, H, lin, i, j);
+      f3 pos, dir;
+      froxel_point(vol, cam, W, H, i, j, pos, dir);
+      f3 result = F3(0.0f, 0.0f, 0.0f);
+      for (int l = 0; l < sc.total_lights; ++l) { // sample_lights :8-19
+         f3 L;
+         float L_dist;
+         f3 radiance = sample_light<(PART & MDH_PF_CUSTOM) != 0>(sc, l, pos, F3(1.0f, 0.0f, 0.0f), L, L_dist); // compute_frustrum_visibility.glsl:12
+         float visibility = raycast_visibility<PART>(sc, pos, L, L_dist);
+         f3 L_in = radiance * (sexp(-L_dist * MDH_TAU) * visibility);
+         result = result + (L_in * MDH_TAU) * henvey_greenstein_phase(L, dir);
+      }
+      float *o = vol.vis + ((size_t)j * W + i) * 3;
+      o[0] = result.x; o[1] = result.y; o[2] = result.z;
    }
-   float *o = vol.vis + ((size_t)j * W + i) * 3;
-   o[0] = result.x; o[1] = result.y; o[2] = result.z;
 #endif
 }
 
