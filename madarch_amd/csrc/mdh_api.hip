@@ -1955,12 +1955,17 @@ static int run_pass(mdh_renderer *r, int pass, hipStream_t st, int src, int dst,
       // MDH_OPT_SCREEN_SPLIT (ScreenArgs::split): launches that leave most of the chip's wavefront slots empty give a tile to
       // two or four wavefronts; never with a tile order (launches of 2 048 tiles and more)
       a.split = 0;
+      a.split_first = 0;
       if (!a.order && !a.cost && r->opt_scr_split > 0) {
          if ((long)own_tiles * 4 <= r->opt_scr_split) a.split = 2;
          else if ((long)own_tiles * 2 <= r->opt_scr_split) a.split = 1;
       }
+      // ... and of an ordered launch the slowest tiles (MADARCH_HIP_SPLIT_FIRST, thousandths of the launch's tiles; a pass that
+      // records the tiles' durations draws every tile with one wavefront: the key is the tile's)
+      static const int split_first_env = [] { const char *e = getenv("MADARCH_HIP_SPLIT_FIRST"); return e ? atoi(e) : MDH_SCREEN_SPLIT_FIRST_PERMILLE; }();
+      if (a.order && !a.cost && r->opt_scr_split > 0 && split_first_env > 0) a.split_first = (int)((long)own_tiles * split_first_env / 1000);
       if (own_tiles > 0) {
-         const long waves = (long)own_tiles << a.split;
+         const long waves = ((long)own_tiles << a.split) + 3l * a.split_first;
          int blocks = (int)((waves + (MDH_BLOCK / 64) - 1) / (MDH_BLOCK / 64));
          if (jit) {
             struct { KScene sc; KProbes pr; KVolumetrics vol; KCamera cam; ScreenArgs a; } args = {r->ks, pr, vol, cam, a};

@@ -107,7 +107,22 @@ struct ScreenArgs {
    // wavefront marches only as long as ITS pixels need and the tile's work runs on several SIMDs.  A pixel's operations do not
    // depend on which lanes march beside it: the same bits (tests/test_gpu_parity.py::test_split_tiles_change_no_pixel).
    int split;
+   // ... and in an ORDERED launch (slowest tiles first) the first `split_first` places -- the tiles whose wavefronts make the
+   // pass's tail, a sum of marches each as long as the longest among 64 pixels -- are drawn by four wavefronts of 4x4 pixels
+   // each (places 0 .. 4 split_first - 1), the others by one
+   int split_first;
 };
+// place of a launch -> its index into the launch's tiles, the part of the tile, the split factor (ScreenArgs::split, split_first)
+MDH_DEV void screen_place(const ScreenArgs &a, int place, int &idx, int &sub, int &split)
+{
+   if (a.split_first > 0) { // (wave-uniform)
+      if (place < 4 * a.split_first) { idx = place >> 2; sub = place & 3; split = 2; }
+      else { idx = place - 3 * a.split_first; sub = 0; split = 0; }
+   } else { idx = place >> a.split; sub = place & ((1 << a.split) - 1); split = a.split; }
+}
+#ifndef MDH_SCREEN_SPLIT_FIRST_PERMILLE
+#define MDH_SCREEN_SPLIT_FIRST_PERMILLE 0 // of an ordered launch's tiles, the slowest so many thousandths as four wavefronts each (ScreenArgs::split_first)
+#endif
 #ifndef MDH_SCREEN_SPLIT_DEFAULT
 #define MDH_SCREEN_SPLIT_DEFAULT 2560 // MDH_OPT_SCREEN_SPLIT's initial value
 #endif
@@ -125,12 +140,12 @@ MDH_DEV unsigned char tile_cost_key(unsigned cycles) { return (unsigned char)min
 // argument segment read through a pointer the compiler cannot trace back and from a lane index taken from the hardware
 // (tile_pixel).  Kept live they cost ~10 VGPRs and ~20 SGPRs which the compiler spilled to scratch (80 bytes per
 // lane written and read back through HBM: 172 MB per launch at 1080p against a 33 MB framebuffer).
-MDH_DEV void tile_pixel(const ScreenArgs &a, int tile, int sub, int lane, int &i, int &j, float &u, float &v)
+MDH_DEV void tile_pixel(const ScreenArgs &a, int tile, int sub, int split, int lane, int &i, int &j, float &u, float &v)
 {
-   if (a.split == 0) { // (wave-uniform)
+   if (split == 0) { // (wave-uniform)
       i = (tile % a.tiles_x) * 8 + (lane & 7);
       j = (tile / a.tiles_x) * 8 + (lane >> 3);
-   } else if (a.split == 1) { // the tile's upper or lower 8x4 pixels
+   } else if (split == 1) { // the tile's upper or lower 8x4 pixels
       i = (tile % a.tiles_x) * 8 + (lane & 7);
       j = (tile / a.tiles_x) * 8 + sub * 4 + ((lane >> 3) & 3);
       if (lane >= 32) i = a.W; // (no pixel: not valid)
@@ -149,9 +164,11 @@ __global__ __launch_bounds__(MDH_BLOCK, MDH_OCC(PART, MODE)) void k_screen(KScen
    stage_table(sc);
    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
    const int place = blockIdx.x * (MDH_BLOCK / 64) + wave;
-   if ((place >> a.split) >= a.n_own) return; // wave-uniform
+   int pidx, psub, psplit;
+   screen_place(a, place, pidx, psub, psplit);
+   if (pidx >= a.n_own) return; // wave-uniform
    const unsigned t_begin = (unsigned)__builtin_amdgcn_s_memtime();
-   const int own = a.order ? (int)a.order[place >> a.split] : place >> a.split;
+   const int own = a.order ? (int)a.order[pidx] : pidx;
    const int tile = a.rank + own * a.world;
    PH_KERNEL_BEGIN();
    MDH_DIAG_WAVE(own);
@@ -162,7 +179,7 @@ __global__ __launch_bounds__(MDH_BLOCK, MDH_OCC(PART, MODE)) void k_screen(KScen
    {
       int i, j;
       float u, v;
-      tile_pixel(a, tile, place & ((1 << a.split) - 1), lane, i, j, u, v);
+      tile_pixel(a, tile, psub, psplit, lane, i, j, u, v);
       const bool valid = i < a.W && j < a.H;
       f3 origin, dir;
       camera_ray(cam, u, v, origin, dir);
@@ -207,9 +224,11 @@ __global__ __launch_bounds__(MDH_BLOCK, MDH_OCC(PART, MODE)) void k_screen(KScen
       int wave2 = wave;
       asm volatile("" : "+s"(wave2));
       const int place2 = (int)blockIdx.x * (MDH_BLOCK / 64) + wave2;
-      const int own2 = a.order ? (int)a.order[place2 >> a.split] : place2 >> a.split;
+      int pidx2, psub2, psplit2;
+      screen_place(a, place2, pidx2, psub2, psplit2);
+      const int own2 = a.order ? (int)a.order[pidx2] : pidx2;
       const int tile2 = a.rank + own2 * a.world;
-      tile_pixel(a, tile2, place2 & ((1 << a.split) - 1), lane_index_fresh(), i, j, u, v);
+      tile_pixel(a, tile2, psub2, psplit2, lane_index_fresh(), i, j, u, v);
       // (everything but the tone map and the stores is behind the wavefront: what it took decides its place in later passes)
       if (a.cost && lane_index_fresh() == 0) a.cost[own2] = tile_cost_key((unsigned)__builtin_amdgcn_s_memtime() - t_begin);
    }
