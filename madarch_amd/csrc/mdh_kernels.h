@@ -622,9 +622,9 @@ MDH_DEV f3 irradiance_blend(const KProbes &pr, const void *prev, float hyst, uns
    const f3 old = atlas_texel(prev, pr.fmt, idx, -1);
    return F3(mix_(fresh.x, old.x, hyst), mix_(fresh.y, old.y, hyst), mix_(fresh.z, old.z, hyst));
 }
-// k_irradiance's channel form, one whole chunk of 64 taps on one wavefront: this wavefront's sixteen taps of the NEXT chunk's
-// weights (NEXT) and the chunk folded into the wavefront's channel (RAD: the channel has a radiance plane; the weight's own
-// chain adds w).
+// The pieces of k_irradiance's channel form (one channel of a probe's fold per wavefront, below): a wavefront's quarter of a
+// chunk's weights (irr_produce) and a chunk folded into the wavefront's channel (irr_fold; RAD: the channel has a radiance
+// plane, the weight's own chain adds w).
 //   A tap's radiance and direction are the same for all 64 texels.  Read as LDS broadcasts they cost an LDS instruction and
 //   four LDS cycles per four taps each, and with two probes on a CU the LDS array, not instruction issue, bounded the pass.
 //   Here sixteen taps sit in ONE register, lane l holding tap l mod 16 (one 4-byte read per sixteen taps and plane), and
@@ -734,7 +734,7 @@ __global__ __launch_bounds__(MDH_IRR_BLOCK) void k_irradiance(KProbes pr, const 
       // dwords apart).  The same multiplications and additions in the reference's order on every chain; the issue slots of a
       // probe's fold spread over four SIMDs instead of one.
 #if MDH_IRR_PRIO
-      // all four wavefronts are the pass's critical path and meet at a barrier every 64 taps; beside the march kernels of the
+      // all four wavefronts are the pass's critical path and meet at a barrier every chunk; beside the march kernels of the
       // neighbouring frames (five or seven wavefronts per SIMD, all of them older) the youngest wavefront of a SIMD gets the
       // issue slots the others leave: raised priority for the pass that heads the next frame's dependency chain
       __builtin_amdgcn_s_setprio(MDH_IRR_PRIO);
@@ -744,8 +744,9 @@ __global__ __launch_bounds__(MDH_IRR_BLOCK) void k_irradiance(KProbes pr, const 
       const int ntp = (ntaps + 63) / 64 * 64, nchunks = (ntaps + CH - 1) / CH;
       // The taps themselves (radiance and direction: the same for all 64 texels) go through a scratch buffer in device memory,
       // six planes of ntp floats per probe of the pass -- written by this workgroup, read back by it behind a barrier, sixteen
-      // taps to a register, a chunk ahead of their use: the LDS holds the weights only (34 KiB; with the taps beside them the
-      // pass needed 59 KiB and, with frames in flight, waited for a CU that had them free: -8 % frame rate, measured).
+      // taps to a register, a turn ahead of their use: the LDS holds the weights only (18 KiB for chunks of 32 taps; with the taps
+      // beside chunks of 64 the pass needed 59 KiB and, with frames in flight, waited for a CU that had them free: -8 % frame
+      // rate, measured).
       float *g_dpl = tap_planes + (size_t)blockIdx.x * 6 * ntp; // [3][ntp] the taps' directions, a plane per component
       float *g_rch = g_dpl + 3 * ntp;                            // [3][ntp] their radiance, a plane per channel
       float *s_w = (float *)s_taps;                              // [2][64][S] weights of two chunks, a row per texel
