@@ -1590,8 +1590,16 @@ template <int PART, int MODE> static void launch_screen_g(mdh_renderer *r, hipSt
 }
 // (pow2: mode 0 with probe counts and tile resolutions that are all powers of two runs the MDH_PF_POW2 variant;
 //  built for scenes without user-defined kinds only -- those compile their own variant at run time, or interpret)
-template <int PART> static void launch_screen_m(mdh_renderer *r, hipStream_t st, const KProbes &pr, const KVolumetrics &vol, const KCamera &cam, const ScreenArgs &a, int blocks, bool pow2)
+template <int PART_> static void launch_screen_m(mdh_renderer *r, hipStream_t st, const KProbes &pr, const KVolumetrics &vol, const KCamera &cam, const ScreenArgs &a, int blocks, bool pow2)
 {
+   // (the census variants are built for the renderer's own pixel program only: the optional specular modes and screen modes 1 and 2
+   //  run the general scan)
+   constexpr int PART = PART_ & ~MDH_PF_ROOM;
+   if (r->opt_mode == 0 && (PART_ & MDH_PF_ROOM) && !(a.spec_mode == 1 || a.spec_mode == 3 || (a.spec_mode == 2 && pr.rad_mips))) {
+      if (pow2) launch_screen_g<MDH_PF_ROOM | MDH_PF_POW2, 0>(r, st, pr, vol, cam, a, blocks);
+      else launch_screen_g<MDH_PF_ROOM, 0>(r, st, pr, vol, cam, a, blocks);
+      return;
+   }
    if (r->opt_mode == 0) {
       if (a.spec_mode == 1 || a.spec_mode == 3 || (a.spec_mode == 2 && pr.rad_mips)) { // the other two bodies of render_probes.glsl:264-272 (and mode 2 over a mip chain): a variant of their own
          if (r->opt_gbuffer) hipLaunchKernelGGL((k_screen<PART, 0, true, true>), dim3(blocks), dim3(MDH_BLOCK), lds_bytes_screen(r), st, r->ks, pr, vol, cam, a);
@@ -1642,6 +1650,11 @@ static int run_pass(mdh_renderer *r, int pass, hipStream_t st, int src, int dst,
    // user-defined kinds the kernels test the setting at run time)
    const int pf = (r->part.enable != 0 ? MDH_PF_PART : 0) | (has_custom ? MDH_PF_CUSTOM : 0) |
                   (r->part.enable != 0 && r->part.border_behavior != 0 && !has_custom ? MDH_PF_FALLBACK : 0);
+   // ... bit 4 = the census of the reference's rooms (MDH_PF_ROOM, mdh_device.h: closest_primitive): every plane folded into
+   // the axis offsets, one sphere, one box, nothing else, no partition -- the scan's loops as straight-line code
+   const bool room = pf == 0 && r->ks.n_axis > 0 && r->ks.gplane_count == 0 && r->ks.tcount[PK_SPHERE] == 1 && r->ks.tcount[PK_BOX] == 1 &&
+                     r->ks.tcount[PK_TRIANGLE] == 0 && MDH_ROOM_VARIANTS;
+   const int pfk = room ? MDH_PF_ROOM : pf; // (the kernels that only march: visibility, scattering)
    // the probe-sampling kernels (radiance, mode-0 screen) have a variant for atlases whose every dimension is a power of two
    auto is_pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
    // (... and small enough for what those variants assume besides: probe ids within 24-bit products, RGBA8 byte offsets
@@ -1653,8 +1666,9 @@ static int run_pass(mdh_renderer *r, int pass, hipStream_t st, int src, int dst,
                      pcount * ires * ires <= (1ll << 30);
 #define MDH_LAUNCH_PF(KERNEL, GRID, BLOCK, LDS, ...)                                                      \
    do {                                                                                                   \
-      switch (pf) {                                                                                       \
+      switch (pfk) {                                                                                      \
       case 0: hipLaunchKernelGGL(KERNEL<0>, GRID, BLOCK, LDS, st, __VA_ARGS__); break;                     \
+      case MDH_PF_ROOM: hipLaunchKernelGGL(KERNEL<MDH_PF_ROOM>, GRID, BLOCK, LDS, st, __VA_ARGS__); break; \
       case 1: hipLaunchKernelGGL(KERNEL<1>, GRID, BLOCK, LDS, st, __VA_ARGS__); break;                     \
       case 2: hipLaunchKernelGGL(KERNEL<2>, GRID, BLOCK, LDS, st, __VA_ARGS__); break;                     \
       case 9: hipLaunchKernelGGL(KERNEL<9>, GRID, BLOCK, LDS, st, __VA_ARGS__); break;                     \
@@ -1779,9 +1793,11 @@ static int run_pass(mdh_renderer *r, int pass, hipStream_t st, int src, int dst,
             if (pow2 && !has_custom) {
                if (pf & MDH_PF_FALLBACK) MDH_LAUNCH_RAD(MDH_PF_PART | MDH_PF_POW2 | MDH_PF_FALLBACK);
                else if (pf & MDH_PF_PART) MDH_LAUNCH_RAD(MDH_PF_PART | MDH_PF_POW2);
+               else if (room) MDH_LAUNCH_RAD(MDH_PF_POW2 | MDH_PF_ROOM);
                else MDH_LAUNCH_RAD(MDH_PF_POW2);
             } else
-               switch (pf) {
+               switch (pfk) {
+               case MDH_PF_ROOM: MDH_LAUNCH_RAD(MDH_PF_ROOM); break;
                case 0: MDH_LAUNCH_RAD(0); break;
                case 1: MDH_LAUNCH_RAD(1); break;
                case 2: MDH_LAUNCH_RAD(2); break;
@@ -1972,7 +1988,8 @@ static int run_pass(mdh_renderer *r, int pass, hipStream_t st, int src, int dst,
             int rc = jit_launch(jm->fn[kname], blocks, MDH_BLOCK, lds_bytes_screen(r), st, args);
             if (rc != MDH_OK) return rc;
          } else
-         switch (pf) {
+         switch (pfk) {
+         case MDH_PF_ROOM: launch_screen_m<MDH_PF_ROOM>(r, st, pr, vol, cam, a, blocks, pow2); break;
          case 0: launch_screen_m<0>(r, st, pr, vol, cam, a, blocks, pow2); break;
          case 1: launch_screen_m<1>(r, st, pr, vol, cam, a, blocks, pow2); break;
          case 2: launch_screen_m<2>(r, st, pr, vol, cam, a, blocks, pow2); break;

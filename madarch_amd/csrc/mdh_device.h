@@ -752,7 +752,12 @@ MDH_DEV SdfRegs sdf_regs(const KScene &sc)
    r.b0 = s_tab[sc.tslot[PK_BOX]]; r.b1 = s_tab[sc.tslot[PK_BOX] + 1];
    return r;
 }
-template <bool CUSTOM> MDH_DEV float closest_primitive(const KScene &sc, f3 x, const SdfRegs *regs = nullptr)
+// ROOM (MDH_PF_ROOM): the scan of a scene whose CENSUS is that of the reference's rooms -- every plane folded into the six axis
+// offsets, exactly one sphere, exactly one box, no triangles, no user-defined kinds (global_illumination, light_shafts: BASELINE
+// configs 3, 4, 5).  The same operations on the same operands; what goes is what a count known only at run time costs at every
+// march step -- the loops' scalar bookkeeping and branches around bodies that run once or never -- and the registers their
+// induction state holds: 96 -> 80 VGPRs in the screen kernel, six wavefronts per SIMD without a further spill.
+template <bool CUSTOM, bool ROOM = false> MDH_DEV float closest_primitive(const KScene &sc, f3 x, const SdfRegs *regs = nullptr)
 {
    float closest = sc.max_dist;
 #if MDH_SDF_SGPR
@@ -765,18 +770,18 @@ template <bool CUSTOM> MDH_DEV float closest_primitive(const KScene &sc, f3 x, c
    const float4 pf_s = regs ? regs->s : s_tab[sc.tslot[PK_SPHERE]];
    const float4 pf_b0 = regs ? regs->b0 : s_tab[sc.tslot[PK_BOX]], pf_b1 = regs ? regs->b1 : s_tab[sc.tslot[PK_BOX] + 1];
 #endif
-   if (sc.n_axis > 0) { // six adds for all axis-aligned planes together
+   if (ROOM || sc.n_axis > 0) { // six adds for all axis-aligned planes together
       closest = min_(closest, min_(x.x + sc.axis_off[0], -x.x + sc.axis_off[1]));
       closest = min_(closest, min_(x.y + sc.axis_off[2], -x.y + sc.axis_off[3]));
       closest = min_(closest, min_(x.z + sc.axis_off[4], -x.z + sc.axis_off[5]));
    }
    {
-      const int n = sc.gplane_count, s0 = sc.gplane_slot;
+      const int n = ROOM ? 0 : sc.gplane_count, s0 = sc.gplane_slot;
 #pragma unroll MDH_SDF_UNROLL
       for (int i = 0; i < n; ++i) closest = min_(closest, sd_plane(s_tab[s0 + i], x)); // (unrolled in pairs: v_min3_f32)
    }
    {
-      const int n = sc.tcount[PK_SPHERE], s0 = sc.tslot[PK_SPHERE];
+      const int n = ROOM ? 1 : sc.tcount[PK_SPHERE], s0 = sc.tslot[PK_SPHERE];
 #define MDH_SPHERE_STEP(a_)                                                                  \
       do {                                                                                   \
          const float4 a = (a_);                                                              \
@@ -796,7 +801,7 @@ template <bool CUSTOM> MDH_DEV float closest_primitive(const KScene &sc, f3 x, c
 #undef MDH_SPHERE_STEP
    }
    {
-      const int n = sc.tcount[PK_BOX], s0 = sc.tslot[PK_BOX];
+      const int n = ROOM ? 1 : sc.tcount[PK_BOX], s0 = sc.tslot[PK_BOX];
 #define MDH_BOX_STEP(c_, e_)                                                                 \
       do {                                                                                   \
          const f3 q = abs3(xyz(c_) - x) - xyz(e_); /* boxes.adb:10 */                        \
@@ -816,7 +821,7 @@ template <bool CUSTOM> MDH_DEV float closest_primitive(const KScene &sc, f3 x, c
 #undef MDH_BOX_STEP
    }
    {
-      const int n = sc.tcount[PK_TRIANGLE], s0 = sc.tslot[PK_TRIANGLE];
+      const int n = ROOM ? 0 : sc.tcount[PK_TRIANGLE], s0 = sc.tslot[PK_TRIANGLE];
 #pragma unroll 1
       for (int i = 0; i < n; ++i)
          closest = min_raw(closest, sd_triangle<false>(xyz(s_tab[s0 + 3 * i]), xyz(s_tab[s0 + 3 * i + 1]), xyz(s_tab[s0 + 3 * i + 2]), x));
@@ -1206,6 +1211,7 @@ template <bool CUSTOM, bool FALLBACK> MDH_DEV float partitioning_closest_bits(co
 #define MDH_PF_CUSTOM 2
 #define MDH_PF_POW2 4 // bit 2 = the probe counts and both tile resolutions are powers of two (every atlas address is shifts and masks)
 #define MDH_PF_FALLBACK 8 // bit 3 = the space partition's Border_Behavior is Fallback (built-in kinds; scenes with user-defined kinds keep the run-time test)
+#define MDH_PF_ROOM 16 // bit 4 = the census of the reference's rooms, known when the kernel is built (closest_primitive's ROOM; never with bits 0, 1 or 3)
 // does this variant carry the full scan of the Fallback border?
 #define MDH_PF_HAS_FALLBACK(PART) ((((PART) & MDH_PF_FALLBACK) != 0) || (((PART) & MDH_PF_CUSTOM) != 0))
 template <int PART> MDH_DEV float sdf(const KScene &sc, f3 x)
@@ -1214,7 +1220,7 @@ template <int PART> MDH_DEV float sdf(const KScene &sc, f3 x)
    int dummy;
    (void)dummy;
    if (PART & MDH_PF_PART) return MDH_PART_BITS ? partitioning_closest_bits<(PART & MDH_PF_CUSTOM) != 0, MDH_PF_HAS_FALLBACK(PART)>(sc, x) : partitioning_lookup<false, (PART & MDH_PF_CUSTOM) != 0, MDH_PF_HAS_FALLBACK(PART)>(sc, x, dummy);
-   return closest_primitive<(PART & MDH_PF_CUSTOM) != 0>(sc, x);
+   return closest_primitive<(PART & MDH_PF_CUSTOM) != 0, (PART & MDH_PF_ROOM) != 0>(sc, x);
 }
 // the same with the first sphere and box already in registers (sdf_regs)
 template <int PART> MDH_DEV float sdf(const KScene &sc, f3 x, const SdfRegs &regs)
@@ -1223,7 +1229,7 @@ template <int PART> MDH_DEV float sdf(const KScene &sc, f3 x, const SdfRegs &reg
    int dummy;
    (void)dummy;
    if (PART & MDH_PF_PART) return MDH_PART_BITS ? partitioning_closest_bits<(PART & MDH_PF_CUSTOM) != 0, MDH_PF_HAS_FALLBACK(PART)>(sc, x) : partitioning_lookup<false, (PART & MDH_PF_CUSTOM) != 0, MDH_PF_HAS_FALLBACK(PART)>(sc, x, dummy);
-   return closest_primitive<(PART & MDH_PF_CUSTOM) != 0>(sc, x, &regs);
+   return closest_primitive<(PART & MDH_PF_CUSTOM) != 0, (PART & MDH_PF_ROOM) != 0>(sc, x, &regs);
 }
 template <int PART> MDH_DEV float sdf_info(const KScene &sc, f3 x, int &index)
 {

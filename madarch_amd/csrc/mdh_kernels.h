@@ -36,7 +36,15 @@
 #ifndef MDH_PART_WAVES_PER_SIMD
 #define MDH_PART_WAVES_PER_SIMD 6
 #endif
-#define MDH_OCC_BUILTIN(PART, MODE) (((PART) & MDH_PF_PART) ? ((MODE) == 2 ? MDH_DIRECT_WAVES_PER_SIMD : MDH_PART_WAVES_PER_SIMD) : MDH_WAVES_PER_SIMD)
+// The variants for the census of the reference's rooms (MDH_PF_ROOM) need 80 registers where the general scan needs 96: six
+// wavefronts per SIMD without a further spill (measured at config 3: five 5 681 - 5 726, six 5 818 - 5 863 Mpixels/s in flight).
+#ifndef MDH_ROOM_VARIANTS
+#define MDH_ROOM_VARIANTS 1 // (0: scenes with the rooms' census run the general scan -- A/B runs, and the literal build)
+#endif
+#ifndef MDH_ROOM_WAVES_PER_SIMD
+#define MDH_ROOM_WAVES_PER_SIMD 6
+#endif
+#define MDH_OCC_BUILTIN(PART, MODE) (((PART) & MDH_PF_PART) ? ((MODE) == 2 ? MDH_DIRECT_WAVES_PER_SIMD : MDH_PART_WAVES_PER_SIMD) : (((PART) & MDH_PF_ROOM) && (MODE) == 0 ? MDH_ROOM_WAVES_PER_SIMD : MDH_WAVES_PER_SIMD))
 #ifdef MDH_JIT
 #define MDH_OCC(PART, MODE) MDH_OCC_BUILTIN(PART, MODE)
 #else
