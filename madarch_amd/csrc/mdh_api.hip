@@ -1594,12 +1594,13 @@ template <int PART_> static void launch_screen_m(mdh_renderer *r, hipStream_t st
 {
    // (the census variants are built for the renderer's own pixel program only: the optional specular modes and screen modes 1 and 2
    //  run the general scan)
-   constexpr int PART = PART_ & ~MDH_PF_ROOM;
-   if (r->opt_mode == 0 && (PART_ & MDH_PF_ROOM) && !(a.spec_mode == 1 || a.spec_mode == 3 || (a.spec_mode == 2 && pr.rad_mips))) {
-      if (pow2) launch_screen_g<MDH_PF_ROOM | MDH_PF_POW2, 0>(r, st, pr, vol, cam, a, blocks);
-      else launch_screen_g<MDH_PF_ROOM, 0>(r, st, pr, vol, cam, a, blocks);
+   constexpr int CENSUS = PART_ & (MDH_PF_ROOM | MDH_PF_PSMALL), PART = PART_ & ~CENSUS;
+   if (CENSUS && r->opt_mode == 0 && !(a.spec_mode == 1 || a.spec_mode == 3 || (a.spec_mode == 2 && pr.rad_mips))) {
+      if (pow2) launch_screen_g<PART_ | MDH_PF_POW2, 0>(r, st, pr, vol, cam, a, blocks);
+      else launch_screen_g<PART_, 0>(r, st, pr, vol, cam, a, blocks);
       return;
    }
+   if ((CENSUS & MDH_PF_PSMALL) && r->opt_mode == 2) { launch_screen_g<PART_, 2>(r, st, pr, vol, cam, a, blocks); return; } // (simple_scene's direct light + occlusion: BASELINE config 2)
    if (r->opt_mode == 0) {
       if (a.spec_mode == 1 || a.spec_mode == 3 || (a.spec_mode == 2 && pr.rad_mips)) { // the other two bodies of render_probes.glsl:264-272 (and mode 2 over a mip chain): a variant of their own
          if (r->opt_gbuffer) hipLaunchKernelGGL((k_screen<PART, 0, true, true>), dim3(blocks), dim3(MDH_BLOCK), lds_bytes_screen(r), st, r->ks, pr, vol, cam, a);
@@ -1654,7 +1655,9 @@ static int run_pass(mdh_renderer *r, int pass, hipStream_t st, int src, int dst,
    // the axis offsets, one sphere, one box, nothing else, no partition -- the scan's loops as straight-line code
    const bool room = pf == 0 && r->ks.n_axis > 0 && r->ks.gplane_count == 0 && r->ks.tcount[PK_SPHERE] == 1 && r->ks.tcount[PK_BOX] == 1 &&
                      r->ks.tcount[PK_TRIANGLE] == 0 && MDH_ROOM_VARIANTS;
-   const int pfk = room ? MDH_PF_ROOM : pf; // (the kernels that only march: visibility, scattering)
+   // ... bit 5 = the partition's small form with its census (MDH_PF_PSMALL, mdh_device.h: partitioning_closest_bits)
+   const bool psmall = pf == MDH_PF_PART && r->ks.part_small && r->ks.part_tmask[PK_TRIANGLE] == 0 && r->ks.part_sp_pow2 && r->ks.part_cells < (1 << 24) && MDH_ROOM_VARIANTS;
+   const int pfk = room ? MDH_PF_ROOM : (psmall ? (MDH_PF_PART | MDH_PF_PSMALL) : pf); // (the kernel variant by the scene's census)
    // the probe-sampling kernels (radiance, mode-0 screen) have a variant for atlases whose every dimension is a power of two
    auto is_pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
    // (... and small enough for what those variants assume besides: probe ids within 24-bit products, RGBA8 byte offsets
@@ -1669,6 +1672,7 @@ static int run_pass(mdh_renderer *r, int pass, hipStream_t st, int src, int dst,
       switch (pfk) {                                                                                      \
       case 0: hipLaunchKernelGGL(KERNEL<0>, GRID, BLOCK, LDS, st, __VA_ARGS__); break;                     \
       case MDH_PF_ROOM: hipLaunchKernelGGL(KERNEL<MDH_PF_ROOM>, GRID, BLOCK, LDS, st, __VA_ARGS__); break; \
+      case MDH_PF_PART | MDH_PF_PSMALL: hipLaunchKernelGGL(KERNEL<MDH_PF_PART | MDH_PF_PSMALL>, GRID, BLOCK, LDS, st, __VA_ARGS__); break; \
       case 1: hipLaunchKernelGGL(KERNEL<1>, GRID, BLOCK, LDS, st, __VA_ARGS__); break;                     \
       case 2: hipLaunchKernelGGL(KERNEL<2>, GRID, BLOCK, LDS, st, __VA_ARGS__); break;                     \
       case 9: hipLaunchKernelGGL(KERNEL<9>, GRID, BLOCK, LDS, st, __VA_ARGS__); break;                     \
@@ -1792,12 +1796,14 @@ static int run_pass(mdh_renderer *r, int pass, hipStream_t st, int src, int dst,
             } else
             if (pow2 && !has_custom) {
                if (pf & MDH_PF_FALLBACK) MDH_LAUNCH_RAD(MDH_PF_PART | MDH_PF_POW2 | MDH_PF_FALLBACK);
+               else if (psmall) MDH_LAUNCH_RAD(MDH_PF_PART | MDH_PF_POW2 | MDH_PF_PSMALL);
                else if (pf & MDH_PF_PART) MDH_LAUNCH_RAD(MDH_PF_PART | MDH_PF_POW2);
                else if (room) MDH_LAUNCH_RAD(MDH_PF_POW2 | MDH_PF_ROOM);
                else MDH_LAUNCH_RAD(MDH_PF_POW2);
             } else
                switch (pfk) {
                case MDH_PF_ROOM: MDH_LAUNCH_RAD(MDH_PF_ROOM); break;
+               case MDH_PF_PART | MDH_PF_PSMALL: MDH_LAUNCH_RAD(MDH_PF_PART | MDH_PF_PSMALL); break;
                case 0: MDH_LAUNCH_RAD(0); break;
                case 1: MDH_LAUNCH_RAD(1); break;
                case 2: MDH_LAUNCH_RAD(2); break;
@@ -1990,6 +1996,7 @@ static int run_pass(mdh_renderer *r, int pass, hipStream_t st, int src, int dst,
          } else
          switch (pfk) {
          case MDH_PF_ROOM: launch_screen_m<MDH_PF_ROOM>(r, st, pr, vol, cam, a, blocks, pow2); break;
+         case MDH_PF_PART | MDH_PF_PSMALL: launch_screen_m<MDH_PF_PART | MDH_PF_PSMALL>(r, st, pr, vol, cam, a, blocks, pow2); break;
          case 0: launch_screen_m<0>(r, st, pr, vol, cam, a, blocks, pow2); break;
          case 1: launch_screen_m<1>(r, st, pr, vol, cam, a, blocks, pow2); break;
          case 2: launch_screen_m<2>(r, st, pr, vol, cam, a, blocks, pow2); break;

@@ -948,10 +948,10 @@ MDH_DEV int partition_cell(const KScene &sc, f3 x, bool &fallback)
    return (int)((fx.x * yz + fx.y * zz) + fx.z);
 }
 // (Border_Behavior = Clamp known when the kernel is built)
-MDH_DEV int partition_cell_clamped(const KScene &sc, f3 x)
+template <bool PSMALL = false> MDH_DEV int partition_cell_clamped(const KScene &sc, f3 x) // (PSMALL: MDH_PF_PSMALL below)
 {
    const f3 rel = x - F3(sc.part_off[0], sc.part_off[1], sc.part_off[2]);
-   const f3 fx = floor3(sc.part_sp_pow2 ? rel * F3(sc.part_inv_sp[0], sc.part_inv_sp[1], sc.part_inv_sp[2]) : rel / F3(sc.part_sp[0], sc.part_sp[1], sc.part_sp[2]));
+   const f3 fx = floor3((PSMALL || sc.part_sp_pow2) ? rel * F3(sc.part_inv_sp[0], sc.part_inv_sp[1], sc.part_inv_sp[2]) : rel / F3(sc.part_sp[0], sc.part_sp[1], sc.part_sp[2]));
 #if MDH_PART_CELL_TRIM
    // clamp (v, 0, d) = min (max (v, 0), d) as ONE instruction: v_med3_f32 is the median of its operands and, with a NaN among
    // them, their minNum -- 0 for v = NaN, as the two-instruction form gives (max (NaN, 0) = 0; d >= 0)
@@ -959,7 +959,7 @@ MDH_DEV int partition_cell_clamped(const KScene &sc, f3 x)
    const float yz = sc.part_fyz, zz = sc.part_fdims[2];
    // (every term and every partial sum is an integer below 2^24 for tables of fewer than 2^24 cells: the two fused forms round
    //  nothing that the four separate operations would not -- the same value with two instructions instead of four)
-   if (sc.part_cells < (1 << 24)) return (int)__builtin_fmaf(cfx.x, yz, __builtin_fmaf(cfx.y, zz, cfx.z));
+   if (PSMALL || sc.part_cells < (1 << 24)) return (int)__builtin_fmaf(cfx.x, yz, __builtin_fmaf(cfx.y, zz, cfx.z));
 #else
    const f3 cfx = F3(clamp_(fx.x, 0.0f, sc.part_fdims[0]), clamp_(fx.y, 0.0f, sc.part_fdims[1]), clamp_(fx.z, 0.0f, sc.part_fdims[2]));
    const float yz = sc.part_fyz, zz = sc.part_fdims[2];
@@ -968,10 +968,10 @@ MDH_DEV int partition_cell_clamped(const KScene &sc, f3 x)
 }
 // partitioning_closest[_info] (scenes.adb:839-1118): per-lane cell record from HBM/L2,
 // per-lane primitive gather from LDS
-template <bool INFO, bool CUSTOM, bool FALLBACK = true> MDH_DEV float partitioning_lookup(const KScene &sc, f3 x, int &index)
+template <bool INFO, bool CUSTOM, bool FALLBACK = true, bool PSMALL = false> MDH_DEV float partitioning_lookup(const KScene &sc, f3 x, int &index)
 {
    bool fb = false;
-   int cell = FALLBACK ? partition_cell(sc, x, fb) : partition_cell_clamped(sc, x);
+   int cell = FALLBACK ? partition_cell(sc, x, fb) : partition_cell_clamped<PSMALL>(sc, x);
    if (FALLBACK && fb) return INFO ? closest_primitive_info<CUSTOM>(sc, x, index) : closest_primitive<CUSTOM>(sc, x);
    float closest = sc.max_dist;
    if (cell < 0 || cell >= sc.part_cells) return closest;
@@ -1138,15 +1138,20 @@ template <int TYPE> MDH_DEV float walk_bits(unsigned w, const float4 *t, f3 x, f
 // FALLBACK: the kernel variant of scenes whose Border_Behavior is Fallback (a point outside the grid scans every
 // primitive, scenes.adb:943-957).  Scenes that clamp -- the reference's own -- run variants without that scan: inlined, its
 // loops sat in every march loop of the partition kernels (a quarter of their code).
-template <bool CUSTOM, bool FALLBACK> MDH_DEV float partitioning_closest_bits(const KScene &sc, f3 x)
+// PSMALL (MDH_PF_PSMALL): the kernel variant of scenes whose partition has the small form AND declares no triangles, with
+// power-of-two grid spacings, fewer than 2^24 cells and the Clamp border (every scene of the reference's examples) -- the form
+// and its census known when the kernel is built.  The same operations; what goes is the general form's loops over kinds (their
+// code, and the registers their state held across every march loop: 80 -> 69 VGPRs and 48 -> 16 bytes of scratch in the screen
+// kernel) and the tests of what a scene never changes.  A type without instances walks an empty word.
+template <bool CUSTOM, bool FALLBACK, bool PSMALL = false> MDH_DEV float partitioning_closest_bits(const KScene &sc, f3 x)
 {
    bool fb = false;
-   const int cell = FALLBACK ? partition_cell(sc, x, fb) : partition_cell_clamped(sc, x);
+   const int cell = FALLBACK ? partition_cell(sc, x, fb) : partition_cell_clamped<PSMALL>(sc, x);
    if (FALLBACK && fb) return closest_primitive<CUSTOM>(sc, x);
    float closest = sc.max_dist;
    if (cell < 0 || cell >= sc.part_cells) return closest;
    MDH_DIAG_STEP(5); // lookups that reach a cell
-   if (!CUSTOM && MDH_PART_SMALL && sc.part_small) { // (wave-uniform) straight-line code: one load, a shift and a mask per type
+   if (!CUSTOM && MDH_PART_SMALL && (PSMALL || sc.part_small)) { // (wave-uniform) straight-line code: one load, a shift and a mask per type
       typedef const unsigned long long __attribute__((address_space(1))) *GlobalPairs;
       const unsigned long long mm = ((GlobalPairs)(sc.part_table + sc.part_mask_off))[cell];
       // a type's candidates: 32 bits of the cell's 64 from bit part_tbit on -- one funnel shift (v_alignbit_b32) while the
@@ -1157,13 +1162,14 @@ template <bool CUSTOM, bool FALLBACK> MDH_DEV float partitioning_closest_bits(co
 #else
 #define MDH_TYPE_BITS(T) ((unsigned)(mm >> sc.part_tbit[T]) & sc.part_tmask[T])
 #endif
-      if (sc.part_tmask[PK_PLANE]) closest = walk_bits<PK_PLANE>(MDH_TYPE_BITS(PK_PLANE), s_tab + sc.tslot[PK_PLANE], x, closest);
-      if (sc.part_tmask[PK_SPHERE]) closest = walk_bits<PK_SPHERE>(MDH_TYPE_BITS(PK_SPHERE), s_tab + sc.tslot[PK_SPHERE], x, closest);
-      if (sc.part_tmask[PK_BOX]) closest = walk_bits<PK_BOX>(MDH_TYPE_BITS(PK_BOX), s_tab + sc.tslot[PK_BOX], x, closest);
-      if (sc.part_tmask[PK_TRIANGLE]) closest = walk_bits<PK_TRIANGLE>(MDH_TYPE_BITS(PK_TRIANGLE), s_tab + sc.tslot[PK_TRIANGLE], x, closest);
+      if (PSMALL || sc.part_tmask[PK_PLANE]) closest = walk_bits<PK_PLANE>(MDH_TYPE_BITS(PK_PLANE), s_tab + sc.tslot[PK_PLANE], x, closest);
+      if (PSMALL || sc.part_tmask[PK_SPHERE]) closest = walk_bits<PK_SPHERE>(MDH_TYPE_BITS(PK_SPHERE), s_tab + sc.tslot[PK_SPHERE], x, closest);
+      if (PSMALL || sc.part_tmask[PK_BOX]) closest = walk_bits<PK_BOX>(MDH_TYPE_BITS(PK_BOX), s_tab + sc.tslot[PK_BOX], x, closest);
+      if (!PSMALL && sc.part_tmask[PK_TRIANGLE]) closest = walk_bits<PK_TRIANGLE>(MDH_TYPE_BITS(PK_TRIANGLE), s_tab + sc.tslot[PK_TRIANGLE], x, closest);
 #undef MDH_TYPE_BITS
       return closest;
    }
+   if (PSMALL) return closest; // (never reached: the variant is only launched for scenes of the small form)
    typedef const unsigned __attribute__((address_space(1))) *GlobalWords;
    const int nk = hdr(H_NK), nw = sc.part_mask_words;
    const bool in_lds = sc.part_bits_f4 > 0; // (wave-uniform: the whole grid's bits are staged behind the scene table)
@@ -1211,6 +1217,7 @@ template <bool CUSTOM, bool FALLBACK> MDH_DEV float partitioning_closest_bits(co
 #define MDH_PF_CUSTOM 2
 #define MDH_PF_POW2 4 // bit 2 = the probe counts and both tile resolutions are powers of two (every atlas address is shifts and masks)
 #define MDH_PF_FALLBACK 8 // bit 3 = the space partition's Border_Behavior is Fallback (built-in kinds; scenes with user-defined kinds keep the run-time test)
+#define MDH_PF_PSMALL 32 // bit 5 = the space partition's small form and its census, known when the kernel is built (partitioning_closest_bits' PSMALL; with bit 0, never with bits 1 or 3)
 #define MDH_PF_ROOM 16 // bit 4 = the census of the reference's rooms, known when the kernel is built (closest_primitive's ROOM; never with bits 0, 1 or 3)
 // does this variant carry the full scan of the Fallback border?
 #define MDH_PF_HAS_FALLBACK(PART) ((((PART) & MDH_PF_FALLBACK) != 0) || (((PART) & MDH_PF_CUSTOM) != 0))
@@ -1219,7 +1226,7 @@ template <int PART> MDH_DEV float sdf(const KScene &sc, f3 x)
    MDH_WORK(2);
    int dummy;
    (void)dummy;
-   if (PART & MDH_PF_PART) return MDH_PART_BITS ? partitioning_closest_bits<(PART & MDH_PF_CUSTOM) != 0, MDH_PF_HAS_FALLBACK(PART)>(sc, x) : partitioning_lookup<false, (PART & MDH_PF_CUSTOM) != 0, MDH_PF_HAS_FALLBACK(PART)>(sc, x, dummy);
+   if (PART & MDH_PF_PART) return MDH_PART_BITS ? partitioning_closest_bits<(PART & MDH_PF_CUSTOM) != 0, MDH_PF_HAS_FALLBACK(PART), (PART & MDH_PF_PSMALL) != 0>(sc, x) : partitioning_lookup<false, (PART & MDH_PF_CUSTOM) != 0, MDH_PF_HAS_FALLBACK(PART), (PART & MDH_PF_PSMALL) != 0>(sc, x, dummy);
    return closest_primitive<(PART & MDH_PF_CUSTOM) != 0, (PART & MDH_PF_ROOM) != 0>(sc, x);
 }
 // the same with the first sphere and box already in registers (sdf_regs)
@@ -1228,13 +1235,13 @@ template <int PART> MDH_DEV float sdf(const KScene &sc, f3 x, const SdfRegs &reg
    MDH_WORK(2);
    int dummy;
    (void)dummy;
-   if (PART & MDH_PF_PART) return MDH_PART_BITS ? partitioning_closest_bits<(PART & MDH_PF_CUSTOM) != 0, MDH_PF_HAS_FALLBACK(PART)>(sc, x) : partitioning_lookup<false, (PART & MDH_PF_CUSTOM) != 0, MDH_PF_HAS_FALLBACK(PART)>(sc, x, dummy);
+   if (PART & MDH_PF_PART) return MDH_PART_BITS ? partitioning_closest_bits<(PART & MDH_PF_CUSTOM) != 0, MDH_PF_HAS_FALLBACK(PART), (PART & MDH_PF_PSMALL) != 0>(sc, x) : partitioning_lookup<false, (PART & MDH_PF_CUSTOM) != 0, MDH_PF_HAS_FALLBACK(PART), (PART & MDH_PF_PSMALL) != 0>(sc, x, dummy);
    return closest_primitive<(PART & MDH_PF_CUSTOM) != 0, (PART & MDH_PF_ROOM) != 0>(sc, x, &regs);
 }
 template <int PART> MDH_DEV float sdf_info(const KScene &sc, f3 x, int &index)
 {
    MDH_WORK(2);
-   if (PART & MDH_PF_PART) return partitioning_lookup<true, (PART & MDH_PF_CUSTOM) != 0, MDH_PF_HAS_FALLBACK(PART)>(sc, x, index);
+   if (PART & MDH_PF_PART) return partitioning_lookup<true, (PART & MDH_PF_CUSTOM) != 0, MDH_PF_HAS_FALLBACK(PART), (PART & MDH_PF_PSMALL) != 0>(sc, x, index);
    return closest_primitive_info<(PART & MDH_PF_CUSTOM) != 0>(sc, x, index);
 }
 

@@ -39,7 +39,7 @@
 // The variants for the census of the reference's rooms (MDH_PF_ROOM) need 80 registers where the general scan needs 96: six
 // wavefronts per SIMD without a further spill (measured at config 3: five 5 681 - 5 726, six 5 818 - 5 863 Mpixels/s in flight).
 #ifndef MDH_ROOM_VARIANTS
-#define MDH_ROOM_VARIANTS 1 // (0: scenes with the rooms' census run the general scan -- A/B runs, and the literal build)
+#define MDH_ROOM_VARIANTS 1 // (0: no scene is given a kernel variant built for its census, MDH_PF_ROOM / MDH_PF_PSMALL -- A/B runs)
 #endif
 #ifndef MDH_ROOM_WAVES_PER_SIMD
 #define MDH_ROOM_WAVES_PER_SIMD 6
