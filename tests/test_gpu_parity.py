@@ -792,3 +792,34 @@ def test_split_tiles_change_no_pixel(hip, scene, mode, world):
             assert (px_a == px_b).all()
     with pytest.raises(B.MadarchError):
         make(scene, 16, 16, hip, mode=mode, probes=SMALL_PROBES).Set_Option(B.OPT_SCREEN_SPLIT, -1)
+
+
+@pytest.mark.parametrize("scene", ["global_illumination", "light_shafts", "simple_scene"])
+def test_census_variants_follow_the_scene(hip, orc, scene):
+    """The kernels exist once more for the censuses the reference's scenes have (MDH_PF_ROOM: every plane folded, one sphere,
+    one box; MDH_PF_PSMALL: the partition's small form), chosen per pass from the committed scene.  Frames in flight while
+    the rooms LEAVE their census -- a second sphere, then a second box: the general kernels take over between two passes --
+    and while simple_scene is edited and its tables rebuilt inside its own: every stage is the oracle's."""
+    from madarch_amd.primitives import boxes, spheres
+    runs = []
+    for b in (hip, orc):
+        R = make(scene, 88, 56, b, probes=SMALL_PROBES)
+        shots = [snapshot(R, 3)]
+        if scene == "simple_scene":  # (stays within the small form: its variant under edits and rebuilt tables)
+            R.Set_Primitive(spheres.Sphere, 1, spheres.Create((1.5, 1.0, 4.5), 0.6, 1))  # (every declared instance is in use: moved, not added)
+            R.Update_Partitioning(Method=renderers.GPU_Fast)
+            shots.append(snapshot(R, 3))
+            R.Set_Primitive(boxes.Box, 1, boxes.Create((4.5, 0.5, 1.5), (0.5, 0.5, 0.5), 2))
+            R.Update_Partitioning(Method=renderers.CPU_Fast)
+            shots.append(snapshot(R, 3))
+        else:
+            s2 = R.Add_Primitive(spheres.Sphere, spheres.Create((1.5, 1.0, 4.5), 0.6, 1))
+            shots.append(snapshot(R, 3))  # two spheres: no room any more
+            b2 = R.Add_Primitive(boxes.Box, boxes.Create((4.5, 0.5, 1.5), (0.5, 0.5, 0.5), 2))
+            shots.append(snapshot(R, 3))
+            assert s2 is not None and b2 is not None
+        runs.append(shots)
+        R.Destroy()
+    for got, want in zip(*runs):
+        assert_parity(got, want)
+    assert not same_bits(runs[1][0]["image"], runs[1][1]["image"])  # (the edits are visible)
