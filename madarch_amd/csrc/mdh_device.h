@@ -290,6 +290,26 @@ MDH_DEV float sqrt_wave_(float x)
    return sqrt_(x);
 #endif
 }
+// Two correctly rounded roots at once (the rooms' scan: its one sphere and its one box), the two nine-instruction cores
+// interleaved: a core's comparisons each wait two slots for their select (a vector comparison's mask is not forwarded), and
+// a core alone has nothing to put there -- the other core's instructions go there, and one wave-wide guard serves both.
+// The same nine operations per operand: the same bits.
+MDH_DEV void sqrt2_(float a, float b, float &ra, float &rb)
+{
+#if MDH_FAST_NUMERICS
+   ra = __builtin_amdgcn_sqrtf(a); rb = __builtin_amdgcn_sqrtf(b);
+   return;
+#endif
+   if (__ballot(min_(a, b) < 0x1p-96f) != 0ull) { ra = __builtin_sqrtf(a); rb = __builtin_sqrtf(b); return; } // (a zero goes the slow way too: never in a march)
+   float sa = __builtin_amdgcn_sqrtf(a), sb = __builtin_amdgcn_sqrtf(b);
+   const int ia = __float_as_int(sa), ib = __float_as_int(sb);
+   const float sda = __int_as_float(ia - 1), sdb = __int_as_float(ib - 1), sua = __int_as_float(ia + 1), sub = __int_as_float(ib + 1);
+   const float vpa = __builtin_fmaf(-sda, sa, a), vpb = __builtin_fmaf(-sdb, sb, b), vsa = __builtin_fmaf(-sua, sa, a), vsb = __builtin_fmaf(-sub, sb, b);
+   const bool ca = vpa <= 0.0f, cb = vpb <= 0.0f, ea = vsa > 0.0f, eb = vsb > 0.0f;
+   sa = ca ? sda : sa; sb = cb ? sdb : sb;
+   sa = ea ? sua : sa; sb = eb ? sub : sb;
+   ra = sa; rb = sb;
+}
 // MDH_HYBRID_NUMERICS: the second LABELLED EXPERIMENT (`make -C madarch_amd/csrc hybrid`; never the shipped
 // library): every operation INSIDE a march loop and the whole primary ray (geometry buffer: index, t, steps) stay as exact
 // as in the shipped build; what SHADES a point behind a hit -- normals, the BRDF, light attenuation, probe directions and
@@ -731,6 +751,9 @@ MDH_DEV float prim_dist(int type, int slot, f3 x)
 #ifndef MDH_SDF_PREFETCH
 #define MDH_SDF_PREFETCH 1
 #endif
+#ifndef MDH_ROOM_SQRT2
+#define MDH_ROOM_SQRT2 0 // the rooms' scan evaluates its sphere and its box together, their square-root cores interleaved (sqrt2_)
+#endif
 #ifndef MDH_SDF_SGPR
 #define MDH_SDF_SGPR 0
 #endif
@@ -775,6 +798,23 @@ template <bool CUSTOM, bool ROOM = false> MDH_DEV float closest_primitive(const 
       closest = min_(closest, min_(x.y + sc.axis_off[2], -x.y + sc.axis_off[3]));
       closest = min_(closest, min_(x.z + sc.axis_off[4], -x.z + sc.axis_off[5]));
    }
+#if MDH_ROOM_SQRT2
+   if (ROOM) { // the one sphere and the one box together (sqrt2_ above); the box's cull against the minimum BEFORE the sphere: never less careful
+      const float d2 = dot2(xyz(pf_s) - x);
+      const float tsum = closest + pf_s.w;
+      const bool need_s = !(tsum < 0.0f) && !(d2 > (tsum * tsum) * 1.000001f);
+      const f3 q = abs3(xyz(pf_b0) - x) - xyz(pf_b1);
+      const float m = max_(q.x, max_(q.y, q.z));
+      const float thr = closest > 0.0f ? closest * 1.000001f : closest;
+      if (!MDH_CULL || __ballot(need_s || !(m > thr)) != 0ull) {
+         float rs, rb;
+         sqrt2_(d2, dot2(F3(max0_raw(q.x), max0_raw(q.y), max0_raw(q.z))), rs, rb);
+         closest = min_raw(closest, rs - pf_s.w);
+         closest = min_raw(closest, rb + min0_raw(m));
+      }
+      return closest;
+   }
+#endif
    {
       const int n = ROOM ? 0 : sc.gplane_count, s0 = sc.gplane_slot;
 #pragma unroll MDH_SDF_UNROLL
