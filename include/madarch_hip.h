@@ -259,8 +259,9 @@ enum {
    MDH_OPT_RADIANCE_MIPS = 17,
    /* Scheduling only, no effect on any pixel: a screen launch whose tiles, as two or four wavefronts each (8x4 or 4x4
     * pixels: 32 or 16 of a wavefront's 64 lanes), stay within `value` wavefronts is launched that way -- a launch that
-    * leaves the chip's wavefront slots empty (a rank's tiles of a sharded frame, a small window) lasts as long as its slowest
-    * wavefront, which then marches for a quarter of the tile only, and the tile's work runs on four SIMDs.  Default 2560
+    * leaves the chip's wavefront slots empty (a small window) lasts as long as its slowest
+    * wavefront, which then marches for a quarter of the tile only, and the tile's work runs on four SIMDs (whole frames only: a
+    * rank's scattered tiles of a sharded frame measured no faster).  Default 2560
     * (half the slots of an MI355X at five wavefronts per SIMD); 0 = every tile one wavefront.  Launches of 2 048 tiles and
     * more (MDH_OPT_SCREEN_ORDER's) are never split. */
    MDH_OPT_SCREEN_SPLIT = 18

@@ -1978,7 +1978,7 @@ static int run_pass(mdh_renderer *r, int pass, hipStream_t st, int src, int dst,
       // two or four wavefronts; never with a tile order (launches of 2 048 tiles and more)
       a.split = 0;
       a.split_first = 0;
-      if (!a.order && !a.cost && r->opt_scr_split > 0) {
+      if (!a.order && !a.cost && r->opt_scr_split > 0 && a.world == 1) { // (a rank's scattered tiles of a sharded frame: measured 1 - 3 % slower split, profiles/r04_x_split_tiles.log)
          if ((long)own_tiles * 4 <= r->opt_scr_split) a.split = 2;
          else if ((long)own_tiles * 2 <= r->opt_scr_split) a.split = 1;
       }

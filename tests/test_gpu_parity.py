@@ -765,7 +765,8 @@ def test_split_tiles_change_no_pixel(hip, scene, mode, world):
     """MDH_OPT_SCREEN_SPLIT: a screen launch that leaves the chip's wavefront slots empty gives every 8x8 tile to two
     wavefronts of 8x4 pixels or four of 4x4 (the other lanes idle).  HOW MANY wavefronts draw a tile, never what it holds:
     framebuffer, geometry buffer and window pixels are those of one wavefront per tile -- both split factors, partial
-    tiles at the right and lower edge, a rank's tiles, frames in flight."""
+    tiles at the right and lower edge, frames in flight; a rank's tiles of a sharded frame are never split (the same
+    pixels whatever the limit)."""
     outs = []
     # 27 x 18 = 486 tiles, the last column and row partial: 4 x 486 <= 2560 (quadrants), 2 x 486 <= 1000 (halves), 0 (whole tiles)
     for limit in (0, 2560, 1000):
